@@ -1,0 +1,351 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference (this container only).
+
+TEST INFRASTRUCTURE -- never imported by the product.  /root/reference does not exist on the GPU
+box; only the small .npz files this script writes travel there.
+
+What is pinned and how the reference is driven:
+  * `radae.radae_base.n` (radae_base.py:80-81) is replaced by clamp-only: the reference adds
+    uniform noise in eval mode, which makes it non-deterministic.
+  * weights: `weights/model19_check3.bin` (byte copy of /root/reference/bin/model19_check3.bin)
+    de-quantised by radae_amd.dnnw and loaded into the reference's own torch modules.
+  * `np.random.randint` (used unseeded by dsp.py:293) is replaced by the documented LCG
+    x <- x*1664525+1013904223 mod 2^32, row = (x>>8) % Nmf, seed 1.
+  * channel noise: `RADAE.forward` draws torch.randn_like internally (radae.py:578); we re-seed
+    torch and regenerate the identical tensor so the fixture can carry the noise explicitly.
+
+Run:  python3 oracle/gen_golden.py            (takes ~1 min)
+"""
+import os
+import sys
+
+REF = "/root/reference"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+torch.set_num_threads(1)
+
+import radae.radae_base as rb
+
+rb.n = lambda x: torch.clamp(x, min=-1.0, max=1.0)
+
+os.chdir(REF)  # reference modules print to stderr and expect cwd-relative imports
+import radae_txe  # noqa: E402
+import radae_rxe  # noqa: E402
+from radae import RADAE, distortion_loss  # noqa: E402
+
+from radae_amd import dnnw  # noqa: E402
+from radae_amd.channel_tools import multipath_g, synth_features  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+BLOB = os.path.join(REPO, "weights", "model19_check3.bin")
+
+
+class Lcg:
+    def __init__(self, seed=1):
+        self.x = seed & 0xFFFFFFFF
+
+    def randint(self, n):
+        self.x = (self.x * 1664525 + 1013904223) & 0xFFFFFFFF
+        return (self.x >> 8) % n
+
+
+_lcg = Lcg(1)
+np.random.randint = lambda n: _lcg.randint(n)
+
+
+def load_into(model, m):
+    """De-quantised blob tensors -> reference torch modules."""
+    enc = model.core_encoder.module
+    dec = model.core_decoder.module
+    T = torch.tensor
+    with torch.no_grad():
+        enc.dense_1.weight.copy_(T(m.enc_dense1.w)); enc.dense_1.bias.copy_(T(m.enc_dense1.b))
+        enc.z_dense.weight.copy_(T(m.enc_zdense.w)); enc.z_dense.bias.copy_(T(m.enc_zdense.b))
+        dec.dense_1.weight.copy_(T(m.dec_dense1.w)); dec.dense_1.bias.copy_(T(m.dec_dense1.b))
+        dec.output.weight.copy_(T(m.dec_output.w)); dec.output.bias.copy_(T(m.dec_output.b))
+        for i in range(5):
+            for mod, G, C in ((enc, m.enc_gru[i], m.enc_conv[i]), (dec, m.dec_gru[i], m.dec_conv[i])):
+                g = getattr(mod, f"gru{i+1}")
+                g.weight_ih_l0.copy_(T(G.w_ih)); g.weight_hh_l0.copy_(T(G.w_hh))
+                g.bias_ih_l0.copy_(T(G.b_ih)); g.bias_hh_l0.copy_(T(G.b_hh))
+                c = getattr(mod, f"conv{i+1}").conv
+                c.weight.copy_(T(C.w)); c.bias.copy_(T(C.b))
+            gate = getattr(dec, f"glu{i+1}").gate
+            W = T(m.dec_glu[i].w)
+            gate.parametrizations.weight.original1.copy_(W)
+            gate.parametrizations.weight.original0.copy_(W.norm(dim=1, keepdim=True))
+    model.core_encoder_statefull_load_state_dict()
+    model.core_decoder_statefull_load_state_dict()
+
+
+def c64(x):
+    return np.asarray(x).astype(np.complex64)
+
+
+def with_aux(feat36):
+    """(T,36) -> (1,T,21) with the aux symbol -1 appended (radae_txe.py:114-121)."""
+    f = feat36[:, :20]
+    return torch.tensor(np.concatenate([f, -np.ones((f.shape[0], 1), np.float32)], axis=1)[None])
+
+
+M19 = dnnw.load_model(BLOB)
+
+
+def new_tx():
+    tx = radae_txe.radae_tx("unused", bypass_enc=True)
+    tx.bypass_enc = False
+    tx.n_floats_in = 432
+    load_into(tx.model, M19)
+    return tx
+
+
+def new_rx():
+    rx = radae_rxe.radae_rx("unused", bypass_dec=True, v=0)
+    rx.bypass_dec = False
+    rx.n_floats_out = 432
+    load_into(rx.model, M19)
+    _lcg.x = 1
+    return rx
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_consts():
+    tx = new_tx()
+    rx = new_rx()
+    md = tx.model
+    rng = np.random.default_rng(65647)
+    bits = np.sign(rng.random(180) - 0.5).astype(np.float32)
+    eoo_default = c64(md.eoo.numpy().flatten())
+    md.set_eoo_bits(torch.tensor(bits))
+    eoo_bits = c64(md.eoo.numpy().flatten())
+    np.savez(
+        os.path.join(OUT, "consts.npz"),
+        w=md.w.numpy().astype(np.float32), Winv=c64(md.Winv.numpy()), Wfwd=c64(md.Wfwd.numpy()),
+        P=c64(md.P.numpy()), Pend=c64(md.Pend.numpy()), p=c64(md.p.numpy()), pend=c64(md.pend.numpy()),
+        p_cp=c64(md.p_cp.numpy()), pend_cp=c64(md.pend_cp.numpy()),
+        pilot_gain=np.float64(md.pilot_gain),
+        eoo_default=eoo_default, eoo_bits_in=bits, eoo_with_bits=eoo_bits,
+        Pmat=c64(rx.receiver.Pmat.numpy()),
+        bpf_h=c64(rx.bpf.h), bpf_alpha=np.float64(rx.bpf.alpha), bpf_phase_vec_exp=c64(rx.bpf.phase_vec_exp[:1120]),
+        acq_p_w=c64(rx.acq.p_w), acq_fcoarse=rx.acq.fcoarse_range.astype(np.float64), acq_sigma_p=np.float64(rx.acq.sigma_p),
+        Nmf=np.int32(rx.Nmf), Nmf_unsync=np.int32(rx.Nmf_unsync),
+    )
+    print("consts ok")
+
+
+def gen_weights_check():
+    d = {}
+    def add(name, a):
+        a = np.asarray(a, dtype=np.float64).ravel()
+        d[name] = np.array([a.size, a.sum(), np.abs(a).sum()] + list(a[:8]) + list(a[-4:]))
+    m = M19
+    add("enc_dense1_w", m.enc_dense1.w); add("enc_dense1_b", m.enc_dense1.b)
+    add("enc_zdense_w", m.enc_zdense.w); add("enc_zdense_b", m.enc_zdense.b)
+    add("dec_dense1_w", m.dec_dense1.w); add("dec_dense1_b", m.dec_dense1.b)
+    add("dec_output_w", m.dec_output.w); add("dec_output_b", m.dec_output.b)
+    for i in range(5):
+        for side, grus, convs in (("enc", m.enc_gru, m.enc_conv), ("dec", m.dec_gru, m.dec_conv)):
+            g = grus[i]; c = convs[i]
+            add(f"{side}_gru{i+1}_w_ih", g.w_ih); add(f"{side}_gru{i+1}_w_hh", g.w_hh)
+            add(f"{side}_gru{i+1}_b_ih", g.b_ih); add(f"{side}_gru{i+1}_b_hh", g.b_hh)
+            # conv flattened as [out][k][in] (tap-major) which is the C layout
+            add(f"{side}_conv{i+1}_w", c.w.transpose(0, 2, 1)); add(f"{side}_conv{i+1}_b", c.b)
+        add(f"dec_glu{i+1}_w", m.dec_glu[i].w)
+    np.savez(os.path.join(OUT, "weights_check.npz"), **d)
+    print("weights_check ok")
+
+
+def gen_enc_tx():
+    """Encoder (stateful, 12 frames per call = radae_txe.do_radae_tx) + transmitter_one."""
+    nutt, T = 2, 120
+    feats = np.stack([synth_features(100 + u, T) for u in range(nutt)])  # (2,120,36)
+    z_all, tx_all, z_stateless = [], [], []
+    for u in range(nutt):
+        tx = new_tx()
+        out = np.zeros(960, np.csingle)
+        zs, txs = [], []
+        enc = tx.model.core_encoder_statefull
+        orig = enc.forward
+        def hook(x, _o=orig, _zs=zs):
+            z = _o(x); _zs.append(z.detach().numpy().copy()); return z
+        enc.forward = hook
+        for k in range(T // 12):
+            tx.do_radae_tx(feats[u, 12 * k:12 * k + 12].flatten(), out)
+            txs.append(out.copy())
+        enc.forward = orig
+        z_all.append(np.concatenate(zs, axis=1)[0])
+        tx_all.append(np.stack(txs))
+        with torch.inference_mode():
+            z_stateless.append(tx.model.core_encoder(with_aux(feats[u])).numpy()[0])
+        if u == 0:
+            mod = tx.model.core_encoder_statefull.module
+            gru_states = np.stack([getattr(mod, f"gru{i}").states.numpy().reshape(-1) for i in range(1, 6)])
+            conv_states = [getattr(mod, f"conv{i}").states.numpy()[0] for i in range(1, 6)]
+    np.savez(os.path.join(OUT, "enc_tx.npz"), features=feats, z=np.stack(z_all).astype(np.float32),
+             z_stateless=np.stack(z_stateless).astype(np.float32), tx=c64(np.stack(tx_all)),
+             gru_states_u0=gru_states.astype(np.float32),
+             **{f"conv{i+1}_state_u0": conv_states[i].astype(np.float32) for i in range(5)})
+    d = np.abs(np.stack(z_all) - np.stack(z_stateless)).max()
+    print(f"enc_tx ok  (stateful vs stateless max diff {d:.2e})")
+
+
+def channel_case(name, T, EbNodB, freq_offset, chan, seed, prepend_s=1.0, append_s=0.3, df_dt=0.0):
+    """inference.py-equivalent channel simulation through the reference's RADAE.forward
+    (radae.py:457-602) + the write_rx tail of inference.py:253-290."""
+    feat36 = synth_features(seed, T)
+    model = RADAE(21, 80, EbNodB, rate_Fs=True, freq_offset=freq_offset, df_dt=df_dt, pilots=True, pilot_eq=True,
+                  eq_mean6=False, cyclic_prefix=0.004, time_offset=-16, coarse_mag=True, bottleneck=3,
+                  correct_freq_offset=True)
+    load_into(model, M19)
+    model.eval()
+    features = with_aux(feat36)
+    nRs = model.num_timesteps_at_rate_Rs(T)
+    nFs = model.num_timesteps_at_rate_Fs(nRs)
+    H = torch.ones((1, nRs, model.Nc))
+    if chan == "awgn":
+        G = np.ones((nFs, 2), np.complex64); G[:, 1] = 0
+    else:
+        G = multipath_g(chan, 8000, nFs, seed + 7)
+    Gt = torch.tensor(G[None])
+    torch.manual_seed(seed)
+    with torch.inference_mode():
+        out = model(features, H, Gt)
+    torch.manual_seed(seed)
+    noise = torch.randn(1, nFs, dtype=torch.complex64)
+    sigma = float(out["sigma"].item())
+    rx = out["rx"]
+    assert torch.allclose(rx, (rx - sigma * noise) + sigma * noise)
+    # write_rx tail: EOO with continued phase, then real-valued pre/post noise (inference.py:263-284)
+    eoo = model.eoo
+    freq = torch.zeros_like(eoo)
+    freq[:, ] = model.freq_offset * torch.ones_like(eoo) + model.df_dt * torch.arange(eoo.shape[1]) / model.Fs
+    omega = freq * 2 * torch.pi / model.Fs
+    lin_phase = torch.exp(1j * torch.cumsum(omega, dim=1))
+    eoo_rot = eoo * lin_phase * model.final_phase
+    n_eoo = torch.randn_like(eoo_rot)
+    eoo_rx = eoo_rot + sigma * n_eoo
+    n_pre = torch.randn(1, int(model.Fs * prepend_s))
+    n_post = torch.randn(1, int(model.Fs * append_s))
+    rx_full = torch.concatenate([sigma * n_pre, rx, eoo_rx, sigma * n_post], dim=1)
+    d = dict(features=feat36, G=G, noise=c64(noise.numpy()[0]), sigma=np.float64(sigma),
+             EbNodB=np.float64(EbNodB), freq_offset=np.float64(freq_offset), df_dt=np.float64(df_dt),
+             tx=c64(out["tx"].numpy()[0]), rx=c64(rx.numpy()[0]), noise_eoo=c64(n_eoo.numpy()[0]),
+             noise_pre=n_pre.numpy()[0].astype(np.float32), noise_post=n_post.numpy()[0].astype(np.float32),
+             rx_full=c64(rx_full.numpy()[0]), z_fwd=out["z_hat"].numpy()[0].astype(np.float32),
+             final_phase=c64(model.final_phase.numpy()))
+    return d
+
+
+def run_rx(rx_stream, foff_err=0.0):
+    """Drive the reference radae_rx exactly like radae_rxe.py:349-356 and record a per-call trace."""
+    rx = new_rx()
+    rx.foff_err = foff_err
+    zlog = []
+    orig = rx.receiver.receiver_one
+    def hook(r, eoo, _o=orig):
+        z = _o(r, eoo); zlog.append(z.detach().numpy().reshape(-1).copy()); return z
+    rx.receiver.receiver_one = hook
+    floats_out = np.zeros(432, np.float32)
+    names = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count",
+             "uw_errors", "synced_count", "snr_int"]
+    tr = {k: [] for k in names}
+    trf = {k: [] for k in ["fmax", "Dthresh", "Dtmax12", "Dtmax12_eoo", "snrdB_3k_est"]}
+    z_hat, feats_out, eoo_out = [], [], []
+    st = {"search": 0, "candidate": 1, "sync": 2}
+    pos = 0
+    while pos + rx.get_nin() <= len(rx_stream):
+        nin = rx.get_nin()
+        buf = np.zeros(rx.get_nin_max(), np.csingle)
+        buf[:nin] = rx_stream[pos:pos + nin]
+        pos += nin
+        sb = st[rx.state]
+        nz = len(zlog)
+        ret = rx.do_radae_rx(buf, floats_out)
+        tr["state_before"].append(sb); tr["state_after"].append(st[rx.state])
+        tr["nin_before"].append(nin); tr["nin_after"].append(rx.get_nin()); tr["ret"].append(int(ret))
+        tr["tmax"].append(int(rx.tmax)); tr["f_ind_max"].append(int(rx.acq.f_ind_max) if hasattr(rx.acq, "f_ind_max") else -1)
+        tr["valid_count"].append(int(rx.valid_count)); tr["uw_errors"].append(int(rx.uw_errors))
+        tr["synced_count"].append(int(rx.synced_count)); tr["snr_int"].append(int(rx.get_snrdB_3k_est()))
+        trf["fmax"].append(float(rx.fmax)); trf["Dthresh"].append(float(rx.acq.Dthresh))
+        trf["Dtmax12"].append(float(rx.acq.Dtmax12)); trf["Dtmax12_eoo"].append(float(rx.acq.Dtmax12_eoo))
+        trf["snrdB_3k_est"].append(float(rx.receiver.snrdB_3k_est))
+        if ret & 1:
+            z_hat.append(zlog[-1].copy()); feats_out.append(floats_out.copy())
+        if ret & 2:
+            eoo_out.append(floats_out[:180].copy())
+    d = {k: np.array(v, np.int32) for k, v in tr.items()}
+    d.update({k: np.array(v, np.float64) for k, v in trf.items()})
+    d["z_hat"] = np.array(z_hat, np.float32).reshape(-1, 240)
+    d["features_out"] = np.array(feats_out, np.float32).reshape(-1, 432)
+    d["eoo_out"] = np.array(eoo_out, np.float32).reshape(-1, 180)
+    return d
+
+
+def gen_chan_rx():
+    from scipy.signal import resample_poly
+    cases = {
+        # name: (T frames, EbNodB, freq_offset, channel, seed, prepend_s)
+        "mpp": (240, 3.0, -11.0, "mpp", 1000, 1.0),       # config 3 / ctest radae_rx_mpp
+        "awgn": (168, 10.0, 11.0, "awgn", 1001, 1.0),     # ctest radae_rx_basic
+    }
+    for name, (T, eb, fo, ch, seed, pre) in cases.items():
+        d = channel_case(name, T, eb, fo, ch, seed, prepend_s=pre)
+        tr = run_rx(d["rx_full"])
+        np.savez_compressed(os.path.join(OUT, f"chan_{name}.npz"), **d)
+        np.savez_compressed(os.path.join(OUT, f"rxtrace_{name}.npz"), rx_in=d["rx_full"], features_in=d["features"], **tr)
+        print(f"chan/rx {name}: calls {len(tr['ret'])} valid {int((tr['ret'] & 1).sum())} eoo {int((tr['ret'] >> 1).sum())}"
+              f" states {tr['state_after'].tolist()}")
+    # timing slips (ctests radae_rx_slip_plus / _minus) -- sox is absent, scipy polyphase resampler instead
+    for name, (up, dn, pre) in {"slip_plus": (1601, 1600, 0.06425), "slip_minus": (1599, 1600, 0.10675)}.items():
+        d = channel_case(name, 480, 10.0, 11.0, "awgn", 1002, prepend_s=pre, append_s=0.3)
+        x = d["rx_full"]
+        xr = (resample_poly(x.real.astype(np.float64), up, dn) + 1j * resample_poly(x.imag.astype(np.float64), up, dn)).astype(np.complex64)
+        tr = run_rx(xr)
+        np.savez_compressed(os.path.join(OUT, f"rxtrace_{name}.npz"), rx_in=xr, features_in=d["features"], **tr)
+        print(f"rx {name}: calls {len(tr['ret'])} valid {int((tr['ret'] & 1).sum())} nin set {sorted(set(tr['nin_after'].tolist()))}"
+              f" tmax range {tr['tmax'].min()}..{tr['tmax'].max()}")
+    # false-sync / UW failure path: rade_api.c:263-264 RADE_FOFF_TEST => foff_err = 10 Hz on first sync
+    d = channel_case("foff", 240, 10.0, 11.0, "awgn", 1003, prepend_s=0.5)
+    tr = run_rx(d["rx_full"], foff_err=10.0)
+    np.savez_compressed(os.path.join(OUT, "rxtrace_foff.npz"), rx_in=d["rx_full"], features_in=d["features"], **tr)
+    print(f"rx foff: states {tr['state_after'].tolist()} uw {tr['uw_errors'].tolist()}")
+
+
+def gen_dec_loss():
+    rng = np.random.default_rng(5)
+    g = np.load(os.path.join(OUT, "rxtrace_awgn.npz"))
+    z = g["z_hat"][:10].reshape(1, 30, 80)
+    rx = new_rx()
+    dec = rx.model.core_decoder_statefull
+    outs = []
+    with torch.inference_mode():
+        for k in range(10):
+            outs.append(dec(torch.tensor(z[:, 3 * k:3 * k + 3])).numpy()[0])
+        stateless = rx.model.core_decoder(torch.tensor(z)).numpy()[0]
+    feats = np.concatenate(outs)  # (120,21)
+    mod = dec.module
+    gru_states = np.stack([getattr(mod, f"gru{i}").states.numpy().reshape(-1) for i in range(1, 6)])
+    a = torch.tensor(rng.standard_normal((1, 50, 20)).astype(np.float32))
+    b = torch.tensor(rng.standard_normal((1, 50, 20)).astype(np.float32))
+    a21 = torch.tensor(rng.standard_normal((1, 50, 21)).astype(np.float32))
+    b21 = torch.tensor(rng.standard_normal((1, 50, 21)).astype(np.float32))
+    np.savez(os.path.join(OUT, "dec_loss.npz"), z_hat=z[0].astype(np.float32), features=feats.astype(np.float32),
+             features_stateless=stateless.astype(np.float32), gru_states=gru_states.astype(np.float32),
+             la=a.numpy()[0], lb=b.numpy()[0], loss20=np.float64(distortion_loss(a, b).item()),
+             la21=a21.numpy()[0], lb21=b21.numpy()[0], loss21=np.float64(distortion_loss(a21, b21).item()))
+    print(f"dec ok (stateful vs stateless max diff {np.abs(feats - stateless).max():.2e})")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec"]
+    if "consts" in which: gen_consts()
+    if "weights" in which: gen_weights_check()
+    if "enc" in which: gen_enc_tx()
+    if "chanrx" in which: gen_chan_rx()
+    if "dec" in which: gen_dec_loss()

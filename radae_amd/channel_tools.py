@@ -1,0 +1,88 @@
+"""Host-side channel tooling: Watterson/Doppler-spread sample generator and synthetic features.
+
+Restates (numpy only, no Octave/scipy dependency at run time)
+  * `/root/reference/doppler_spread.m:7-50`  -- Gaussian-PSD filtered complex noise at a low
+    sample rate, linearly interpolated up to Fs,
+  * `/root/reference/multipath_samples.m:10-31` -- channel presets (mpg/mpp/mpd) and the
+    `hf_gain = 1/sqrt(var(G1)+var(G2))` normalisation,
+and the synthetic 20-dim vocoder-feature generator fixed in SURVEY.md section 8(d).
+
+G is an *input* of the channel model (`radae/radae.py:529-539` takes it as a tensor), so the exact
+FIR design (Octave `fir2`) is not part of the parity contract; only the statistics matter.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+PRESETS = {  # multipath_samples.m:10-16  (doppler spread Hz, path delay s)
+    "mpg": (0.1, 0.5e-3),
+    "mpp": (1.0, 2.0e-3),
+    "mpd": (2.0, 4.0e-3),
+}
+
+
+def _fir_from_gaussian_psd(spread_hz: float, low_fs: float, ntaps: int = 100) -> np.ndarray:
+    """Frequency-sampling FIR design (same recipe as fir2: interpolate the desired magnitude on a
+    dense grid, inverse FFT, linear phase, Hamming window)."""
+    sigma = spread_hz / 2.0
+    npt = 512
+    f = np.linspace(0.0, low_fs / 2.0, npt + 1)
+    mag = (1.0 / (sigma * math.sqrt(2 * math.pi))) * np.exp(-(f ** 2) / (2 * sigma * sigma))
+    # linear-phase shift by (ntaps-1)/2 samples
+    k = np.arange(npt + 1)
+    spec = mag * np.exp(-1j * math.pi * k * (ntaps - 1) / (2.0 * npt))
+    h = np.fft.irfft(spec, 2 * npt)[:ntaps]
+    return h * np.hamming(ntaps)
+
+
+def doppler_spread(spread_hz: float, fs: int, nsam: int, rng: np.random.Generator) -> np.ndarray:
+    """doppler_spread.m:7-50. Returns nsam complex128 samples at rate fs."""
+    low_fs = math.ceil(10 * spread_hz)
+    ntaps = 100
+    m = fs / low_fs
+    if m != math.floor(m):
+        m = math.floor(m)
+        low_fs = fs / m
+    m = int(m)
+    nsam_low = max(math.ceil(nsam / m), 2)
+    b = _fir_from_gaussian_psd(spread_hz, low_fs, ntaps)
+    x = rng.standard_normal(nsam_low + ntaps) + 1j * rng.standard_normal(nsam_low + ntaps)
+    y = np.convolve(x, b)[: nsam_low + ntaps][ntaps:]
+    # linear interpolation (with extrapolation past the last low-rate point), Octave 1-based
+    # abscissae 1, 1+M, ... map to 0-based sample index n -> position n / M
+    pos = np.arange(nsam) / m
+    i0 = np.minimum(np.floor(pos).astype(np.int64), nsam_low - 2)
+    frac = pos - i0
+    return y[i0] + (y[i0 + 1] - y[i0]) * frac
+
+
+def multipath_g(channel: str, fs: int, nsam: int, seed: int) -> np.ndarray:
+    """(nsam, 2) complex64 [G1, G2] already multiplied by hf_gain, i.e. what
+    `inference.py:160-171` hands to `RADAE.forward` after reading a g_*.f32 file."""
+    spread, _delay = PRESETS[channel]
+    rng = np.random.default_rng(seed)
+    g1 = doppler_spread(spread, fs, nsam, rng)
+    g2 = doppler_spread(spread, fs, nsam, rng)
+    hf_gain = 1.0 / math.sqrt(np.var(g1) + np.var(g2))
+    return (hf_gain * np.stack([g1, g2], axis=1)).astype(np.complex64)
+
+
+def synth_features(seed: int, nframes: int, stride: int = 36) -> np.ndarray:
+    """SURVEY.md 8(d) synthetic vocoder features: AR(1) process x[t]=0.9x[t-1]+0.436 N(0,1) over
+    20 dims, f0=4x0, f1..17=x1..17, f18=0.5x18, f19=clip(0.3x19,+-0.5); zero padded to `stride`."""
+    rng = np.random.default_rng(seed)
+    e = rng.standard_normal((nframes, 20))
+    x = np.zeros((nframes, 20))
+    prev = np.zeros(20)
+    for t in range(nframes):
+        prev = 0.9 * prev + 0.436 * e[t]
+        x[t] = prev
+    f = x.copy()
+    f[:, 0] *= 4.0
+    f[:, 18] *= 0.5
+    f[:, 19] = np.clip(0.3 * x[:, 19], -0.5, 0.5)
+    out = np.zeros((nframes, stride), dtype=np.float32)
+    out[:, :20] = f.astype(np.float32)
+    return out

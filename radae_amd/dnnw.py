@@ -1,0 +1,173 @@
+"""DNNw weight-blob reader (host side, numpy only).
+
+The RADAE reference ships its deployed model as an Opus-style "DNNw" blob
+(`bin/model19_check3.bin`); the layout is produced by
+`/root/reference/src/write_rade_weights.c:51-74` from tables emitted by
+`weight-exchange/wexchange/c_export/common.py` (dense :290-293, int8 8x4 blocks :59-69,
+"sparse" GRU input blocks :140-176, scale/subias :263-271, GRU gate swap :360-368,
+conv tap flattening :307-311).
+
+This module inverts that export into plain fp32 matrices in *row-major [out][in]* form
+(the orientation torch.nn.Linear uses) so that the same numbers can be
+  * loaded into the C/HIP engine (it has its own C twin of this reader, `csrc/rade_dnnw.c`),
+  * loaded into the reference's PyTorch modules by `oracle/gen_golden.py`.
+
+De-quantisation rule: the int8 value q and the per-output `scale` array satisfy
+w = q * scale * 127 (the exporter stores scale/127, common.py:267).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import Dict
+
+import numpy as np
+
+_TYPE_F32, _TYPE_I32, _TYPE_I8 = 0, 1, 3
+_HDR = 64
+
+
+def read_records(path: str) -> Dict[str, np.ndarray]:
+    """Parse every record of a DNNw blob into a flat numpy array keyed by name."""
+    blob = open(path, "rb").read()
+    out: Dict[str, np.ndarray] = {}
+    off = 0
+    while off < len(blob):
+        magic, version, typ, size, block = struct.unpack_from("<4siiii", blob, off)
+        if magic != b"DNNw" or version != 0:
+            raise ValueError(f"bad DNNw record header at byte {off}")
+        name = blob[off + 20: off + _HDR].split(b"\0", 1)[0].decode("ascii")
+        payload = blob[off + _HDR: off + _HDR + size]
+        if typ == _TYPE_F32:
+            arr = np.frombuffer(payload, dtype="<f4")
+        elif typ == _TYPE_I32:
+            arr = np.frombuffer(payload, dtype="<i4")
+        elif typ == _TYPE_I8:
+            arr = np.frombuffer(payload, dtype=np.int8)
+        else:
+            raise ValueError(f"record {name}: unknown type {typ}")
+        out[name] = arr.copy()
+        off += _HDR + block
+    return out
+
+
+def _dense_float(rec, name):
+    """`*_weights_float` is W.T, i.e. (n_in, n_out) row-major."""
+    bias = rec[name + "_bias"]
+    n_out = bias.shape[0]
+    w = rec[name + "_weights_float"].reshape(-1, n_out).T
+    return np.ascontiguousarray(w, dtype=np.float32), bias.astype(np.float32)
+
+
+def _dense_int8(rec, name):
+    """8x4-blocked int8: stored as q.reshape(n_in/4,4,n_out/8,8).transpose(2,0,3,1)."""
+    scale = rec[name + "_scale"].astype(np.float32) * np.float32(127.0)
+    n_out = scale.shape[0]
+    q = rec[name + "_weights_int8"]
+    n_in = q.size // n_out
+    q = q.reshape(n_out // 8, n_in // 4, 8, 4).transpose(1, 3, 0, 2).reshape(n_in, n_out)
+    w = (q.astype(np.float32) * scale[None, :]).T
+    return np.ascontiguousarray(w, dtype=np.float32), rec[name + "_bias"].astype(np.float32)
+
+
+def _sparse_int8(rec, name):
+    """GRU-input "sparse" form: per 8-output group an idx list [count, pos...]; each kept
+    block is 4 inputs x 8 outputs stored output-major (8x4)."""
+    scale = rec[name + "_scale"].astype(np.float32) * np.float32(127.0)
+    n_out = scale.shape[0]
+    idx = rec[name + "_weights_idx"]
+    q = rec[name + "_weights_int8"]
+    # n_in is not stored; it is the largest referenced input position + 4
+    n_in = 0
+    p = 0
+    for _ in range(n_out // 8):
+        cnt = int(idx[p]); p += 1
+        if cnt:
+            n_in = max(n_in, int(idx[p:p + cnt].max()) + 4)
+        p += cnt
+    wq = np.zeros((n_in, n_out), dtype=np.float32)
+    p = 0
+    blk = 0
+    for g in range(n_out // 8):
+        cnt = int(idx[p]); p += 1
+        for _ in range(cnt):
+            j = int(idx[p]); p += 1
+            b = q[blk * 32:(blk + 1) * 32].reshape(8, 4).T  # (4 in, 8 out)
+            wq[j:j + 4, g * 8:(g + 1) * 8] = b
+            blk += 1
+    w = (wq * scale[None, :]).T
+    return np.ascontiguousarray(w, dtype=np.float32), rec[name + "_bias"].astype(np.float32)
+
+
+def _unswap_gates(a):
+    """exporter order z,r,n -> torch order r,z,n (swap first two thirds)."""
+    n = a.shape[0] // 3
+    out = a.copy()
+    out[0:n] = a[n:2 * n]
+    out[n:2 * n] = a[0:n]
+    return out
+
+
+@dataclass
+class GRU:
+    w_ih: np.ndarray  # (3H, In) torch gate order r,z,n
+    w_hh: np.ndarray  # (3H, H)
+    b_ih: np.ndarray
+    b_hh: np.ndarray
+
+
+@dataclass
+class Conv:
+    w: np.ndarray  # (out, in, 2) torch layout; k=0 is the older tap
+    b: np.ndarray
+    dilation: int
+
+
+@dataclass
+class Dense:
+    w: np.ndarray  # (out, in)
+    b: np.ndarray
+
+
+def _gru(rec, name):
+    w_ih, b_ih = _sparse_int8(rec, name + "_input")
+    w_hh, b_hh = _dense_int8(rec, name + "_recurrent")
+    return GRU(_unswap_gates(w_ih), _unswap_gates(w_hh), _unswap_gates(b_ih), _unswap_gates(b_hh))
+
+
+def _conv(rec, name, dilation):
+    w, b = _dense_int8(rec, name)  # (out, 2*in), column index = k*in + i
+    n_out, two_in = w.shape
+    w3 = w.reshape(n_out, 2, two_in // 2).transpose(0, 2, 1)
+    return Conv(np.ascontiguousarray(w3), b, dilation)
+
+
+@dataclass
+class Model:
+    enc_dense1: Dense
+    enc_gru: list
+    enc_conv: list
+    enc_zdense: Dense
+    dec_dense1: Dense
+    dec_gru: list
+    dec_glu: list
+    dec_conv: list
+    dec_output: Dense
+
+
+ENC_DILATION = (1, 2, 2, 2, 2)  # radae_base.py:241-249
+
+
+def load_model(path: str) -> Model:
+    rec = read_records(path)
+    return Model(
+        enc_dense1=Dense(*_dense_float(rec, "enc_dense1")),
+        enc_gru=[_gru(rec, f"enc_gru{i}") for i in range(1, 6)],
+        enc_conv=[_conv(rec, f"enc_conv{i}", ENC_DILATION[i - 1]) for i in range(1, 6)],
+        enc_zdense=Dense(*_dense_float(rec, "enc_zdense")),
+        dec_dense1=Dense(*_dense_float(rec, "dec_dense1")),
+        dec_gru=[_gru(rec, f"dec_gru{i}") for i in range(1, 6)],
+        dec_glu=[Dense(*_dense_int8(rec, f"dec_glu{i}")) for i in range(1, 6)],
+        dec_conv=[_conv(rec, f"dec_conv{i}", 1) for i in range(1, 6)],
+        dec_output=Dense(*_dense_float(rec, "dec_output")),
+    )
