@@ -1,0 +1,119 @@
+"""Pin the CPU oracle (oracle/rade_oracle.c) against golden vectors captured from the imported
+reference (oracle/gen_golden.py).  Tolerances: discrete sync outputs bit-exact; float32 stages
+within a few ulp-scaled units; NN outputs within the rounding-noise amplification the reference
+itself shows between its stateful and stateless paths (stateful_encoder.py:102 uses 0.01 on loss)."""
+import numpy as np
+import pytest
+
+RX_CASES = ["awgn", "mpp", "slip_plus", "slip_minus", "foff"]
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean(np.abs(np.asarray(a, np.complex128) - np.asarray(b, np.complex128)) ** 2)))
+
+
+def test_constants(oracle, golden):
+    c = golden("consts")
+    cases = [("w", 30, False, c["w"], 0.0), ("Winv", 9600, True, c["Winv"].ravel(), 2e-9), ("Wfwd", 9600, True, c["Wfwd"].ravel(), 2e-7),
+             ("P", 60, True, c["P"], 0.0), ("Pend", 60, True, c["Pend"], 0.0), ("p", 320, True, c["p"], 5e-8), ("pend", 320, True, c["pend"], 5e-8),
+             ("p_cp", 384, True, c["p_cp"], 5e-8), ("pend_cp", 384, True, c["pend_cp"], 5e-8), ("eoo", 2304, True, c["eoo_default"], 1e-6),
+             ("Pmat", 360, True, c["Pmat"].ravel(), 2e-6), ("bpf_h", 101, False, c["bpf_h"].real, 5e-9),
+             ("bpf_phase_vec_exp", 2240, True, c["bpf_phase_vec_exp"], 2e-7), ("acq_p_w", 12800, True, c["acq_p_w"].ravel(), 5e-8),
+             ("acq_fcoarse", 40, False, c["acq_fcoarse"], 0.0), ("bpf_alpha", 1, False, c["bpf_alpha"], 0.0), ("pilot_gain", 1, False, c["pilot_gain"], 1e-6)]
+    for name, n, cplx, ref, tol in cases:
+        got = oracle.get_const(name, n, cplx)
+        assert np.abs(got - ref).max() <= tol, name
+
+
+def test_blob_reader_matches_python_reader(oracle_model, golden):
+    w = golden("weights_check")
+    for k in w.files:
+        t = oracle_model.tensor(k).astype(np.float64)
+        got = np.array([t.size, t.sum(), np.abs(t).sum()] + list(t[:8]) + list(t[-4:]))
+        assert np.allclose(got, w[k], rtol=1e-12, atol=0), k
+
+
+def test_encoder_and_tx(oracle, oracle_model, golden):
+    e = golden("enc_tx")
+    for u in range(2):
+        tx = oracle.Tx(oracle_model)
+        zs, txs = [], []
+        for k in range(10):
+            o, z = tx.frame(e["features"][u, 12 * k:12 * k + 12].ravel())
+            zs.append(z); txs.append(o)
+        zs = np.array(zs).reshape(30, 80)
+        ref_gap = rms(e["z_stateless"][u], e["z"][u])   # the reference's own stateful/stateless gap
+        assert rms(zs, e["z"][u]) < 1e-4 and rms(zs, e["z"][u]) < 3 * ref_gap
+        assert np.abs(zs - e["z"][u]).max() < 2e-6 * np.abs(e["z"][u]).max() + 1e-5
+        assert np.abs(np.array(txs) - e["tx"][u]).max() < 2e-5
+        # transmitter alone on the reference's z: float32 rounding only
+        t2 = np.array([oracle.ofdm_mod(e["z"][u].reshape(10, 240)[k]) for k in range(10)])
+        assert np.abs(t2 - e["tx"][u]).max() < 5e-6
+    enc = oracle.Encoder(oracle_model)
+    f = e["features"][0]
+    for s in range(30):
+        feat = np.concatenate([np.concatenate([f[4 * s + i, :20], [-1.0]]) for i in range(4)])
+        enc.step(feat)
+    for l in range(5):
+        assert np.abs(enc.gru_state(l + 1) - e["gru_states_u0"][l]).max() < 2e-5
+
+
+def test_eoo_bits(oracle, oracle_model, golden):
+    c = golden("consts")
+    tx = oracle.Tx(oracle_model)
+    assert np.abs(tx.eoo() - c["eoo_default"]).max() < 1e-6
+    tx.set_eoo_bits(c["eoo_bits_in"])
+    assert np.abs(tx.eoo() - c["eoo_with_bits"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["mpp", "awgn"])
+def test_channel(oracle, oracle_model, golden, name):
+    g = golden("chan_" + name)
+    sigma = float(g["sigma"])
+    assert oracle.lib().orc_sigma_from_EbNodB(float(g["EbNodB"])) == pytest.approx(sigma, rel=1e-7)
+    rx, fin = oracle.channel(g["tx"], g["G"], g["noise"], sigma, float(g["freq_offset"]), float(g["df_dt"]))
+    assert np.abs(rx - g["rx"]).max() < 2e-6
+    assert abs(fin - g["final_phase"].ravel()[0]) < 1e-6
+    eoo = oracle.channel_eoo(oracle.Tx(oracle_model).eoo(), g["noise_eoo"], sigma, float(g["freq_offset"]), float(g["df_dt"]), fin)
+    full = np.concatenate([sigma * g["noise_pre"], rx, eoo, sigma * g["noise_post"]]).astype(np.complex64)
+    assert np.abs(full - g["rx_full"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("name", RX_CASES)
+def test_rx_trace(oracle, oracle_model, golden, name):
+    g = golden("rxtrace_" + name)
+    d = oracle.run_rx_stream(oracle_model, g["rx_in"], 1, 10.0 if name == "foff" else 0.0)
+    for k in ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]:
+        assert np.array_equal(d[k], g[k]), k     # the discrete "indices": bit-exact
+    assert np.abs(d["fmax"] - g["fmax"]).max() < 1e-9
+    for k in ["Dthresh", "Dtmax12", "Dtmax12_eoo", "snrdB_3k_est"]:
+        assert np.abs(d[k] - g[k]).max() < 2e-5, k
+    assert d["z_hat"].shape == g["z_hat"].shape
+    assert rms(d["z_hat"], g["z_hat"]) < 1e-4
+    assert rms(d["features_out"], g["features_out"]) < 1e-5 and np.abs(d["features_out"] - g["features_out"]).max() < 1e-4
+    if g["eoo_out"].size:
+        assert np.abs(d["eoo_out"] - g["eoo_out"]).max() < 1e-4
+        # the aux/EOO bit decisions are the discrete part
+        assert np.array_equal(d["eoo_out"] > 0, g["eoo_out"] > 0)
+
+
+def test_decoder_and_loss(oracle, oracle_model, golden):
+    g = golden("dec_loss")
+    dec = oracle.Decoder(oracle_model)
+    out = np.array([dec.step(g["z_hat"][k]) for k in range(30)]).reshape(120, 21)
+    assert rms(out, g["features"]) < 1e-5 and np.abs(out - g["features"]).max() < 1e-4
+    for l in range(5):
+        assert np.abs(dec.gru_state(l + 1) - g["gru_states"][l]).max() < 2e-5
+    assert oracle.distortion_loss(g["la"], g["lb"], 20) == pytest.approx(float(g["loss20"]), rel=2e-6)
+    assert oracle.distortion_loss(g["la21"], g["lb21"], 21) == pytest.approx(float(g["loss21"]), rel=2e-6)
+
+
+def test_loopback_loss_alignment(oracle, oracle_model, golden):
+    """loss.py-style aligned loss between features_in and the oracle receiver's output equals the
+    one computed from the reference's own output (delta < 1e-4)."""
+    g = golden("rxtrace_awgn")
+    d = oracle.run_rx_stream(oracle_model, g["rx_in"])
+    fi = g["features_in"]
+    l_ref, s_ref = oracle.find_loss(fi, g["features_out"].reshape(-1, 36))
+    l_orc, s_orc = oracle.find_loss(fi, d["features_out"].reshape(-1, 36))
+    assert s_ref == s_orc and abs(l_ref - l_orc) < 1e-4
