@@ -1,0 +1,114 @@
+/*
+ * rade_batch.h -- batched (many independent streams) form of the RADE hot path, C ABI.
+ *
+ * Additive extension of rade_api.h: the single-stream API cannot express "256 utterances on one
+ * MI355X", which is the workload BASELINE.json names.  Every call processes the same step for all
+ * B streams; streams never exchange data, so sharding across GPUs is one
+ * engine per device with a disjoint set of streams.
+ *
+ * All *_dev pointers are device (HBM) addresses; `stream` is a hipStream_t passed as void*
+ * (NULL = the legacy default stream).  No torch / C++ types cross this boundary.
+ *
+ * Reference behaviour implemented per entry point:
+ *   rade_batch_tx          radae_txe.py:108-135 (do_radae_tx) + rade_api.c:403-445, n_mf modem frames at once,
+ *                          encoder state carried across calls (radae_base.py:97-129)
+ *   rade_batch_tx_eoo      radae_txe.py:138-144, radae.py:208-219, :441-455
+ *   rade_batch_channel     radae.py:529-589 (rate-Fs multipath, offsets, AWGN; power normalised per
+ *                          stream = the reference's batch-1 behaviour) + inference.py:263-284 (EOO / noise framing)
+ *   rade_batch_rx          radae_rxe.py:171-330 (do_radae_rx) looped like radae_rxe.py:349-356 /
+ *                          src/radae_rx.c:42-53, incl. rade_api.c:480-513 decoder + UW accounting
+ */
+#ifndef RADE_BATCH_H
+#define RADE_BATCH_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rade_batch rade_batch;
+
+typedef struct {
+    int n_streams;        /* B */
+    int max_tx_mf;        /* largest n_mf a single rade_batch_tx call may carry */
+    int device;           /* HIP device ordinal */
+    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured */
+    int rx_trace_calls;   /* >0: keep a per-call trace of this many do_radae_rx calls per stream (tests) */
+} rade_batch_config;
+
+/* blob = DNNw weight file (weights/model19_check3.bin).  Returns NULL on failure (message on stderr). */
+rade_batch *rade_batch_open(const char *blob_path, const rade_batch_config *cfg);
+rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_batch_config *cfg);
+void rade_batch_close(rade_batch *h);
+int rade_batch_n_streams(const rade_batch *h);
+
+/* ---- transmit ------------------------------------------------------------------------------
+ * features_dev : [B][n_mf*12][36] float32 (first 20 of each 36 used; aux symbol -1 added inside)
+ * iq_out_dev   : stream b written at iq_out_dev + b*iq_stride (units: complex samples), n_mf*960 samples
+ * z_out_dev    : optional [B][n_mf*3][80] latents (NULL to skip)
+ * returns n_mf*960 or <0 on error */
+int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride,
+                  float *z_out_dev, void *stream);
+/* bits_host: [B][180] +-1 floats, or NULL to restore the default (all-zero data symbols) EOO frame */
+int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host);
+/* writes the 1152-sample end-of-over frame of every stream; returns 1152 */
+int rade_batch_tx_eoo(rade_batch *h, void *iq_out_dev, long iq_stride, void *stream);
+void rade_batch_tx_reset(rade_batch *h);
+
+/* ---- channel simulator ---------------------------------------------------------------------- */
+typedef struct {
+    int n_sig;            /* signal samples per stream (multiple of 960) */
+    int n_pre, n_post;    /* noise-only samples before / after (inference.py --prepend_noise/--append_noise) */
+    int with_eoo;         /* append the stream's EOO frame, phase-continued (inference.py --end_of_over) */
+    float sigma;          /* AWGN std-dev, see rade_sigma_from_EbNodB */
+    float freq_offset;    /* Hz */
+    float df_dt;          /* Hz/s */
+    const void *G_dev;    /* [B][n_sig][2] complex64 Doppler samples (G1,G2) or NULL = (1,0) */
+    const void *noise_dev;/* [B][n_total] complex64, unit variance, or NULL: generate (Philox) from seed; seed 0 = no noise */
+    unsigned long long seed;
+} rade_channel_params;
+/* n_total = n_pre + n_sig + (with_eoo ? 1152 : 0) + n_post samples written per stream; returns n_total */
+int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *rx_out_dev, long rx_stride,
+                       const rade_channel_params *p, void *stream);
+float rade_sigma_from_EbNodB(float EbNodB);
+
+/* ---- receive --------------------------------------------------------------------------------
+ * rx_dev + b*rx_stride points at the first sample stream b has NOT yet consumed; n_avail_host[b]
+ * samples are readable there.  Each stream consumes whole do_radae_rx calls (rade_nin() samples
+ * each) while enough samples remain and fewer than max_calls calls were made in this invocation.
+ * features_out_dev: stream b at + b*feat_stride floats; each valid modem frame appends 432 floats.
+ * eoo_out_dev: [B][180] soft bits of the most recent end-of-over frame (NULL to skip).
+ * status_host: [B] records filled on return (the call synchronises `stream`). */
+typedef struct {
+    int consumed;         /* samples consumed by this invocation */
+    int n_calls;          /* do_radae_rx calls made */
+    int n_valid;          /* calls that produced features (432 floats each) */
+    int has_eoo;          /* an end-of-over frame was decoded */
+    int nin;              /* samples the next call needs (rade_nin) */
+    int sync;             /* rade_sync */
+    int snr_dB;           /* rade_snrdB_3k_est */
+    int state;            /* 0 search 1 candidate 2 sync */
+} rade_rx_status;
+int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *n_avail_host, int max_calls,
+                  float *features_out_dev, long feat_stride, float *eoo_out_dev, rade_rx_status *status_host,
+                  void *stream);
+void rade_batch_rx_reset(rade_batch *h);
+/* seed of the documented LCG that picks the 48 rows check_pilots refreshes (dsp.py:291-295 uses an
+ * unseeded np.random.randint); seeds_host[B] or NULL for all-ones */
+void rade_batch_rx_set_lcg(rade_batch *h, const unsigned *seeds_host);
+
+/* per-call trace record (tests): mirrors what radae_rxe.py prints per frame at -v 2 */
+typedef struct {
+    int state_before, state_after, nin_before, nin_after, ret, tmax, f_ind_max, valid_count;
+    int uw_errors, synced_count, snr_int, pad;
+    double fmax, Dthresh, Dtmax12, Dtmax12_eoo;
+    float snrdB_3k_est; float pad2;
+} rade_rx_trace;
+/* copies up to max_calls records + 240-float z_hat rows per call of stream b to host; returns #calls traced */
+int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,169 @@
+/*
+ * rade_dev.h -- data layouts shared by the C host (rade_engine.c / rade_tables.c) and the HIP
+ * kernels (rade_kernels.hip), and the thin launch shims the host calls ("FFI" between plain C and
+ * device code).  Everything here is POD; float2-like pairs are spelled as float[2] so that plain C
+ * can fill them.
+ */
+#ifndef RADE_DEV_H
+#define RADE_DEV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* numerology of RADE V1 / model19_check3 (radae/radae.py:128-234) */
+#define RD_M        160   /* samples per OFDM symbol body */
+#define RD_NCP      32    /* cyclic prefix */
+#define RD_SYM      192
+#define RD_NC       30    /* carriers */
+#define RD_NS       4     /* data symbols per modem frame */
+#define RD_NMF      960   /* samples per modem frame */
+#define RD_NEOO     1152
+#define RD_RXBUF    2112  /* 2*Nmf + M + Ncp */
+#define RD_NFC      40    /* coarse frequency bins */
+#define RD_NTAP     101
+#define RD_NINMAX   1120
+#define RD_LATENT   80
+#define RD_ZMF      240   /* latent floats per modem frame */
+#define RD_FEAT_MF  432   /* 12 frames x 36 */
+#define RD_NEOOBITS 180
+#define RD_ENC_W    864   /* encoder concat width */
+#define RD_DEC_W    736
+#define RD_ENC_IN   88    /* 84 padded to a multiple of 8 */
+#define RD_RX_ROUND 8     /* max do_radae_rx calls per stream per sync-kernel launch */
+#define RD_DEC_ROWS 24    /* = 3 * RD_RX_ROUND decoder steps per round */
+
+/* constant tables, one copy in HBM (filled by rade_tables.c) */
+typedef struct {
+    float Winv[RD_NC][RD_M][2];        /* radae.py:175-178 */
+    float Wfwd[RD_M][RD_NC][2];        /* :179 */
+    float P[RD_NC], Pend[RD_NC];       /* real parts (imag = 0), :182-185 */
+    float p[RD_M][2], pend[RD_M][2];   /* :183,:186 */
+    float eoo[RD_NEOO][2];             /* default EOO frame :208-219 */
+    float Pmat[RD_NC][2][3][2];        /* dsp.py:400-412 */
+    float eq_rot[RD_NC][2];            /* exp(-1j*w[c]*20), dsp.py:433 */
+    float bpf_h[RD_NTAP + 3];          /* dsp.py:46-49 */
+    float bpf_E[RD_NINMAX][2];         /* phase_vec_exp, dsp.py:61 */
+    float p_w[RD_M][RD_NFC][2];        /* acquisition.p_w, dsp.py:166-173 */
+    double fcoarse[RD_NFC];            /* dsp.py:163 */
+    float pilot_gain;                  /* radae.py:196-199 */
+    float snr_c1, snr_c2;              /* 10log10(Rs*Nc/3000), 10log10((M+Ncp)/M)  dsp.py:453 */
+    float pad;
+} rd_tables;
+
+/* per-stream receiver state (HBM, one record per stream, touched by exactly one workgroup) */
+typedef struct {
+    int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf;
+    int f_ind_max, dec_reset_pending, bpf_mem_len, n_out_frames;
+    uint32_t lcg; int has_eoo, pad0, pad1;
+    double fmax, foff_err, rx_phase[2];
+    double Dthresh, Dtmax12, Dtmax12_eoo;
+    float snr_est, bpf_phase[2], pad2;
+    long long consumed;                 /* samples consumed since reset */
+    float bpf_mem[102][2];
+    float rx_buf[RD_RXBUF][2];
+    float rowsum1[RD_NMF], rowsum2[RD_NMF];   /* sum_f |Dt1[t,f]|, |Dt2[t,f]|: all check_pilots ever reads back */
+} rd_rx_stream;
+
+/* per-stream, per-round hand-off from the sync kernel to the decoder kernels and the post kernel */
+typedef struct {
+    int n_calls;                        /* calls made this round */
+    int n_rows;                         /* decoder steps emitted (3 per valid call) */
+    int uw_from_row;                    /* aux-bit errors count from this row on (sync entry resets) */
+    int consumed;                       /* samples consumed this round */
+    int row_reset[RD_DEC_ROWS];         /* 1: decoder state is reset before this step */
+    int call_ret[RD_RX_ROUND];          /* bit0 valid bit1 eoo */
+    int call_row_lo[RD_RX_ROUND], call_row_hi[RD_RX_ROUND]; /* trace patching of uw_errors */
+    int call_trace_idx[RD_RX_ROUND];
+    int blocked;                        /* stopped because a UW decision waits for the decoder */
+    int out_base;                       /* valid frames this invocation before this round (features_out slot) */
+    int pad[2];
+} rd_rx_round;
+
+/* same layout as rade_rx_trace in include/rade_batch.h */
+typedef struct {
+    int state_before, state_after, nin_before, nin_after, ret, tmax, f_ind_max, valid_count;
+    int uw_errors, synced_count, snr_int, pad;
+    double fmax, Dthresh, Dtmax12, Dtmax12_eoo;
+    float snrdB_3k_est; float pad2;
+} rd_rx_trace;
+
+/* ---- launch shims (defined in rade_kernels.hip) -------------------------------------------- */
+typedef void *rd_stream_t;
+
+/* Y[r, n] = act(sum_k A[r,k] W[n,k] + bias[n]) on f32 MFMA; rows r = b*T + t.
+ * A row (b,t) = [tap0 | tap1]: tap1 at a1 + b*a1_sb + t*a1_st (K1 floats), tap0 (K0 floats, may be 0)
+ * at a0 + b*a0_sb + t*a0_st, or the zero row when reset[b*T+t] != 0.  Wp = packed weights
+ * (rd_pack_weights).  act: 0 none, 1 tanh+clamp, 2 GLU (y = a1[r][n] * sigmoid(acc), clamp). */
+typedef struct {
+    const float *a1; long a1_sb, a1_st; int K1;
+    const float *a0; long a0_sb, a0_st; int K0;
+    const int *reset;                  /* optional [B*T] */
+    const int *n_rows;                 /* optional [B]: rows t >= n_rows[b] are skipped */
+    const float *Wp; const float *bias;
+    float *y; long y_sb, y_st; int N;  /* N valid outputs (<= 32*NT) */
+    int B, T, act;
+} rd_gemm_args;
+int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s);
+/* packs W[N][K] (row-major) into the fragment order the GEMM kernel streams; returns #floats (K,N padded) */
+long rd_pack_weights(const float *W, int N, int K, float *out);
+long rd_packed_size(int N, int K);
+
+/* GRU recurrence over T steps, one workgroup per stream.  gi[b][t][3H] = W_ih x + b_ih (from the GEMM).
+ * h state [B][H] in/out.  Writes clamp(h_t) to out + b*out_sb + t*out_st. */
+typedef struct {
+    const float *gi; long gi_sb, gi_st;
+    const float *Whh; const float *bhh;   /* [3H][H], [3H], torch gate order r,z,n */
+    float *h;                             /* [B][H] */
+    float *out; long out_sb, out_st;
+    const int *reset;                     /* optional [B*T]: zero h before step */
+    const int *n_rows;                    /* optional [B] */
+    int B, T, H;
+} rd_scan_args;
+int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s);
+
+/* encoder input packing: features [B][T*4][36] -> [B][T][88] = 4 x (20 feats, aux -1), zero pad */
+int rd_launch_enc_pack(const float *features, float *xin, int B, int T, rd_stream_t s);
+/* x is [B][nhist+Tcap][W]: copy time rows [T, T+nhist) (or [n_rows[b], ..)) of each stream to rows [0, nhist) */
+int rd_launch_carry_rows(float *x, int B, int Tcap, int W, int nhist, int T, const int *n_rows, rd_stream_t s);
+/* z [B][n_mf*3][80] -> tx [b*stride + mf*960 ...] (transmitter_one, dsp.py:340-378) */
+int rd_launch_ofdm_mod(const rd_tables *tab, const float *z, void *tx, long tx_stride, int B, int n_mf, rd_stream_t s);
+/* EOO data symbols: bits [B][180] -> eoo frames [B][1152] (radae.py:441-455); bits NULL = defaults */
+int rd_launch_eoo_build(const rd_tables *tab, const float *bits, float *eoo, int B, rd_stream_t s);
+int rd_launch_copy_eoo(const float *eoo, void *out, long stride, int B, rd_stream_t s);
+
+typedef struct {
+    const rd_tables *tab; const void *tx; long tx_stride; void *rx; long rx_stride;
+    const void *G; const void *noise; const float *eoo; void *scratch; /* >= B*64*2 doubles */
+    int B, n_sig, n_pre, n_post, with_eoo; float sigma, freq_offset, df_dt; unsigned long long seed;
+} rd_chan_args;
+int rd_launch_channel(const rd_chan_args *a, rd_stream_t s);
+
+typedef struct {
+    const rd_tables *tab; rd_rx_stream *st; rd_rx_round *round;
+    const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
+    int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
+    int max_calls;                                       /* call budget per stream per invocation */
+    float *zrows;                                        /* [B][RD_DEC_ROWS][80] */
+    int *n_rows; int *row_reset;                         /* flat [B], [B][RD_DEC_ROWS] copies for the decoder kernels */
+    int *status;                                         /* [B][4]: nin, sync, snr_int, state */
+    float *eoo_out;                                      /* [B][180] or NULL */
+    rd_rx_trace *trace; float *trace_z; int trace_cap;   /* optional */
+    int *progress;                                       /* [4]: calls made this round, max rows, unused, unused */
+    int B;
+} rd_sync_args;
+int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
+
+typedef struct {
+    rd_rx_stream *st; rd_rx_round *round; const float *feat84;   /* [B][RD_DEC_ROWS][84] */
+    float *features_out; long feat_stride; rd_rx_trace *trace; int trace_cap;
+    int B;
+} rd_post_args;
+int rd_launch_rx_post(const rd_post_args *a, rd_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,382 @@
+/*
+ * rade_engine.c -- batched RADE engine (plain C host code driving the HIP kernels through the
+ * launch shims in rade_dev.h).  Implements include/rade_batch.h.
+ *
+ * Execution model: the encoder / decoder are evaluated layer by layer over
+ * ALL streams and ALL time steps of a chunk: the feed-forward part of every layer is one skinny-N
+ * f32-MFMA GEMM with M = B*T rows, and only the 64/96-wide GRU recurrences run as serial scans.
+ * The receiver runs one persistent workgroup per stream; because the sync state machine consumes the
+ * decoder's aux bits (UW errors, radae_rxe.py:220-224, :306-312) the receive side proceeds in rounds
+ * of at most RD_RX_ROUND modem frames: sync kernel -> decoder layers -> post kernel.
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "rade_batch.h"
+#include "rade_api.h"
+#include "rade_host.h"
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rade: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); goto fail; } } while (0)
+
+typedef struct { float *wp, *bias; int N, K; } dev_lin;
+
+struct rade_batch {
+    int B, max_tx_mf, device, flags, trace_cap, Tcap;
+    rd_tables *d_tab;
+    /* weights */
+    dev_lin enc_dense1, enc_zdense, dec_dense1, dec_output, enc_gin[5], dec_gin[5], enc_conv[5], dec_conv[5], dec_glu[5];
+    float *enc_whh[5], *enc_bhh[5], *dec_whh[5], *dec_bhh[5];
+    /* transmit side */
+    float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
+    void *chan_scratch;
+    /* receive side */
+    rd_rx_stream *rx_st; rd_rx_round *rx_round;
+    int *rx_avail, *rx_acc, *rx_progress, *rx_nrows, *rx_rowreset, *rx_status;
+    float *zrows, *dec_x, *dec_gi, *dec_hbuf, *dec_h[5], *feat84;
+    rd_rx_trace *trace; float *trace_z;
+    int *h_small;                    /* pinned host scratch */
+    unsigned *lcg_seeds;             /* host copy for resets */
+};
+
+static const int ENC_IN[5] = { 64, 224, 384, 544, 704 };    /* GRU input widths (radae_base.py:240-248) */
+static const int ENC_DIL[5] = { 1, 2, 2, 2, 2 };
+static const int DEC_IN[5] = { 96, 224, 352, 480, 608 };    /* radae_base.py:378-386 */
+
+static void *dev_upload(const void *src, size_t bytes)
+{
+    void *d = NULL;
+    if (hipMalloc(&d, bytes) != hipSuccess) return NULL;
+    if (hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return NULL; }
+    return d;
+}
+static void *dev_zeros(size_t bytes)
+{
+    void *d = NULL;
+    if (hipMalloc(&d, bytes) != hipSuccess) return NULL;
+    if (hipMemset(d, 0, bytes) != hipSuccess) { hipFree(d); return NULL; }
+    return d;
+}
+
+/* pack W[N][K] (optionally padding K up to Kpad with zero columns) and upload */
+static int upload_lin(dev_lin *d, const float *w, const float *b, int N, int K, int Kpad)
+{
+    float *wsrc = (float *)w, *tmp = NULL;
+    if (Kpad != K) {
+        tmp = calloc((size_t)N * Kpad, sizeof(float));
+        for (int o = 0; o < N; o++) memcpy(tmp + (size_t)o * Kpad, w + (size_t)o * K, sizeof(float) * K);
+        wsrc = tmp;
+    }
+    const long n = rd_packed_size(N, Kpad);
+    float *packed = malloc(sizeof(float) * n);
+    rd_pack_weights(wsrc, N, Kpad, packed);
+    d->wp = dev_upload(packed, sizeof(float) * n);
+    d->bias = b ? dev_upload(b, sizeof(float) * N) : NULL;
+    d->N = N; d->K = Kpad;
+    free(packed); free(tmp);
+    return (d->wp && (!b || d->bias)) ? 0 : -1;
+}
+
+static void rx_state_init_host(rd_rx_stream *s, unsigned seed, int flags)
+{   /* radae_rxe.py:128-142 */
+    memset(s, 0, sizeof *s);
+    s->state = 0; s->nin = RD_NMF; s->mf = 1; s->bpf_mem_len = 100; s->lcg = seed;
+    s->rx_phase[0] = 1.0; s->bpf_phase[0] = 1.0f;
+    s->foff_err = (flags & RADE_FOFF_TEST) ? 10.0 : 0.0;      /* rade_api.c:263-264 */
+}
+
+void rade_batch_rx_reset(rade_batch *h)
+{
+    rd_rx_stream *tmp = malloc(sizeof(rd_rx_stream));
+    for (int b = 0; b < h->B; b++) {
+        rx_state_init_host(tmp, h->lcg_seeds[b], h->flags);
+        hipMemcpy(h->rx_st + b, tmp, sizeof *tmp, hipMemcpyHostToDevice);
+    }
+    free(tmp);
+    for (int l = 0; l < 5; l++) hipMemset(h->dec_h[l], 0, sizeof(float) * h->B * 96);
+    hipMemset(h->dec_x, 0, sizeof(float) * (size_t)h->B * (1 + RD_DEC_ROWS) * RD_DEC_W);
+    hipMemset(h->rx_rowreset, 0, sizeof(int) * h->B * RD_DEC_ROWS);
+    if (h->trace) { hipMemset(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap); hipMemset(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF); }
+}
+
+void rade_batch_rx_set_lcg(rade_batch *h, const unsigned *seeds_host)
+{
+    for (int b = 0; b < h->B; b++) h->lcg_seeds[b] = seeds_host ? seeds_host[b] : 1u;
+    rade_batch_rx_reset(h);
+}
+
+void rade_batch_tx_reset(rade_batch *h)
+{
+    for (int l = 0; l < 5; l++) hipMemset(h->enc_h[l], 0, sizeof(float) * h->B * 64);
+    hipMemset(h->enc_x, 0, sizeof(float) * (size_t)h->B * (2 + h->Tcap) * RD_ENC_W);
+}
+
+rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_batch_config *cfg)
+{
+    rade_batch *h = NULL;
+    rd_model m; int have_model = 0;
+    if (!cfg || cfg->n_streams <= 0 || cfg->max_tx_mf <= 0) { fprintf(stderr, "rade: bad batch config\n"); return NULL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "rade: no HIP device available -- this library has no CPU fallback\n");
+        return NULL;
+    }
+    CHK(hipSetDevice(cfg->device));
+    if (rd_model_parse(blob, blob_len, &m)) return NULL;
+    have_model = 1;
+    h = calloc(1, sizeof *h);
+    h->B = cfg->n_streams; h->max_tx_mf = cfg->max_tx_mf; h->device = cfg->device; h->flags = cfg->flags;
+    h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
+    const size_t B = (size_t)h->B, T = (size_t)h->Tcap;
+
+    rd_tables *tab = malloc(sizeof *tab);
+    rd_tables_fill(tab);
+    h->d_tab = dev_upload(tab, sizeof *tab);
+    free(tab);
+    if (!h->d_tab) goto fail;
+
+    int err = 0;
+    err |= upload_lin(&h->enc_dense1, m.enc_dense1.w, m.enc_dense1.b, 64, 84, RD_ENC_IN);
+    err |= upload_lin(&h->enc_zdense, m.enc_zdense.w, m.enc_zdense.b, 80, 864, 864);
+    err |= upload_lin(&h->dec_dense1, m.dec_dense1.w, m.dec_dense1.b, 96, 80, 80);
+    err |= upload_lin(&h->dec_output, m.dec_output.w, m.dec_output.b, 84, 736, 736);
+    for (int l = 0; l < 5 && !err; l++) {
+        err |= upload_lin(&h->enc_gin[l], m.enc_gru[l].w_ih, m.enc_gru[l].b_ih, 192, ENC_IN[l], ENC_IN[l]);
+        err |= upload_lin(&h->dec_gin[l], m.dec_gru[l].w_ih, m.dec_gru[l].b_ih, 288, DEC_IN[l], DEC_IN[l]);
+        err |= upload_lin(&h->enc_conv[l], m.enc_conv[l].w, m.enc_conv[l].b, 96, m.enc_conv[l].n_in, m.enc_conv[l].n_in);
+        err |= upload_lin(&h->dec_conv[l], m.dec_conv[l].w, m.dec_conv[l].b, 32, m.dec_conv[l].n_in, m.dec_conv[l].n_in);
+        err |= upload_lin(&h->dec_glu[l], m.dec_glu[l].w, NULL, 96, 96, 96);
+        h->enc_whh[l] = dev_upload(m.enc_gru[l].w_hh, sizeof(float) * 192 * 64);
+        h->enc_bhh[l] = dev_upload(m.enc_gru[l].b_hh, sizeof(float) * 192);
+        h->dec_whh[l] = dev_upload(m.dec_gru[l].w_hh, sizeof(float) * 288 * 96);
+        h->dec_bhh[l] = dev_upload(m.dec_gru[l].b_hh, sizeof(float) * 288);
+        if (!h->enc_whh[l] || !h->enc_bhh[l] || !h->dec_whh[l] || !h->dec_bhh[l]) err = -1;
+    }
+    if (err) { fprintf(stderr, "rade: weight upload failed\n"); goto fail; }
+
+    h->enc_xin = dev_zeros(sizeof(float) * B * T * RD_ENC_IN);
+    h->enc_x = dev_zeros(sizeof(float) * B * (2 + T) * RD_ENC_W);
+    h->enc_gi = dev_zeros(sizeof(float) * B * T * 192);
+    h->enc_z = dev_zeros(sizeof(float) * B * T * RD_LATENT);
+    h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
+    h->eoo_bits = dev_zeros(sizeof(float) * B * RD_NEOOBITS);
+    h->chan_scratch = dev_zeros(sizeof(double) * B * 64 * 2);
+    for (int l = 0; l < 5; l++) { h->enc_h[l] = dev_zeros(sizeof(float) * B * 64); h->dec_h[l] = dev_zeros(sizeof(float) * B * 96); if (!h->enc_h[l] || !h->dec_h[l]) goto fail; }
+    h->rx_st = dev_zeros(sizeof(rd_rx_stream) * B);
+    h->rx_round = dev_zeros(sizeof(rd_rx_round) * B);
+    h->rx_avail = dev_zeros(sizeof(int) * B); h->rx_acc = dev_zeros(sizeof(int) * B * 4); h->rx_progress = dev_zeros(sizeof(int) * 4);
+    h->rx_nrows = dev_zeros(sizeof(int) * B); h->rx_rowreset = dev_zeros(sizeof(int) * B * RD_DEC_ROWS); h->rx_status = dev_zeros(sizeof(int) * B * 4);
+    h->zrows = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * RD_LATENT);
+    h->dec_x = dev_zeros(sizeof(float) * B * (1 + RD_DEC_ROWS) * RD_DEC_W);
+    h->dec_gi = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 288);
+    h->dec_hbuf = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 96);
+    h->feat84 = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 84);
+    if (!h->enc_xin || !h->enc_x || !h->enc_gi || !h->enc_z || !h->eoo || !h->eoo_bits || !h->chan_scratch || !h->rx_st || !h->rx_round || !h->rx_avail ||
+        !h->rx_acc || !h->rx_progress || !h->rx_nrows || !h->rx_rowreset || !h->rx_status || !h->zrows || !h->dec_x || !h->dec_gi || !h->dec_hbuf || !h->feat84) {
+        fprintf(stderr, "rade: device allocation failed\n"); goto fail;
+    }
+    if (h->trace_cap > 0) {
+        h->trace = dev_zeros(sizeof(rd_rx_trace) * B * h->trace_cap);
+        h->trace_z = dev_zeros(sizeof(float) * B * h->trace_cap * RD_ZMF);
+        if (!h->trace || !h->trace_z) goto fail;
+    }
+    CHK(hipHostMalloc((void **)&h->h_small, sizeof(int) * (8 + B * 8), 0));
+    h->lcg_seeds = malloc(sizeof(unsigned) * B);
+    for (size_t b = 0; b < B; b++) h->lcg_seeds[b] = 1u;
+    rade_batch_rx_reset(h);
+    if (rd_launch_eoo_build(h->d_tab, NULL, h->eoo, h->B, NULL)) goto fail;
+    CHK(hipDeviceSynchronize());
+    rd_model_free(&m);
+    return h;
+fail:
+    if (have_model) rd_model_free(&m);
+    if (h) rade_batch_close(h);
+    return NULL;
+}
+
+rade_batch *rade_batch_open(const char *blob_path, const rade_batch_config *cfg)
+{
+    FILE *f = blob_path ? fopen(blob_path, "rb") : NULL;
+    if (!f) { fprintf(stderr, "rade: cannot open weight blob %s\n", blob_path ? blob_path : "(null)"); return NULL; }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    void *buf = malloc(n);
+    if (fread(buf, 1, n, f) != (size_t)n) { fclose(f); free(buf); return NULL; }
+    fclose(f);
+    rade_batch *h = rade_batch_open_mem(buf, n, cfg);
+    free(buf);
+    return h;
+}
+
+static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFree(d->bias); }
+void rade_batch_close(rade_batch *h)
+{
+    if (!h) return;
+    void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z };
+    for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
+    free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
+    for (int l = 0; l < 5; l++) {
+        free_lin(&h->enc_gin[l]); free_lin(&h->dec_gin[l]); free_lin(&h->enc_conv[l]); free_lin(&h->dec_conv[l]); free_lin(&h->dec_glu[l]);
+        void *p[] = { h->enc_whh[l], h->enc_bhh[l], h->dec_whh[l], h->dec_bhh[l], h->enc_h[l], h->dec_h[l] };
+        for (int i = 0; i < 6; i++) if (p[i]) hipFree(p[i]);
+    }
+    if (h->h_small) hipHostFree(h->h_small);
+    free(h->lcg_seeds);
+    free(h);
+}
+
+int rade_batch_n_streams(const rade_batch *h) { return h->B; }
+
+/* ---- one GEMM launch helper ------------------------------------------------------------------ */
+static int gemm(const dev_lin *w, const float *a1, long a1_sb, long a1_st, int K1, const float *a0, long a0_sb, long a0_st, int K0,
+                const int *reset, const int *n_rows, float *y, long y_sb, long y_st, int B, int T, int act, void *stream)
+{
+    rd_gemm_args g;
+    memset(&g, 0, sizeof g);
+    g.a1 = a1; g.a1_sb = a1_sb; g.a1_st = a1_st; g.K1 = K1; g.a0 = a0; g.a0_sb = a0_sb; g.a0_st = a0_st; g.K0 = K0;
+    g.reset = reset; g.n_rows = n_rows; g.Wp = w->wp; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
+    if (K0 + K1 != w->K) { fprintf(stderr, "rade: internal GEMM shape error (%d+%d != %d)\n", K0, K1, w->K); return -1; }
+    return rd_launch_gemm(&g, stream);
+}
+
+/* ---- transmit (radae_txe.py:108-135 for n_mf modem frames and B streams at once) -------------- */
+int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, float *z_out_dev, void *stream)
+{
+    if (!h || n_mf <= 0 || n_mf > h->max_tx_mf) return -1;
+    const int B = h->B, T = 3 * n_mf, W = RD_ENC_W;
+    const long xsb = (long)(2 + h->Tcap) * W;
+    float *x = h->enc_x + 2 * W;               /* time row 0 of each stream; rows -2,-1 hold the conv history */
+    float *z = z_out_dev ? z_out_dev : h->enc_z;
+    int e = 0;
+    e |= rd_launch_enc_pack(features_dev, h->enc_xin, B, T, stream);
+    e |= gemm(&h->enc_dense1, h->enc_xin, (long)T * RD_ENC_IN, RD_ENC_IN, RD_ENC_IN, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
+    for (int l = 0; l < 5 && !e; l++) {
+        const int in = ENC_IN[l];
+        e |= gemm(&h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, h->enc_gi, (long)T * 192, 192, B, T, 0, stream);
+        rd_scan_args s = { h->enc_gi, (long)T * 192, 192, h->enc_whh[l], h->enc_bhh[l], h->enc_h[l], x + in, xsb, W, NULL, NULL, B, T, 64 };
+        e |= rd_launch_gru_scan(&s, stream);
+        const int cin = in + 64;
+        e |= gemm(&h->enc_conv[l], x, xsb, W, cin, x - (long)ENC_DIL[l] * W, xsb, W, cin, NULL, NULL, x + cin, xsb, W, B, T, 1, stream);
+    }
+    e |= gemm(&h->enc_zdense, x, xsb, W, 864, NULL, 0, 0, 0, NULL, NULL, z, (long)T * RD_LATENT, RD_LATENT, B, T, 0, stream);
+    e |= rd_launch_carry_rows(h->enc_x, B, h->Tcap, W, 2, T, NULL, stream);
+    e |= rd_launch_ofdm_mod(h->d_tab, z, iq_out_dev, iq_stride, B, n_mf, stream);
+    return e ? -1 : n_mf * RD_NMF;
+}
+
+int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host)
+{
+    if (bits_host && hipMemcpy(h->eoo_bits, bits_host, sizeof(float) * h->B * RD_NEOOBITS, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (rd_launch_eoo_build(h->d_tab, bits_host ? h->eoo_bits : NULL, h->eoo, h->B, NULL)) return -1;
+    return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
+}
+
+int rade_batch_tx_eoo(rade_batch *h, void *iq_out_dev, long iq_stride, void *stream)
+{
+    return rd_launch_copy_eoo(h->eoo, iq_out_dev, iq_stride, h->B, stream) ? -1 : RD_NEOO;
+}
+
+/* ---- channel ----------------------------------------------------------------------------------- */
+float rade_sigma_from_EbNodB(float EbNodB)
+{   /* radae.py:567-573 (bottleneck 3): sigma = sqrt(Fs/(EbNo*Rb)), Rb = latent_dim/Tz */
+    const float EbNo = powf(10.0f, EbNodB / 10.0f), Rb = (float)(80.0 / (0.01 * 4));
+    return powf(8000.0f / (EbNo * Rb), 0.5f);
+}
+
+int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *rx_out_dev, long rx_stride, const rade_channel_params *p, void *stream)
+{
+    rd_chan_args a;
+    memset(&a, 0, sizeof a);
+    a.tab = h->d_tab; a.tx = tx_dev; a.tx_stride = tx_stride; a.rx = rx_out_dev; a.rx_stride = rx_stride; a.G = p->G_dev; a.noise = p->noise_dev;
+    a.eoo = h->eoo; a.scratch = h->chan_scratch; a.B = h->B; a.n_sig = p->n_sig; a.n_pre = p->n_pre; a.n_post = p->n_post; a.with_eoo = p->with_eoo;
+    a.sigma = p->sigma; a.freq_offset = p->freq_offset; a.df_dt = p->df_dt; a.seed = p->seed;
+    if (rd_launch_channel(&a, stream)) return -1;
+    return p->n_pre + p->n_sig + (p->with_eoo ? RD_NEOO : 0) + p->n_post;
+}
+
+/* ---- receive ----------------------------------------------------------------------------------- */
+static int decoder_round(rade_batch *h, void *stream)
+{   /* CoreDecoderStatefull.forward (radae_base.py:400-416) over the rows the sync kernel emitted */
+    const int B = h->B, T = RD_DEC_ROWS, W = RD_DEC_W;
+    const long xsb = (long)(1 + T) * W;
+    float *x = h->dec_x + W;                    /* slot 0 of each stream = conv history (previous valid step) */
+    const int *nr = h->rx_nrows, *rst = h->rx_rowreset;
+    int e = 0;
+    e |= gemm(&h->dec_dense1, h->zrows, (long)T * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
+    for (int l = 0; l < 5 && !e; l++) {
+        const int in = DEC_IN[l];
+        e |= gemm(&h->dec_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, nr, h->dec_gi, (long)T * 288, 288, B, T, 0, stream);
+        rd_scan_args s = { h->dec_gi, (long)T * 288, 288, h->dec_whh[l], h->dec_bhh[l], h->dec_h[l], h->dec_hbuf, (long)T * 96, 96, rst, nr, B, T, 96 };
+        e |= rd_launch_gru_scan(&s, stream);
+        e |= gemm(&h->dec_glu[l], h->dec_hbuf, (long)T * 96, 96, 96, NULL, 0, 0, 0, NULL, nr, x + in, xsb, W, B, T, 2, stream);
+        const int cin = in + 96;
+        e |= gemm(&h->dec_conv[l], x, xsb, W, cin, x - W, xsb, W, cin, rst, nr, x + cin, xsb, W, B, T, 1, stream);
+    }
+    e |= gemm(&h->dec_output, x, xsb, W, 736, NULL, 0, 0, 0, NULL, nr, h->feat84, (long)T * 84, 84, B, T, 0, stream);
+    return e;
+}
+
+int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *n_avail_host, int max_calls,
+                  float *features_out_dev, long feat_stride, float *eoo_out_dev, rade_rx_status *status_host, void *stream)
+{
+    if (!h || !n_avail_host || max_calls <= 0) return -1;
+    const int B = h->B;
+    hipStream_t st = (hipStream_t)stream;
+    int *hs = h->h_small;
+    CHK(hipMemcpyAsync(h->rx_avail, n_avail_host, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    CHK(hipMemsetAsync(h->rx_acc, 0, sizeof(int) * B * 4, st));
+    rd_sync_args sa;
+    memset(&sa, 0, sizeof sa);
+    sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
+    sa.max_calls = max_calls; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev;
+    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
+    rd_post_args pa;
+    memset(&pa, 0, sizeof pa);
+    pa.st = h->rx_st; pa.round = h->rx_round; pa.feat84 = h->feat84; pa.features_out = features_out_dev; pa.feat_stride = feat_stride;
+    pa.trace = h->trace; pa.trace_cap = h->trace_cap; pa.B = B;
+    for (;;) {
+        CHK(hipMemsetAsync(h->rx_progress, 0, sizeof(int) * 4, st));
+        if (rd_launch_rx_sync(&sa, st)) goto fail;
+        CHK(hipMemcpyAsync(hs, h->rx_progress, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        CHK(hipStreamSynchronize(st));
+        if (hs[0] == 0) break;                  /* no stream could make a call: out of samples or budget */
+        if (hs[1] > 0) {
+            if (decoder_round(h, st)) goto fail;
+            if (rd_launch_rx_post(&pa, st)) goto fail;
+            if (rd_launch_carry_rows(h->dec_x, B, RD_DEC_ROWS, RD_DEC_W, 1, 0, h->rx_nrows, st)) goto fail;
+        }
+    }
+    if (status_host) {
+        int *acc = hs + 8, *sts = hs + 8 + 4 * B;
+        CHK(hipMemcpyAsync(acc, h->rx_acc, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
+        CHK(hipMemcpyAsync(sts, h->rx_status, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
+        CHK(hipStreamSynchronize(st));
+        for (int b = 0; b < B; b++) {
+            rade_rx_status *s = status_host + b;
+            s->consumed = acc[4 * b]; s->n_calls = acc[4 * b + 1]; s->n_valid = acc[4 * b + 2]; s->has_eoo = acc[4 * b + 3] > 0;
+            s->nin = sts[4 * b]; s->sync = sts[4 * b + 1]; s->snr_dB = sts[4 * b + 2]; s->state = sts[4 * b + 3];
+        }
+    } else CHK(hipStreamSynchronize(st));
+    return 0;
+fail:
+    return -1;
+}
+
+int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls)
+{
+    if (!h->trace || b < 0 || b >= h->B) return -1;
+    rd_rx_stream *tmp = malloc(sizeof *tmp);
+    hipMemcpy(tmp, h->rx_st + b, sizeof *tmp, hipMemcpyDeviceToHost);
+    int n = tmp->mf - 1;
+    free(tmp);
+    if (n > h->trace_cap) n = h->trace_cap;
+    if (n > max_calls) n = max_calls;
+    if (n <= 0) return 0;
+    if (out) hipMemcpy(out, h->trace + (size_t)b * h->trace_cap, sizeof(rd_rx_trace) * n, hipMemcpyDeviceToHost);
+    if (z_hat_out) hipMemcpy(z_hat_out, h->trace_z + (size_t)b * h->trace_cap * RD_ZMF, sizeof(float) * n * RD_ZMF, hipMemcpyDeviceToHost);
+    return n;
+}

@@ -1,0 +1,267 @@
+/*
+ * rade_host.c -- host-side (plain C) model preparation for the HIP engine:
+ *   1. constant tables of the OFDM modem (rd_tables), evaluated with the same float32/float64 steps
+ *      NumPy/PyTorch take in the reference so the device kernels see bit-comparable constants;
+ *   2. DNNw weight-blob reader -> fp32 matrices (the blob is int8 + per-row scales for most layers);
+ *   3. weight packing into the MFMA fragment order k_gemm streams.
+ *
+ * Reference: radae/radae.py:128-234 (numerology/DFT/pilots/EOO), radae/dsp.py:40-61 (BPF),
+ * :153-176 (p_w), :400-416 (Pmat); blob format src/write_rade_weights.c:51-74 and
+ * weight-exchange/wexchange/c_export/common.py:59-69,140-176,263-271,290-293,307-311,360-368.
+ */
+#include "rade_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PI_D 3.14159265358979323846
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. tables
+ * -------------------------------------------------------------------------------------------*/
+static void pa_limit_host(float *re, float *im)
+{   /* tanh(|x|)*exp(1j*angle(x)) in float32 (radae.py:218) */
+    float mag = hypotf(*re, *im), ang = atan2f(*im, *re), t = tanhf(mag);
+    *re = t * cosf(ang); *im = t * sinf(ang);
+}
+
+void rd_tables_fill(rd_tables *T)
+{
+    static const float barker13[13] = { 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1 };
+    float w[RD_NC];
+    memset(T, 0, sizeof *T);
+    /* w = 2*pi*(15+arange(30))/160 as float32 tensor arithmetic (radae.py:172-174) */
+    const float two_pi = (float)(2.0 * PI_D);
+    for (int c = 0; c < RD_NC; c++) w[c] = (two_pi * (float)(15 + c)) / 160.0f;
+    for (int c = 0; c < RD_NC; c++)
+        for (int n = 0; n < RD_M; n++) {
+            const float arg = (float)n * w[c];          /* float32 product, then exp(1j*arg) in float32 */
+            const float cs = (float)cos((double)arg), sn = (float)sin((double)arg);
+            T->Winv[c][n][0] = cs / 160.0f; T->Winv[c][n][1] = sn / 160.0f;
+            T->Wfwd[n][c][0] = cs; T->Wfwd[n][c][1] = -sn;
+        }
+    const float r2 = (float)sqrt(2.0);
+    for (int c = 0; c < RD_NC; c++) { T->P[c] = r2 * barker13[c % 13]; T->Pend[c] = (c & 1) ? -T->P[c] : T->P[c]; }
+    for (int n = 0; n < RD_M; n++) {                    /* p = P @ Winv, pend = Pend @ Winv (complex64) */
+        float ar = 0, ai = 0, br = 0, bi = 0;
+        for (int c = 0; c < RD_NC; c++) {
+            const float wr = T->Winv[c][n][0], wi = T->Winv[c][n][1];
+            ar += T->P[c] * wr - 0.0f * wi; ai += T->P[c] * wi + 0.0f * wr;
+            br += T->Pend[c] * wr - 0.0f * wi; bi += T->Pend[c] * wi + 0.0f * wr;
+        }
+        T->p[n][0] = ar; T->p[n][1] = ai; T->pend[n][0] = br; T->pend[n][1] = bi;
+    }
+    T->pilot_gain = (float)(pow(10.0, -2.0 / 20.0) * 160.0 / sqrt(30.0));
+    /* default EOO frame: [p_cp][pend_cp][0][0][0][pend_cp] * pilot_gain, PA-limited */
+    for (int n = 0; n < RD_SYM; n++) {
+        const int src = n < RD_NCP ? RD_M - RD_NCP + n : n - RD_NCP;
+        T->eoo[n][0] = T->p[src][0]; T->eoo[n][1] = T->p[src][1];
+        T->eoo[RD_SYM + n][0] = T->pend[src][0]; T->eoo[RD_SYM + n][1] = T->pend[src][1];
+        T->eoo[RD_NMF + n][0] = T->pend[src][0]; T->eoo[RD_NMF + n][1] = T->pend[src][1];
+    }
+    for (int n = 0; n < RD_NEOO; n++) { T->eoo[n][0] *= T->pilot_gain; T->eoo[n][1] *= T->pilot_gain; pa_limit_host(&T->eoo[n][0], &T->eoo[n][1]); }
+    /* 3-pilot least-squares matrices Pmat[c] = inv(A^T A) A^T with A = [[1, e^{-j w a}]] (plain transpose) */
+    for (int c = 0; c < RD_NC; c++) {
+        const int cm = c == 0 ? 1 : (c == RD_NC - 1 ? RD_NC - 2 : c);
+        double er[3], ei[3];
+        for (int k = 0; k < 3; k++) { const float ang = -(w[cm - 1 + k] * 20.0f); er[k] = (float)cos((double)ang); ei[k] = (float)sin((double)ang); }
+        double s1r = er[0] + er[1] + er[2], s1i = ei[0] + ei[1] + ei[2], s2r = 0, s2i = 0;
+        for (int k = 0; k < 3; k++) { s2r += er[k] * er[k] - ei[k] * ei[k]; s2i += 2 * er[k] * ei[k]; }
+        double dr = 3 * s2r - (s1r * s1r - s1i * s1i), di = 3 * s2i - 2 * s1r * s1i;
+        double dn = dr * dr + di * di, ir = dr / dn, ii = -di / dn;
+        for (int k = 0; k < 3; k++) {
+            double a0r = s2r - (s1r * er[k] - s1i * ei[k]), a0i = s2i - (s1r * ei[k] + s1i * er[k]);
+            double a1r = 3 * er[k] - s1r, a1i = 3 * ei[k] - s1i;
+            T->Pmat[c][0][k][0] = (float)(ir * a0r - ii * a0i); T->Pmat[c][0][k][1] = (float)(ir * a0i + ii * a0r);
+            T->Pmat[c][1][k][0] = (float)(ir * a1r - ii * a1i); T->Pmat[c][1][k][1] = (float)(ir * a1i + ii * a1r);
+        }
+        const float ang = -(w[c] * 20.0f);
+        T->eq_rot[c][0] = (float)cos((double)ang); T->eq_rot[c][1] = (float)sin((double)ang);
+    }
+    /* input band-pass filter: 101-tap sinc low-pass at baseband, float32 like NumPy builds it */
+    const float bandwidth = ((1.2f * (w[RD_NC - 1] - w[0])) * 8000.0f) / two_pi;
+    const float centre = (((w[RD_NC - 1] + w[0]) * 8000.0f) / two_pi) / 2.0f;
+    const float Bn = bandwidth / 8000.0f, alpha = (two_pi * centre) / 8000.0f;
+    for (int i = 0; i < RD_NTAP; i++) {
+        const float x = (float)(i - 50) * Bn;
+        const float y = (float)PI_D * (x == 0.0f ? 1.0e-20f : x);
+        T->bpf_h[i] = Bn * ((float)sin((double)y) / y);
+    }
+    for (int k = 0; k < RD_NINMAX; k++) {
+        const float arg = (float)((double)alpha * (double)(k + 1));
+        T->bpf_E[k][0] = (float)cos((double)arg); T->bpf_E[k][1] = (float)-sin((double)arg);
+    }
+    /* coarse acquisition grid and frequency-shifted pilot replicas */
+    for (int f = 0; f < RD_NFC; f++) {
+        T->fcoarse[f] = -50.0 + 2.5 * f;
+        const double wf = 2.0 * PI_D * T->fcoarse[f] / 8000.0;
+        for (int n = 0; n < RD_M; n++) {
+            const double cr = cos(wf * n), ci = sin(wf * n), pr = T->p[n][0], pi = T->p[n][1];
+            T->p_w[n][f][0] = (float)(cr * pr - ci * pi); T->p_w[n][f][1] = (float)(cr * pi + ci * pr);
+        }
+    }
+    T->snr_c1 = (float)(10.0 * log10(50.0 * 30 / 3000.0));
+    T->snr_c2 = (float)(10.0 * log10(192.0 / 160.0));
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. DNNw blob
+ * -------------------------------------------------------------------------------------------*/
+typedef struct { const char *name; int type, size; const unsigned char *data; } dnnw_rec;
+
+static const dnnw_rec *rec_find(const dnnw_rec *r, int n, const char *base, const char *suffix)
+{
+    char nm[96];
+    snprintf(nm, sizeof nm, "%s%s", base, suffix);
+    for (int i = 0; i < n; i++) if (!strcmp(r[i].name, nm)) return &r[i];
+    return NULL;
+}
+
+static int dequant_dense_float(const dnnw_rec *R, int n, const char *name, rd_linear *l)
+{
+    const dnnw_rec *b = rec_find(R, n, name, "_bias"), *w = rec_find(R, n, name, "_weights_float");
+    if (!b || !w) return -1;
+    l->n_out = b->size / 4; l->n_in = w->size / 4 / l->n_out;
+    l->b = malloc(sizeof(float) * l->n_out); l->w = malloc(sizeof(float) * l->n_in * l->n_out);
+    memcpy(l->b, b->data, sizeof(float) * l->n_out);
+    const float *src = (const float *)w->data;                     /* stored as W^T: (n_in, n_out) */
+    for (int i = 0; i < l->n_in; i++) for (int o = 0; o < l->n_out; o++) l->w[(size_t)o * l->n_in + i] = src[(size_t)i * l->n_out + o];
+    return 0;
+}
+
+static int dequant_dense_int8(const dnnw_rec *R, int n, const char *name, rd_linear *l)
+{
+    const dnnw_rec *b = rec_find(R, n, name, "_bias"), *s = rec_find(R, n, name, "_scale"), *q = rec_find(R, n, name, "_weights_int8");
+    if (!b || !s || !q) return -1;
+    l->n_out = b->size / 4; l->n_in = q->size / l->n_out;
+    l->b = malloc(sizeof(float) * l->n_out); l->w = malloc(sizeof(float) * l->n_in * l->n_out);
+    memcpy(l->b, b->data, sizeof(float) * l->n_out);
+    const float *sc = (const float *)s->data; const signed char *qq = (const signed char *)q->data;
+    const int blocks_in = l->n_in / 4;
+    size_t pos = 0;                                                  /* walk the [n_out/8][n_in/4][8][4] tiles in storage order */
+    for (int og = 0; og < l->n_out / 8; og++)
+        for (int ib = 0; ib < blocks_in; ib++)
+            for (int o8 = 0; o8 < 8; o8++)
+                for (int i4 = 0; i4 < 4; i4++, pos++) {
+                    const int o = og * 8 + o8;
+                    l->w[(size_t)o * l->n_in + ib * 4 + i4] = (float)qq[pos] * (sc[o] * 127.0f);
+                }
+    return 0;
+}
+
+static int dequant_blocksparse_int8(const dnnw_rec *R, int n, const char *name, rd_linear *l)
+{
+    const dnnw_rec *b = rec_find(R, n, name, "_bias"), *s = rec_find(R, n, name, "_scale"), *q = rec_find(R, n, name, "_weights_int8"),
+                   *ix = rec_find(R, n, name, "_weights_idx");
+    if (!b || !s || !q || !ix) return -1;
+    l->n_out = b->size / 4;
+    const int *idx = (const int *)ix->data; const int nidx = ix->size / 4;
+    const float *sc = (const float *)s->data; const signed char *qq = (const signed char *)q->data;
+    int n_in = 0;
+    for (int p = 0, g = 0; g < l->n_out / 8 && p < nidx; g++) { const int cnt = idx[p++]; for (int k = 0; k < cnt; k++, p++) if (idx[p] + 4 > n_in) n_in = idx[p] + 4; }
+    l->n_in = n_in;
+    l->b = malloc(sizeof(float) * l->n_out); l->w = calloc((size_t)l->n_in * l->n_out, sizeof(float));
+    memcpy(l->b, b->data, sizeof(float) * l->n_out);
+    size_t pos = 0;
+    for (int p = 0, g = 0; g < l->n_out / 8; g++) {
+        const int cnt = idx[p++];
+        for (int k = 0; k < cnt; k++) {
+            const int j = idx[p++];
+            for (int o8 = 0; o8 < 8; o8++) for (int i4 = 0; i4 < 4; i4++, pos++) {
+                const int o = g * 8 + o8;
+                l->w[(size_t)o * l->n_in + j + i4] = (float)qq[pos] * (sc[o] * 127.0f);
+            }
+        }
+    }
+    return 0;
+}
+
+static void swap_first_two_thirds(float *a, int third)
+{   /* exporter wrote gates as z,r,n; torch (and our kernels) use r,z,n */
+    for (int i = 0; i < third; i++) { const float t = a[i]; a[i] = a[third + i]; a[third + i] = t; }
+}
+
+static int load_gru(const dnnw_rec *R, int n, const char *name, rd_gru *g)
+{
+    char nm[64]; rd_linear in, rec;
+    snprintf(nm, sizeof nm, "%s_input", name); if (dequant_blocksparse_int8(R, n, nm, &in)) return -1;
+    snprintf(nm, sizeof nm, "%s_recurrent", name); if (dequant_dense_int8(R, n, nm, &rec)) return -1;
+    g->hid = rec.n_in; g->n_in = in.n_in; g->w_ih = in.w; g->b_ih = in.b; g->w_hh = rec.w; g->b_hh = rec.b;
+    swap_first_two_thirds(g->w_ih, g->hid * g->n_in); swap_first_two_thirds(g->w_hh, g->hid * g->hid);
+    swap_first_two_thirds(g->b_ih, g->hid); swap_first_two_thirds(g->b_hh, g->hid);
+    return 0;
+}
+
+int rd_model_parse(const void *blob, size_t len, rd_model *m)
+{
+    const unsigned char *p = blob;
+    dnnw_rec recs[256]; char names[256][48]; int n = 0;
+    size_t off = 0;
+    memset(m, 0, sizeof *m);
+    while (off + 64 <= len && n < 256) {
+        int ver, type, size, block;
+        if (memcmp(p + off, "DNNw", 4)) { fprintf(stderr, "rade: bad weight blob (offset %zu)\n", off); return -1; }
+        memcpy(&ver, p + off + 4, 4); memcpy(&type, p + off + 8, 4); memcpy(&size, p + off + 12, 4); memcpy(&block, p + off + 16, 4);
+        if (ver != 0 || off + 64 + (size_t)block > len) { fprintf(stderr, "rade: truncated weight blob\n"); return -1; }
+        memset(names[n], 0, 48); memcpy(names[n], p + off + 20, 44);
+        recs[n].name = names[n]; recs[n].type = type; recs[n].size = size; recs[n].data = p + off + 64;
+        n++; off += 64 + block;
+    }
+    int err = 0;
+    err |= dequant_dense_float(recs, n, "enc_dense1", &m->enc_dense1);
+    err |= dequant_dense_float(recs, n, "enc_zdense", &m->enc_zdense);
+    err |= dequant_dense_float(recs, n, "dec_dense1", &m->dec_dense1);
+    err |= dequant_dense_float(recs, n, "dec_output", &m->dec_output);
+    for (int i = 0; i < 5 && !err; i++) {
+        char nm[32];
+        snprintf(nm, sizeof nm, "enc_gru%d", i + 1); err |= load_gru(recs, n, nm, &m->enc_gru[i]);
+        snprintf(nm, sizeof nm, "dec_gru%d", i + 1); err |= load_gru(recs, n, nm, &m->dec_gru[i]);
+        snprintf(nm, sizeof nm, "enc_conv%d", i + 1); err |= dequant_dense_int8(recs, n, nm, &m->enc_conv[i]);
+        snprintf(nm, sizeof nm, "dec_conv%d", i + 1); err |= dequant_dense_int8(recs, n, nm, &m->dec_conv[i]);
+        snprintf(nm, sizeof nm, "dec_glu%d", i + 1); err |= dequant_dense_int8(recs, n, nm, &m->dec_glu[i]);
+    }
+    if (err) { fprintf(stderr, "rade: weight blob is missing layers\n"); rd_model_free(m); return -1; }
+    /* sanity: the architecture this engine is built for (radae_base.py:239-251, :377-393) */
+    static const int enc_in[5] = { 64, 224, 384, 544, 704 }, dec_in[5] = { 96, 224, 352, 480, 608 };
+    for (int i = 0; i < 5; i++)
+        if (m->enc_gru[i].n_in != enc_in[i] || m->enc_gru[i].hid != 64 || m->dec_gru[i].n_in != dec_in[i] || m->dec_gru[i].hid != 96 ||
+            m->enc_conv[i].n_in != 2 * (enc_in[i] + 64) || m->enc_conv[i].n_out != 96 || m->dec_conv[i].n_in != 2 * (dec_in[i] + 96) || m->dec_conv[i].n_out != 32) {
+            fprintf(stderr, "rade: unexpected layer shape in weight blob (layer %d)\n", i + 1); rd_model_free(m); return -1;
+        }
+    if (m->enc_dense1.n_in != 84 || m->enc_zdense.n_in != 864 || m->enc_zdense.n_out != 80 || m->dec_dense1.n_in != 80 || m->dec_output.n_out != 84) {
+        fprintf(stderr, "rade: unexpected dense layer shape in weight blob\n"); rd_model_free(m); return -1;
+    }
+    return 0;
+}
+
+static void lin_free(rd_linear *l) { free(l->w); free(l->b); l->w = l->b = NULL; }
+void rd_model_free(rd_model *m)
+{
+    lin_free(&m->enc_dense1); lin_free(&m->enc_zdense); lin_free(&m->dec_dense1); lin_free(&m->dec_output);
+    for (int i = 0; i < 5; i++) {
+        free(m->enc_gru[i].w_ih); free(m->enc_gru[i].w_hh); free(m->enc_gru[i].b_ih); free(m->enc_gru[i].b_hh);
+        free(m->dec_gru[i].w_ih); free(m->dec_gru[i].w_hh); free(m->dec_gru[i].b_ih); free(m->dec_gru[i].b_hh);
+        lin_free(&m->enc_conv[i]); lin_free(&m->dec_conv[i]); lin_free(&m->dec_glu[i]);
+    }
+    memset(m, 0, sizeof *m);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. packing for k_gemm: out[((kb*ntt + nt)*64 + lane)*4 + s] = W[nt*32 + (lane&31)][8kb + 4(lane>>5) + s]
+ * -------------------------------------------------------------------------------------------*/
+long rd_packed_size(int N, int K) { return (long)((K + 7) / 8) * ((N + 31) / 32) * 256; }
+
+long rd_pack_weights(const float *W, int N, int K, float *out)
+{
+    const int nkb = (K + 7) / 8, ntt = (N + 31) / 32;
+    for (int kb = 0; kb < nkb; kb++)
+        for (int nt = 0; nt < ntt; nt++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int s = 0; s < 4; s++) {
+                    const int nn = nt * 32 + (lane & 31), k = kb * 8 + 4 * (lane >> 5) + s;
+                    out[(((size_t)kb * ntt + nt) * 64 + lane) * 4 + s] = (nn < N && k < K) ? W[(size_t)nn * K + k] : 0.0f;
+                }
+    return rd_packed_size(N, K);
+}

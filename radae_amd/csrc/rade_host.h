@@ -1,0 +1,30 @@
+/* rade_host.h -- host-side model preparation (see rade_host.c) */
+#ifndef RADE_HOST_H
+#define RADE_HOST_H
+
+#include <stddef.h>
+
+#include "rade_dev.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int n_in, n_out; float *w, *b; } rd_linear;                 /* w[out][in] row-major */
+typedef struct { int n_in, hid; float *w_ih, *w_hh, *b_ih, *b_hh; } rd_gru; /* torch gate order r,z,n */
+
+typedef struct {
+    rd_linear enc_dense1, enc_zdense, dec_dense1, dec_output;
+    rd_gru enc_gru[5], dec_gru[5];
+    rd_linear enc_conv[5], dec_conv[5];   /* w[out][2*in]: columns [0,in) = older tap, [in,2in) = current frame */
+    rd_linear dec_glu[5];
+} rd_model;
+
+void rd_tables_fill(rd_tables *T);
+int rd_model_parse(const void *blob, size_t len, rd_model *m);
+void rd_model_free(rd_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,955 @@
+// rade_kernels.hip -- gfx950 (MI355X) kernels of the RADE hot path + the C launch shims.
+//
+// Kernel inventory (reference op each one replaces):
+//   k_gemm<NT>      f32 MFMA (v_mfma_f32_32x32x2_f32) skinny-N GEMM with fused bias/tanh/GLU epilogue:
+//                   every Linear / GRU-input / Conv1d(k=2) / GLU layer of CoreEncoder / CoreDecoder,
+//                   evaluated for all streams and all time steps of a chunk at once
+//                   (radae_base.py:260-286, :400-416; src/rade_enc.c:55-114; src/rade_dec.c:50-102)
+//   k_gru_scan<H>   the serial part of a GRU layer: h_t = f(gi_t, W_hh h_{t-1}); one workgroup per
+//                   stream, W_hh rows held in VGPRs, h in LDS (radae_base.py:97-108)
+//   k_enc_pack      12x36 feature frames -> 3x(4x21) encoder input rows, aux symbol -1 (radae_txe.py:114-121)
+//   k_ofdm_mod      QPSK map, pilot row, 30->160 IDFT, cyclic prefix, tanh PA limiter (dsp.py:340-378)
+//   k_eoo_build     end-of-over frame with 180 data bits (radae.py:208-219, :441-455)
+//   k_chan_power / k_chan_apply   rate-Fs two-path multipath, power normalisation, freq offset, AWGN,
+//                   EOO / noise framing (radae.py:529-589, inference.py:263-284)
+//   k_rx_sync       one workgroup per stream runs do_radae_rx (radae_rxe.py:171-330): BPF (dsp.py:63-102),
+//                   detect_pilots / refine / check_pilots (dsp.py:178-320), sync state machine, frequency
+//                   correction, OFDM demod + 3-pilot LS EQ (dsp.py:418-526)
+//   k_rx_post       decoder output -> 36-float feature frames, aux-bit (UW) error accounting
+//                   (rade_api.c:480-513, radae_rxe.py:300-319)
+//
+// Written for gfx950 only: 64-lane wavefronts, MFMA f32 32x32x2, LDS-resident per-stream working sets.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "rade_dev.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PI_D 3.14159265358979323846
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
+__device__ __forceinline__ float2 ld2(const float (*p)[2], int i) { return make_float2(p[i][0], p[i][1]); }
+
+__device__ float g_zero_row[2048];   // tap-0 source of a conv row whose decoder state was just reset
+
+// =====================================================================================================
+// GEMM: one wavefront = 32 rows x (32*NT) columns; A and packed-W fragments stream straight from
+// global/L2 into VGPRs as 16-byte loads (no LDS: each A row is read by exactly one wave, W is
+// L2-resident and shared by every wave).  Lane l holds A[row l&31][k = 8kb + 4(l>>5) + s], s=0..3,
+// and the packed W holds the matching k for the same lane, so MFMA s contracts k pairs
+// {8kb+s, 8kb+4+s}; summation order over k does not matter.
+// =====================================================================================================
+template <int NT>
+__global__ __launch_bounds__(64) void k_gemm(rd_gemm_args a)
+{
+    const int lane = threadIdx.x;
+    const int rows = a.B * a.T;
+    const int r0 = blockIdx.x * 32;
+    const int ntt = (a.N + 31) >> 5;
+    const int nt0 = blockIdx.y * NT;
+    int r = r0 + (lane & 31);
+    if (r >= rows) r = rows - 1;
+    const int b = r / a.T, t = r - b * a.T;
+    const int half = lane >> 5;
+    const float *p1 = a.a1 + b * a.a1_sb + t * a.a1_st + 4 * half;
+    const float *p0 = nullptr;
+    if (a.K0) {
+        const bool rst = a.reset && a.reset[r];
+        p0 = (rst ? g_zero_row : a.a0 + b * a.a0_sb + t * a.a0_st) + 4 * half;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+
+    const float *wp = a.Wp + ((size_t)nt0 * 64 + lane) * 4;
+    const size_t wstep = (size_t)ntt * 256;
+#pragma unroll 1
+    for (int seg = 0; seg < 2; seg++) {
+        const float *p = seg == 0 ? p0 : p1;
+        const int nkb = (seg == 0 ? a.K0 : a.K1) >> 3;
+        if (nkb == 0) continue;
+        f32x4 av = *(const f32x4 *)p;
+        f32x4 bv[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) bv[i] = *(const f32x4 *)(wp + i * 256);
+        for (int kb = 0; kb < nkb; kb++) {
+            f32x4 an = av; f32x4 bn[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++) bn[i] = bv[i];
+            if (kb + 1 < nkb) {          // prefetch next k-block while the MFMAs of this one run
+                an = *(const f32x4 *)(p + (kb + 1) * 8);
+#pragma unroll
+                for (int i = 0; i < NT; i++) bn[i] = *(const f32x4 *)(wp + wstep + i * 256);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < NT; i++)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[i][s], acc[i], 0, 0, 0);
+            av = an;
+#pragma unroll
+            for (int i = 0; i < NT; i++) bv[i] = bn[i];
+            wp += wstep;
+        }
+    }
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (j&3) + 8*(j>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int col = (nt0 + i) * 32 + (lane & 31);
+        if (col >= a.N) continue;
+        const float bias = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int rr = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
+            if (rr >= rows) continue;
+            const int bb = rr / a.T, tt = rr - bb * a.T;
+            if (a.n_rows && tt >= a.n_rows[bb]) continue;
+            float v = acc[i][j] + bias;
+            if (a.act == 1) v = clamp1(tanhf(v));
+            else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * sigmoid_f(v));
+            a.y[bb * a.y_sb + tt * a.y_st + col] = v;
+        }
+    }
+}
+
+extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
+{
+    const int rows = a->B * a->T;
+    if (rows <= 0) return 0;
+    const int ntt = (a->N + 31) >> 5;
+    hipStream_t st = (hipStream_t)s;
+    dim3 block(64);
+    if (ntt % 3 == 0) { dim3 grid((rows + 31) / 32, ntt / 3); hipLaunchKernelGGL(k_gemm<3>, grid, block, 0, st, *a); }
+    else if (ntt % 2 == 0) { dim3 grid((rows + 31) / 32, ntt / 2); hipLaunchKernelGGL(k_gemm<2>, grid, block, 0, st, *a); }
+    else { dim3 grid((rows + 31) / 32, ntt); hipLaunchKernelGGL(k_gemm<1>, grid, block, 0, st, *a); }
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================================
+// GRU recurrence.  Thread o < 3H owns row o of W_hh in registers; h lives in LDS and is broadcast.
+// =====================================================================================================
+template <int H>
+__global__ __launch_bounds__(((3 * H + 63) / 64) * 64) void k_gru_scan(rd_scan_args a)
+{
+    __shared__ __attribute__((aligned(16))) float hs[H];
+    __shared__ float gh[3 * H];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const bool active = tid < 3 * H;
+    float w[H];
+    float bias = 0.0f;
+    if (active) {
+        const float *wr = a.Whh + (size_t)tid * H;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) { f32x4 v = *(const f32x4 *)(wr + k); w[k] = v[0]; w[k + 1] = v[1]; w[k + 2] = v[2]; w[k + 3] = v[3]; }
+        bias = a.bhh[tid];
+    }
+    const int Tb = a.n_rows ? a.n_rows[b] : a.T;
+    __shared__ int rst[64];                      // reset flags are only used by the decoder rounds (T <= 64)
+    if (a.reset && tid < 64) rst[tid] = tid < a.T ? a.reset[b * a.T + tid] : 0;
+    if (tid < H) hs[tid] = a.h[(size_t)b * H + tid];
+    const float *gi = a.gi + (size_t)b * a.gi_sb;
+    float g_r = 0, g_z = 0, g_n = 0, q_r = 0, q_z = 0, q_n = 0;     // gi of step t and t+1 (prefetched)
+    if (tid < H && Tb > 0) { g_r = gi[tid]; g_z = gi[H + tid]; g_n = gi[2 * H + tid]; }
+    if (tid < H && Tb > 1) { const float *g = gi + a.gi_st; q_r = g[tid]; q_z = g[H + tid]; q_n = g[2 * H + tid]; }
+    __syncthreads();
+    for (int t = 0; t < Tb; t++) {
+        if (a.reset && rst[t]) {                       // uniform over the workgroup
+            __syncthreads();
+            if (tid < H) hs[tid] = 0.0f;
+            __syncthreads();
+        }
+        float n_r = 0, n_z = 0, n_n = 0;
+        if (tid < H && t + 2 < Tb) { const float *g = gi + (size_t)(t + 2) * a.gi_st; n_r = g[tid]; n_z = g[H + tid]; n_n = g[2 * H + tid]; }
+        if (active) {
+            float s0 = bias, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < H; k += 4) {
+                f32x4 hv = *(const f32x4 *)(hs + k);
+                s0 += w[k] * hv[0]; s1 += w[k + 1] * hv[1]; s2 += w[k + 2] * hv[2]; s3 += w[k + 3] * hv[3];
+            }
+            gh[tid] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (tid < H) {
+            const float r = sigmoid_f(gh[tid] + g_r);
+            const float z = sigmoid_f(gh[H + tid] + g_z);
+            const float n = tanhf(g_n + gh[2 * H + tid] * r);
+            const float hn = (hs[tid] - n) * z + n;
+            a.out[(size_t)b * a.out_sb + (size_t)t * a.out_st + tid] = clamp1(hn);
+            hs[tid] = hn;
+            g_r = q_r; g_z = q_z; g_n = q_n; q_r = n_r; q_z = n_z; q_n = n_n;
+        }
+        __syncthreads();
+    }
+    if (tid < H) a.h[(size_t)b * H + tid] = hs[tid];
+}
+
+extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
+{
+    if (a->B <= 0) return 0;
+    hipStream_t st = (hipStream_t)s;
+    if (a->H == 64) hipLaunchKernelGGL(k_gru_scan<64>, dim3(a->B), dim3(192), 0, st, *a);
+    else if (a->H == 96) hipLaunchKernelGGL(k_gru_scan<96>, dim3(a->B), dim3(320), 0, st, *a);
+    else return -1;
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================================
+// small data-movement kernels
+// =====================================================================================================
+__global__ void k_enc_pack(const float *features, float *xin, int B, int T)
+{
+    const long n = (long)B * T * RD_ENC_IN;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % RD_ENC_IN); const long bt = i / RD_ENC_IN;
+        float v = 0.0f;
+        if (c < 84) { const int fr = c / 21, j = c - fr * 21; v = j < 20 ? features[(bt * 4 + fr) * 36 + j] : -1.0f; }
+        xin[i] = v;
+    }
+}
+extern "C" int rd_launch_enc_pack(const float *features, float *xin, int B, int T, rd_stream_t s)
+{
+    const long n = (long)B * T * RD_ENC_IN; if (n <= 0) return 0;
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_enc_pack, dim3(grid), dim3(256), 0, (hipStream_t)s, features, xin, B, T);
+    return (int)hipGetLastError();
+}
+
+// x is [B][nhist+Tcap][W]; copy rows [Tb, Tb+nhist) -> [0, nhist)  (Tb = n_rows[b] or T).  Source and
+// destination overlap when Tb < nhist, so every thread reads all its elements before any write.
+__global__ __launch_bounds__(256) void k_carry_rows(float *x, int Tcap, int W, int nhist, int T, const int *n_rows)
+{
+    const int b = blockIdx.x;
+    const int Tb = n_rows ? n_rows[b] : T;
+    if (Tb <= 0) return;
+    float *base = x + (size_t)b * (nhist + Tcap) * W;
+    const int n = nhist * W;       // <= 2048
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int i = threadIdx.x + q * 256; v[q] = i < n ? base[(size_t)Tb * W + i] : 0.0f; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int i = threadIdx.x + q * 256; if (i < n) base[i] = v[q]; }
+}
+extern "C" int rd_launch_carry_rows(float *x, int B, int Tcap, int W, int nhist, int T, const int *n_rows, rd_stream_t s)
+{
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_carry_rows, dim3(B), dim3(256), 0, (hipStream_t)s, x, Tcap, W, nhist, T, n_rows);
+    return (int)hipGetLastError();
+}
+
+// tanh(|x|) * exp(j*angle(x))   (radae.py:218, dsp.py:377)
+__device__ __forceinline__ float2 pa_limit(float2 x)
+{
+    const float mag = hypotf(x.x, x.y), ang = atan2f(x.y, x.x);
+    const float t = tanhf(mag);
+    float sn, cs; sincosf(ang, &sn, &cs);
+    return make_float2(t * cs, t * sn);
+}
+
+// one workgroup per (modem frame, stream): 5 symbols x 160 samples, 30-term IDFT per sample
+__global__ __launch_bounds__(192) void k_ofdm_mod(const rd_tables *tab, const float *z, float2 *tx, long tx_stride, int n_mf)
+{
+    __shared__ float2 sym[RD_NS + 1][RD_NC];
+    const int mf = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *zf = z + ((size_t)b * n_mf + mf) * RD_ZMF;
+    if (tid < RD_NC) sym[0][tid] = make_float2(tab->P[tid] * tab->pilot_gain, 0.0f * tab->pilot_gain);
+    if (tid < 120) sym[1 + tid / RD_NC][tid % RD_NC] = make_float2(zf[2 * tid], zf[2 * tid + 1]);
+    __syncthreads();
+    float2 *out = tx + (size_t)b * tx_stride + (size_t)mf * RD_NMF;
+    if (tid < RD_M) {
+        for (int s = 0; s <= RD_NS; s++) {
+            float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll 6
+            for (int c = 0; c < RD_NC; c++) acc = cadd(acc, cmul(sym[s][c], ld2(tab->Winv[c], tid)));
+            const float2 v = pa_limit(acc);
+            out[s * RD_SYM + RD_NCP + tid] = v;
+            if (tid >= RD_M - RD_NCP) out[s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
+        }
+    }
+}
+extern "C" int rd_launch_ofdm_mod(const rd_tables *tab, const float *z, void *tx, long tx_stride, int B, int n_mf, rd_stream_t s)
+{
+    if (B <= 0 || n_mf <= 0) return 0;
+    hipLaunchKernelGGL(k_ofdm_mod, dim3(n_mf, B), dim3(192), 0, (hipStream_t)s, tab, z, (float2 *)tx, tx_stride, n_mf);
+    return (int)hipGetLastError();
+}
+
+// EOO frame per stream: default table copy, optionally with 3 data symbols (90 QPSK) inserted
+__global__ __launch_bounds__(192) void k_eoo_build(const rd_tables *tab, const float *bits, float2 *eoo)
+{
+    __shared__ float2 sym[RD_NS - 1][RD_NC];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float2 *out = eoo + (size_t)b * RD_NEOO;
+    for (int i = tid; i < RD_NEOO; i += blockDim.x) out[i] = ld2(tab->eoo, i);
+    if (!bits) return;
+    if (tid < 90) sym[tid / RD_NC][tid % RD_NC] = make_float2(bits[b * RD_NEOOBITS + 2 * tid], bits[b * RD_NEOOBITS + 2 * tid + 1]);
+    __syncthreads();
+    if (tid < RD_M) {
+        for (int s = 0; s < RD_NS - 1; s++) {
+            float2 acc = make_float2(0.0f, 0.0f);
+            for (int c = 0; c < RD_NC; c++) acc = cadd(acc, cmul(sym[s][c], ld2(tab->Winv[c], tid)));
+            const float2 v = pa_limit(make_float2(acc.x * tab->pilot_gain, acc.y * tab->pilot_gain));
+            out[(2 + s) * RD_SYM + RD_NCP + tid] = v;
+            if (tid >= RD_M - RD_NCP) out[(2 + s) * RD_SYM + tid - (RD_M - RD_NCP)] = v;
+        }
+    }
+}
+extern "C" int rd_launch_eoo_build(const rd_tables *tab, const float *bits, float *eoo, int B, rd_stream_t s)
+{
+    hipLaunchKernelGGL(k_eoo_build, dim3(B), dim3(192), 0, (hipStream_t)s, tab, bits, (float2 *)eoo);
+    return (int)hipGetLastError();
+}
+__global__ void k_copy_eoo(const float2 *eoo, float2 *out, long stride)
+{
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < RD_NEOO; i += blockDim.x) out[(size_t)b * stride + i] = eoo[(size_t)b * RD_NEOO + i];
+}
+extern "C" int rd_launch_copy_eoo(const float *eoo, void *out, long stride, int B, rd_stream_t s)
+{
+    hipLaunchKernelGGL(k_copy_eoo, dim3(B), dim3(256), 0, (hipStream_t)s, (const float2 *)eoo, (float2 *)out, stride);
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================================
+// channel simulator
+// =====================================================================================================
+#define CH_NCH 64   // partial-sum chunks per stream (fixed => deterministic reduction order)
+
+__device__ __forceinline__ float2 chan_mp(const float2 *tx, const float2 *G, int i)
+{
+    if (!G) return tx[i];
+    float2 v = cmul(tx[i], G[2 * i]);
+    if (i >= 16) v = cadd(v, cmul(tx[i - 16], G[2 * (i - 16) + 1]));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_chan_power(rd_chan_args a, double *part)
+{
+    __shared__ double red[2][256];
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const float2 *tx = (const float2 *)a.tx + (size_t)b * a.tx_stride;
+    const float2 *G = a.G ? (const float2 *)a.G + (size_t)b * a.n_sig * 2 : nullptr;
+    const int per = (a.n_sig + CH_NCH - 1) / CH_NCH;
+    const int lo = ch * per, hi = min(a.n_sig, lo + per);
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = lo + tid; i < hi; i += 256) {
+        const float2 x = tx[i], m = chan_mp(tx, G, i);
+        const float ax = hypotf(x.x, x.y), am = hypotf(m.x, m.y);
+        s0 += (double)(ax * ax); s1 += (double)(am * am);
+    }
+    red[0][tid] = s0; red[1][tid] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; } __syncthreads(); }
+    if (tid == 0) { part[((size_t)b * CH_NCH + ch) * 2] = red[0][0]; part[((size_t)b * CH_NCH + ch) * 2 + 1] = red[1][0]; }
+}
+
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11) -> two complex N(0,1/2)+jN(0,1/2) samples
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float2 gauss_pair(uint32_t u0, uint32_t u1)
+{   // Box-Muller, unit variance per component
+    const float a = ((float)u0 + 0.5f) * (1.0f / 4294967296.0f), bq = ((float)u1 + 0.5f) * (1.0f / 4294967296.0f);
+    const float rad = sqrtf(-2.0f * logf(a));
+    float sn, cs; sincosf(6.28318530718f * bq, &sn, &cs);
+    return make_float2(rad * cs, rad * sn);
+}
+
+__device__ __forceinline__ double chan_phase_acc(int i, float f0, float df_dt)
+{   // sum_{k<=i} omega_k, omega_k = float32(freq_k*2*pi/Fs) summed in double (torch.cumsum on CPU)
+    if (df_dt == 0.0f) { const float om = ((f0 * 2.0f) * (float)PI_D) / 8000.0f; return (double)(i + 1) * (double)om; }
+    const double n = (double)(i + 1);
+    return (2.0 * PI_D / 8000.0) * (n * (double)f0 + ((double)df_dt / 8000.0) * 0.5 * (double)i * n);
+}
+
+__global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double *part)
+{
+    const int b = blockIdx.y;
+    const int n_eoo = a.with_eoo ? RD_NEOO : 0;
+    const int n_total = a.n_pre + a.n_sig + n_eoo + a.n_post;
+    __shared__ float s_gain; __shared__ float2 s_fin;
+    if (threadIdx.x == 0) {
+        double p0 = 0.0, p1 = 0.0;
+        for (int c = 0; c < CH_NCH; c++) { p0 += part[((size_t)b * CH_NCH + c) * 2]; p1 += part[((size_t)b * CH_NCH + c) * 2 + 1]; }
+        const float tx_power = (float)(p0 / a.n_sig), mp_power = (float)(p1 / a.n_sig);
+        s_gain = a.G ? powf(tx_power / mp_power, 0.5f) : 1.0f;
+        float2 fin = make_float2(1.0f, 0.0f);
+        if (a.freq_offset != 0.0f && a.n_sig > 0) { float sn, cs; sincosf((float)chan_phase_acc(a.n_sig - 1, a.freq_offset, a.df_dt), &sn, &cs); fin = make_float2(cs, sn); }
+        s_fin = fin;
+    }
+    __syncthreads();
+    const float gain = s_gain; const float2 fin = s_fin;
+    const float2 *tx = (const float2 *)a.tx + (size_t)b * a.tx_stride;
+    const float2 *G = a.G ? (const float2 *)a.G + (size_t)b * a.n_sig * 2 : nullptr;
+    const float2 *noise = a.noise ? (const float2 *)a.noise + (size_t)b * n_total : nullptr;
+    const float2 *eoo = (const float2 *)a.eoo + (size_t)b * RD_NEOO;
+    float2 *rx = (float2 *)a.rx + (size_t)b * a.rx_stride;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_total; j += gridDim.x * 256) {
+        float2 v = make_float2(0.0f, 0.0f);
+        bool real_noise = true;
+        const int i = j - a.n_pre;
+        if (i >= 0 && i < a.n_sig) {
+            real_noise = false;
+            const float2 m = chan_mp(tx, G, i);
+            v = make_float2(m.x * gain, m.y * gain);
+            if (a.freq_offset != 0.0f) { float sn, cs; sincosf((float)chan_phase_acc(i, a.freq_offset, a.df_dt), &sn, &cs); v = cmul(v, make_float2(cs, sn)); }
+        } else if (i >= a.n_sig && i < a.n_sig + n_eoo) {
+            real_noise = false;
+            const int e = i - a.n_sig;
+            float sn, cs; sincosf((float)chan_phase_acc(e, a.freq_offset, a.df_dt), &sn, &cs);
+            v = cmul(cmul(eoo[e], make_float2(cs, sn)), fin);
+        }
+        if (noise) { v.x += a.sigma * noise[j].x; v.y += a.sigma * noise[j].y; }
+        else if (a.seed) {
+            uint32_t r[4];
+            philox4x32((uint32_t)j, (uint32_t)b, 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+            const float2 g = gauss_pair(r[0], r[1]);
+            if (real_noise) v.x += a.sigma * g.x;                                  // inference.py:277-284: real-valued randn
+            else { v.x += a.sigma * 0.70710678f * g.x; v.y += a.sigma * 0.70710678f * g.y; }   // complex randn: 1/2 per component
+        }
+        rx[j] = v;
+    }
+}
+
+extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
+{
+    if (a->B <= 0) return 0;
+    hipStream_t st = (hipStream_t)s;
+    double *part = (double *)a->scratch;
+    hipLaunchKernelGGL(k_chan_power, dim3(CH_NCH, a->B), dim3(256), 0, st, *a, part);
+    const int n_total = a->n_pre + a->n_sig + (a->with_eoo ? RD_NEOO : 0) + a->n_post;
+    int gx = (n_total + 255) / 256; if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_chan_apply, dim3(gx, a->B), dim3(256), 0, st, *a, (const double *)part);
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================================
+// receiver: one workgroup (256 threads) per stream, up to RD_RX_ROUND do_radae_rx calls per launch
+// =====================================================================================================
+enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
+#define NT_RX 256
+
+struct RxScalars {
+    int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
+    uint32_t lcg;
+    int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, blocked, pending_valid, out_base;
+    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate;
+    float snr_est, mag; float2 bpf_phase;
+    double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
+};
+
+struct RxShared {
+    RxScalars S;
+    float2 bmem[102];                     // BPF memory (dsp.py:55,96)
+    float2 rxb[RD_RXBUF];                 // rx_buf (radae_rxe.py:141)
+    float2 xm[102 + RD_NINMAX + 2];       // BPF [mem | mixed-down new]; reused as rx1[1152] for the demod
+    float2 pw[RD_M][RD_NFC];              // acquisition.p_w
+    float2 sym[6][RD_NC];
+    float2 rp[2][RD_NC];
+    float bpf_h[RD_NTAP + 3];
+    float absd[96][RD_NFC + 1];           // check_pilots scratch |Dt| rows
+    float rowsum1[RD_NMF], rowsum2[RD_NMF]; // sum_f |Dt1[t,f]|, |Dt2[t,f]|
+    int rows48[48];
+    double redd[NT_RX];                   // block reductions (double)
+    float redf[NT_RX]; int redi[NT_RX]; int redj[NT_RX];
+};
+
+// max reduction with lexicographic tie-break (smaller k0, then smaller k1 wins); result in sh->redf[0], redi[0], redj[0]
+__device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
+{
+    const int tid = threadIdx.x;
+    sh->redf[tid] = v; sh->redi[tid] = k0; sh->redj[tid] = k1;
+    __syncthreads();
+    for (int w = NT_RX / 2; w > 0; w >>= 1) {
+        if (tid < w) {
+            const float ov = sh->redf[tid + w]; const int o0 = sh->redi[tid + w], o1 = sh->redj[tid + w];
+            const float mv = sh->redf[tid]; const int m0 = sh->redi[tid], m1 = sh->redj[tid];
+            const bool take = ov > mv || (ov == mv && (o0 < m0 || (o0 == m0 && o1 < m1)));
+            if (take) { sh->redf[tid] = ov; sh->redi[tid] = o0; sh->redj[tid] = o1; }
+        }
+        __syncthreads();
+    }
+}
+__device__ double block_sum_d(RxShared *sh, double v)
+{
+    const int tid = threadIdx.x;
+    sh->redd[tid] = v; __syncthreads();
+    for (int w = NT_RX / 2; w > 0; w >>= 1) { if (tid < w) sh->redd[tid] += sh->redd[tid + w]; __syncthreads(); }
+    const double r = sh->redd[0]; __syncthreads();
+    return r;
+}
+
+// correlate conj(rx[t..t+160)) and conj(rx[t+Nmf..)) with p_w[:, f0..f0+NF) -> |Dt1|, |Dt2| (dsp.py:207-209).
+// Both modem frames share the p_w reads, which keeps the loop VALU-bound instead of LDS-bound.
+template <int NF>
+__device__ __forceinline__ void corr_rows2(const RxShared *sh, int t, int f0, float *abs1, float *abs2)
+{
+    float2 a1[NF], a2[NF];
+#pragma unroll
+    for (int f = 0; f < NF; f++) { a1[f] = make_float2(0.0f, 0.0f); a2[f] = make_float2(0.0f, 0.0f); }
+    for (int m = 0; m < RD_M; m++) {
+        const float2 x = sh->rxb[t + m], y = sh->rxb[t + RD_NMF + m];   // conj applied in the product: (xr, -xi)
+#pragma unroll
+        for (int f = 0; f < NF; f++) {
+            const float2 w = sh->pw[m][f0 + f];
+            a1[f].x += x.x * w.x + x.y * w.y; a1[f].y += x.x * w.y - x.y * w.x;
+            a2[f].x += y.x * w.x + y.y * w.y; a2[f].y += y.x * w.y - y.y * w.x;
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NF; f++) { abs1[f] = hypotf(a1[f].x, a1[f].y); abs2[f] = hypotf(a2[f].x, a2[f].y); }
+}
+
+__device__ float sigma_r_from_rowsums(RxShared *sh)
+{   // dsp.py:218-220: (mean|Dt1| + mean|Dt2|)/sqrt(pi/2)/2 in float32
+    const int tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = tid; t < RD_NMF; t += NT_RX) { s1 += (double)sh->rowsum1[t]; s2 += (double)sh->rowsum2[t]; }
+    const double t1 = block_sum_d(sh, s1), t2 = block_sum_d(sh, s2);
+    const float k = (float)sqrt(PI_D / 2.0);
+    const float m1 = (float)(t1 / (RD_NMF * RD_NFC)) / k, m2 = (float)(t2 / (RD_NMF * RD_NFC)) / k;
+    return (m1 + m2) / 2.0f;
+}
+
+// refine(): fine timing/frequency search maximising |Dt1+Dt2| (dsp.py:233-270); complex128 dots rounded to complex64
+__device__ void rx_refine(RxShared *sh, const rd_tables *tab, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep)
+{
+    const int tid = threadIdx.x;
+    const int nf = (int)ceil((fstop - fstart) / fstep);                 // np.arange length
+    const double delta = (fstart + fstep) - fstart;                       // np.arange fill rule
+    float best = -1.0f; int bf = 0x7fffffff, bt = 0x7fffffff;
+    for (int task = tid; task < nf * nt; task += NT_RX) {
+        const int fi = task / nt, ti = task - fi * nt;
+        const double f = fstart + fi * delta;
+        const double w = 2.0 * PI_D * f / 8000.0;
+        const int t = t0 + ti;
+        double sr, cr; sincos(-w, &sr, &cr);                                // per-sample rotation e^{-jw}
+        double zr = 1.0, zi = 0.0, ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+        for (int n = 0; n < RD_M; n++) {
+            if ((n & 31) == 0) sincos(-w * n, &zi, &zr);                    // re-anchor the recurrence
+            const double pr = (double)tab->p[n][0], pi = -(double)tab->p[n][1];
+            const double qr = zr * pr - zi * pi, qi = zr * pi + zi * pr;  // w_vec1 * conj(p)
+            const float2 x = sh->rxb[t + n], y = sh->rxb[t + RD_NMF + n];
+            ar += (double)x.x * qr - (double)x.y * qi; ai += (double)x.x * qi + (double)x.y * qr;
+            br += (double)y.x * qr - (double)y.y * qi; bi += (double)y.x * qi + (double)y.y * qr;
+            const double nzr = zr * cr - zi * sr; zi = zr * sr + zi * cr; zr = nzr;
+        }
+        double s2, c2; sincos(-w * RD_NMF, &s2, &c2);                       // w_vec2 = w_vec1*exp(-1j*w*Nmf)
+        const double b2r = br * c2 - bi * s2, b2i = br * s2 + bi * c2;
+        const float vr = (float)ar + (float)b2r, vi = (float)ai + (float)b2i;   // complex64 Dt1 + Dt2
+        const float v = hypotf(vr, vi);
+        if (v > best || (v == best && (fi < bf || (fi == bf && ti < bt)))) { best = v; bf = fi; bt = ti; }
+    }
+    block_argmax(sh, best, bf, bt);
+    if (sh->redf[0] > 0.0f) { *tmax = t0 + sh->redj[0]; *fmax = fstart + sh->redi[0] * delta; }
+    __syncthreads();
+}
+
+// |dot(conj(w_vec*rx[t0..]), ref)| in complex128 (dsp.py:307-313)
+__device__ double rx_corr_abs(RxShared *sh, int t0, double w, const float (*ref)[2])
+{
+    const int tid = threadIdx.x;
+    double ar = 0.0, ai = 0.0;
+    if (tid < RD_M) {
+        double s, c; sincos(-w * tid, &s, &c);
+        const float2 x = sh->rxb[t0 + tid];
+        const double qr = c * x.x - s * x.y, qi = -(c * x.y + s * x.x);    // conj(w_vec*rx)
+        const double rr = ref[tid][0], ri = ref[tid][1];
+        ar = qr * rr - qi * ri; ai = qr * ri + qi * rr;
+    }
+    const double sr = block_sum_d(sh, ar), si = block_sum_d(sh, ai);
+    return hypot(sr, si);
+}
+
+// Scalar receiver state lives in LDS (sh->S): thread 0 is the only writer, everybody reads it after a
+// barrier.  (Keeping ~40 loop-carried "uniform" scalars in every thread's registers cost 256 VGPRs
+// and proved fragile under -O3.)
+__global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    RxShared *sh = (RxShared *)smem_raw;
+    RxScalars *S = &sh->S;
+    const rd_tables *tab = a.tab;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    rd_rx_stream *st = a.st + b;
+    rd_rx_round *rnd = a.round + b;
+    const float2 *rxin = (const float2 *)a.rx + (size_t)b * a.rx_stride;
+
+    // ---- load the stream's working set into LDS
+    for (int i = tid; i < RD_RXBUF; i += NT_RX) sh->rxb[i] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]);
+    for (int i = tid; i < RD_M * RD_NFC; i += NT_RX) sh->pw[i / RD_NFC][i % RD_NFC] = make_float2(tab->p_w[i / RD_NFC][i % RD_NFC][0], tab->p_w[i / RD_NFC][i % RD_NFC][1]);
+    for (int i = tid; i < RD_NTAP; i += NT_RX) sh->bpf_h[i] = tab->bpf_h[i];
+    for (int i = tid; i < RD_NMF; i += NT_RX) { sh->rowsum1[i] = st->rowsum1[i]; sh->rowsum2[i] = st->rowsum2[i]; }
+    for (int i = tid; i < 102; i += NT_RX) sh->bmem[i] = make_float2(st->bpf_mem[i][0], st->bpf_mem[i][1]);
+    if (tid == 0) {
+        S->state = st->state; S->nin = st->nin; S->tmax = st->tmax; S->tmax_candidate = st->tmax_candidate; S->valid_count = st->valid_count;
+        S->uw_errors = st->uw_errors; S->synced_count = st->synced_count; S->mf = st->mf; S->f_ind_max = st->f_ind_max;
+        S->dec_reset_pending = st->dec_reset_pending; S->bpf_mem_len = st->bpf_mem_len; S->has_eoo = st->has_eoo; S->lcg = st->lcg;
+        S->fmax = st->fmax; S->foff_err = st->foff_err; S->rph_r = st->rx_phase[0]; S->rph_i = st->rx_phase[1];
+        S->Dthresh = st->Dthresh; S->Dtmax12 = st->Dtmax12; S->Dtmax12_eoo = st->Dtmax12_eoo; S->snr_est = st->snr_est;
+        S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
+        S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
+        S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->blocked = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
+        S->go = 0;
+    }
+    const int avail = a.avail[b];
+    __syncthreads();
+
+    for (int it = 0; it < RD_RX_ROUND; it++) {
+        // ---- can this stream make another call right now?  (decided once, by thread 0)
+        if (tid == 0) {
+            int go = 1;
+            if (S->calls_inv >= a.max_calls) go = 0;
+            else if (S->consumed_inv + S->nin > avail) go = 0;
+            else if (S->state == ST_SYNC && S->pending_valid > 0 && ((S->synced_count + 1) % 8) == 0) { S->blocked = 1; go = 0; }  // UW decision needs the decoder
+            S->go = go;
+            S->state_before = S->state; S->nin_before = S->nin;
+            S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
+        }
+        __syncthreads();
+        if (!S->go) break;
+        const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
+        const float2 bpf_phase = S->bpf_phase;
+
+        // ---- complex_bpf.bpf (dsp.py:63-102)
+        const float2 *xin = rxin + S->consumed_inv;
+        for (int i = tid; i < ml; i += NT_RX) sh->xm[i] = sh->bmem[i];
+        for (int i = tid; i < nin; i += NT_RX) {
+            const float2 pv = cmul(bpf_phase, ld2(tab->bpf_E, i));
+            sh->xm[ml + i] = cmul(xin[i], pv);
+        }
+        __syncthreads();
+        float2 filt[(RD_NINMAX + NT_RX - 1) / NT_RX];
+#pragma unroll
+        for (int q = 0; q < (RD_NINMAX + NT_RX - 1) / NT_RX; q++) {
+            const int i = tid + q * NT_RX;
+            float ar = 0.0f, ai = 0.0f;
+            if (i < nin) {
+                for (int k = 0; k < RD_NTAP; k++) { const float2 x = sh->xm[i + k]; const float h = sh->bpf_h[k]; ar += x.x * h; ai += x.y * h; }
+                const float2 pv = cmul(bpf_phase, ld2(tab->bpf_E, i));
+                const float2 o = cmul(make_float2(ar, ai), cconj(pv));
+                ar = o.x; ai = o.y;
+            }
+            filt[q] = make_float2(ar, ai);
+        }
+        // new BPF memory = last 102 of [mem | new]; rx_buf shift (radae_rxe.py:196-197)
+        float2 keep[(RD_RXBUF + NT_RX - 1) / NT_RX];
+#pragma unroll
+        for (int q = 0; q < (RD_RXBUF + NT_RX - 1) / NT_RX; q++) { const int i = tid + q * NT_RX; keep[q] = (i + nin < RD_RXBUF) ? sh->rxb[i + nin] : make_float2(0.0f, 0.0f); }
+        float2 memv = make_float2(0.0f, 0.0f);
+        if (tid < 102) memv = sh->xm[ml + nin - 102 + tid];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (RD_RXBUF + NT_RX - 1) / NT_RX; q++) { const int i = tid + q * NT_RX; if (i + nin < RD_RXBUF) sh->rxb[i] = keep[q]; }
+#pragma unroll
+        for (int q = 0; q < (RD_NINMAX + NT_RX - 1) / NT_RX; q++) { const int i = tid + q * NT_RX; if (i < nin) sh->rxb[RD_RXBUF - nin + i] = filt[q]; }
+        if (tid < 102) sh->bmem[tid] = memv;
+        if (tid == 0) {
+            S->bpf_phase = cmul(bpf_phase, ld2(tab->bpf_E, nin - 1));
+            S->bpf_mem_len = 102; S->consumed_inv += nin; S->consumed_round += nin;
+        }
+        __syncthreads();
+
+        if (state == ST_SEARCH || state == ST_CANDIDATE) {
+            // ---- acquisition.detect_pilots (dsp.py:178-231): rows t and t+Nmf by the same thread
+            float best = -1.0f; int bt = 0x7fffffff, bfi = 0;
+            for (int t = tid; t < RD_NMF; t += NT_RX) {
+                float rs1 = 0.0f, rs2 = 0.0f, lmax = -1.0f; int larg = 0;
+#pragma unroll 1
+                for (int f0 = 0; f0 < RD_NFC; f0 += 8) {
+                    float a1[8], a2[8];
+                    corr_rows2<8>(sh, t, f0, a1, a2);
+#pragma unroll
+                    for (int f = 0; f < 8; f++) { rs1 += a1[f]; rs2 += a2[f]; const float v = a1[f] + a2[f]; if (v > lmax) { lmax = v; larg = f0 + f; } }
+                }
+                sh->rowsum1[t] = rs1; sh->rowsum2[t] = rs2;
+                if (lmax > best) { best = lmax; bt = t; bfi = larg; }     // t ascending per thread: first max kept
+            }
+            block_argmax(sh, best, bt, bfi);
+            const float Dmax = sh->redf[0]; const int tbest = sh->redi[0], fbest = sh->redj[0];
+            __syncthreads();
+            const float sr = sigma_r_from_rowsums(sh);
+            if (tid == 0) {
+                S->Dthresh = (double)(2.0f * sr) * sqrt(-log(0.00001 / 5.0));
+                if (Dmax > 0.0f) { S->tmax = tbest; S->f_ind_max = fbest; S->fmax = tab->fcoarse[fbest]; S->Dtmax12 = (double)Dmax; }
+                else { S->tmax = 0; S->f_ind_max = 0; S->fmax = 0.0; S->Dtmax12 = 0.0; }
+                S->candidate = S->Dtmax12 > S->Dthresh;
+            }
+            __syncthreads();
+        } else {
+            // ---- in sync: refine, check_pilots, slips, UW, frequency correction, demod
+            {
+                const int tm = S->tmax; const double fm = S->fmax;
+                const int t0 = max(0, tm - 8);
+                int tnew = tm; double fhat = fm;
+                rx_refine(sh, tab, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1);
+                if (tid == 0) { S->tmax = tnew; S->fmax = 0.9 * fm + 0.1 * fhat; }
+            }
+            // check_pilots (dsp.py:273-320): refresh 48 pseudo-random rows
+            if (tid == 0) { uint32_t x = S->lcg; for (int i = 0; i < 48; i++) { x = x * 1664525u + 1013904223u; sh->rows48[i] = (int)((x >> 8) % RD_NMF); } S->lcg = x; }
+            __syncthreads();
+            for (int task = tid; task < 48 * 5; task += NT_RX) {
+                const int row = task / 5, fg = task - row * 5;
+                corr_rows2<8>(sh, sh->rows48[row], fg * 8, &sh->absd[2 * row][fg * 8], &sh->absd[2 * row + 1][fg * 8]);
+            }
+            __syncthreads();
+            // duplicates in rows48 are harmless: every copy writes the same value
+            if (tid < 96) {
+                float s = 0.0f;
+                for (int f = 0; f < RD_NFC; f++) s += sh->absd[tid][f];
+                const int t = sh->rows48[tid >> 1];
+                if (tid & 1) sh->rowsum2[t] = s; else sh->rowsum1[t] = s;
+            }
+            __syncthreads();
+            const float sr = sigma_r_from_rowsums(sh);
+            const int tm = S->tmax; const double w = 2.0 * PI_D * S->fmax / 8000.0;
+            const double D = rx_corr_abs(sh, tm, w, tab->p) + rx_corr_abs(sh, tm + RD_NMF, w, tab->p);
+            const double De = rx_corr_abs(sh, tm + RD_M + RD_NCP, w, tab->pend) + rx_corr_abs(sh, tm + RD_NMF, w, tab->pend);
+            if (tid == 0) {
+                S->Dthresh = (double)(2.0f * sr) * sqrt(-log(0.0001 / 5.0));
+                const double Dthresh_eoo = (double)(2.0f * sr) * sqrt(-log(0.00001 / 5.0));
+                S->Dtmax12 = D; S->Dtmax12_eoo = De;
+                S->candidate = D > S->Dthresh; S->endofover = De > Dthresh_eoo;
+                int nn = RD_NMF, t2 = tm;                                       // radae_rxe.py:209-218
+                if (t2 >= RD_NMF - RD_M) { nn = RD_NMF + RD_M; t2 -= RD_M; }
+                if (t2 < RD_M) { nn = RD_NMF - RD_M; t2 += RD_M; }
+                S->nin = nn; S->tmax = t2;
+                S->synced_count++;                                              // :220-224
+                if (S->synced_count % 8 == 0) { if (S->uw_errors > 7) S->uw_fail = 1; S->uw_errors = 0; S->uw_from_row = S->n_rows; }
+            }
+            __syncthreads();
+            const int tmax = S->tmax, endofover = S->endofover, n_rows = S->n_rows;
+            const double rph_r = S->rph_r, rph_i = S->rph_i;
+            // frequency correction (:227-233): rx_phase advances e^{-jw} per sample in complex128
+            float2 *rx1 = sh->xm;
+            for (int n = tid; n < RD_NEOO; n += NT_RX) {
+                double s, c; sincos(-w * (double)(n + 1), &s, &c);
+                const float pr = (float)(rph_r * c - rph_i * s), pi = (float)(rph_r * s + rph_i * c);
+                rx1[n] = cmul(sh->rxb[tmax - RD_NCP + n], make_float2(pr, pi));
+            }
+            __syncthreads();
+            if (tid == 0) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
+            // receiver_one (dsp.py:487-526): window [16:176] of each 192-sample symbol, 160->30 DFT
+            if (tid < 6 * RD_NC) {
+                const int s = tid / RD_NC, c = tid - s * RD_NC;
+                const float2 *x = rx1 + s * RD_SYM + RD_NCP - 16;
+                float2 acc = make_float2(0.0f, 0.0f);
+                for (int n = 0; n < RD_M; n++) acc = cadd(acc, cmul(x[n], ld2(tab->Wfwd[n], c)));
+                sh->sym[s][c] = acc;
+            }
+            __syncthreads();
+            float *zrow = a.zrows + ((size_t)b * RD_DEC_ROWS + n_rows) * RD_LATENT;   // 3 rows = 240 contiguous floats
+            float *eoo_dst = a.eoo_out ? a.eoo_out + (size_t)b * RD_NEOOBITS : nullptr;
+            const int call_idx0 = S->mf - 1;
+            if (!endofover) {
+                // est_pilots (dsp.py:418-435) for pilot rows 0 and 5
+                if (tid < 2 * RD_NC) {
+                    const int i = tid / RD_NC, c = tid - i * RD_NC;
+                    const int cm = c == 0 ? 1 : (c == RD_NC - 1 ? RD_NC - 2 : c);
+                    const float2 *row = sh->sym[i ? 5 : 0];
+                    float2 g0 = make_float2(0.0f, 0.0f), g1 = g0;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const float pp = tab->P[cm - 1 + k];
+                        const float2 h = make_float2(row[cm - 1 + k].x / pp, row[cm - 1 + k].y / pp);
+                        g0 = cadd(g0, cmul(make_float2(tab->Pmat[c][0][k][0], tab->Pmat[c][0][k][1]), h));
+                        g1 = cadd(g1, cmul(make_float2(tab->Pmat[c][1][k][0], tab->Pmat[c][1][k][1]), h));
+                    }
+                    sh->rp[i][c] = cadd(g0, cmul(g1, make_float2(tab->eq_rot[c][0], tab->eq_rot[c][1])));
+                }
+                __syncthreads();
+                // update_snr_est (dsp.py:438-456) + coarse magnitude (:477-482): per-carrier terms reduced by wave shuffles
+                if (tid < 64) {
+                    float s1 = 0.0f, s2 = 0.0f, pm = 0.0f;
+                    if (tid < RD_NC) {
+                        const float2 r0 = sh->rp[0][tid], r1 = sh->rp[1][tid], pc = sh->sym[0][tid];
+                        const float ph = atan2f(r0.y, r0.x);
+                        float sn, cs; sincosf(-ph, &sn, &cs);
+                        const float2 rc = cmul(pc, make_float2(cs, sn));
+                        const float ap = hypotf(pc.x, pc.y); s1 = ap * ap; s2 = fabsf(rc.y) * fabsf(rc.y);
+                        const float a0 = hypotf(r0.x, r0.y), a1 = hypotf(r1.x, r1.y); pm = a0 * a0 + a1 * a1;
+                    }
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); pm += __shfl_xor(pm, off); }
+                    if (tid == 0) {
+                        const float S1 = s1, S2 = s2 + 1e-12f;
+                        float snr = S1 / (2.0f * S2) - 1.0f;
+                        if (snr <= 0.0f) snr = 0.1f;
+                        float snrdB = 10.0f * log10f(snr);
+                        snrdB = (snrdB - 2.513f) / 0.8070f;
+                        const float snr3k = snrdB + tab->snr_c1 + tab->snr_c2;
+                        S->snr_est = 0.9f * S->snr_est + 0.1f * snr3k;
+                        float mag = powf(pm / 60.0f, 0.5f) + 1e-6f;
+                        S->mag = (mag * fabsf(tab->P[0])) / tab->pilot_gain;
+                        S->valid_output = 1;
+                    }
+                }
+                __syncthreads();
+                const float mag = S->mag;
+                // linear-interpolated phase EQ of the 4 data symbols (:468-474), demap to z_hat
+                if (tid < RD_NS * RD_NC) {
+                    const int k = 1 + tid / RD_NC, c = tid % RD_NC;
+                    const float2 r0 = sh->rp[0][c], r1 = sh->rp[1][c];
+                    const float2 slope = make_float2((r1.x - r0.x) / 5.0f, (r1.y - r0.y) / 5.0f);
+                    const float2 ch = make_float2(slope.x * (float)k + r0.x, slope.y * (float)k + r0.y);
+                    const float ang = atan2f(ch.y, ch.x);
+                    float sn, cs; sincosf(-ang, &sn, &cs);
+                    const float2 v = cmul(sh->sym[k][c], make_float2(cs, sn));
+                    const float zr = v.x / mag, zi = v.y / mag;
+                    zrow[2 * tid] = zr; zrow[2 * tid + 1] = zi;
+                    if (a.trace_z && call_idx0 < a.trace_cap) { float *tz = a.trace_z + ((size_t)b * a.trace_cap + call_idx0) * RD_ZMF; tz[2 * tid] = zr; tz[2 * tid + 1] = zi; }
+                }
+            } else {
+                // EOO branch (:513-524): mean of the three pilots per carrier, symbols 2..4 carry the 180 soft bits
+                if (tid < 3 * RD_NC) {
+                    const int k = 2 + tid / RD_NC, c = tid % RD_NC;
+                    const float pp = tab->P[c], pe = tab->Pend[c];
+                    const float2 s = make_float2(sh->sym[0][c].x / pp + sh->sym[1][c].x / pe + sh->sym[5][c].x / pe,
+                                                 sh->sym[0][c].y / pp + sh->sym[1][c].y / pe + sh->sym[5][c].y / pe);
+                    const float ang = atan2f(s.y, s.x);
+                    float sn, cs; sincosf(-ang, &sn, &cs);
+                    const float2 v = cmul(sh->sym[k][c], make_float2(cs, sn));
+                    if (eoo_dst) { eoo_dst[2 * tid] = v.x; eoo_dst[2 * tid + 1] = v.y; }
+                    if (a.trace_z && call_idx0 < a.trace_cap) { float *tz = a.trace_z + ((size_t)b * a.trace_cap + call_idx0) * RD_ZMF; tz[2 * tid] = v.x; tz[2 * tid + 1] = v.y; }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- state machine (radae_rxe.py:248-297).  Sync entry needs the whole workgroup for refine().
+        const int do_entry = (state == ST_CANDIDATE) && S->candidate && (abs(S->tmax - S->tmax_candidate) < RD_NCP) && (S->valid_count + 1 > 3);
+        if (do_entry) {
+            const int tm = S->tmax; const double fm = S->fmax;
+            const int t0 = max(0, tm - 1);
+            int tnew = tm; double fnew = fm;
+            rx_refine(sh, tab, &tnew, &fnew, t0, tm + 2 - t0, fm - 10.0, fm + 10.0, 0.25);
+            if (tid == 0) { S->tmax = tnew; S->fmax = fnew + S->foff_err; S->foff_err = 0.0; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int next_state = state;
+            if (state == ST_SEARCH) {
+                if (S->candidate) { next_state = ST_CANDIDATE; S->tmax_candidate = S->tmax; S->valid_count = 1; }
+            } else if (state == ST_CANDIDATE) {
+                if (do_entry) {
+                    next_state = ST_SYNC;
+                    S->dec_reset_pending = 1; S->synced_count = 0; S->uw_fail = 0; S->uw_errors = 0; S->uw_from_row = S->n_rows; S->valid_count = 25;
+                } else if (S->candidate && abs(S->tmax - S->tmax_candidate) < RD_NCP) S->valid_count++;
+                else next_state = ST_SEARCH;
+            } else {
+                if (S->candidate) S->valid_count = 25;
+                else { S->valid_count--; if (S->valid_count == 0) next_state = ST_SEARCH; }
+                if (S->endofover || S->uw_fail) next_state = ST_SEARCH;
+            }
+            S->state = next_state;
+            if (next_state == ST_SEARCH) S->nin = RD_NMF;
+            S->mf++;
+            const int ret = S->valid_output | (S->endofover << 1);
+            const int call_idx = S->mf - 2;                   // 0-based index of this call since reset
+            if (S->valid_output) {
+                for (int k = 0; k < 3; k++) { const int rf = (k == 0) ? S->dec_reset_pending : 0; rnd->row_reset[S->n_rows + k] = rf; a.row_reset[b * RD_DEC_ROWS + S->n_rows + k] = rf; }
+                S->dec_reset_pending = 0; S->n_rows += 3; S->pending_valid++; S->valid_inv++;
+            }
+            if (S->endofover) { S->has_eoo = 1; S->eoo_inv++; }
+            const int nc = S->n_calls;
+            rnd->call_ret[nc] = ret; rnd->call_row_lo[nc] = S->uw_from_row; rnd->call_row_hi[nc] = S->n_rows; rnd->call_trace_idx[nc] = call_idx;
+            if (a.trace && call_idx < a.trace_cap) {
+                rd_rx_trace *tr = a.trace + (size_t)b * a.trace_cap + call_idx;
+                tr->state_before = S->state_before; tr->state_after = S->state; tr->nin_before = S->nin_before; tr->nin_after = S->nin; tr->ret = ret;
+                tr->tmax = S->tmax; tr->f_ind_max = S->f_ind_max; tr->valid_count = S->valid_count; tr->uw_errors = S->uw_errors; tr->synced_count = S->synced_count;
+                tr->snr_int = (int)S->snr_est; tr->fmax = S->fmax; tr->Dthresh = S->Dthresh; tr->Dtmax12 = S->Dtmax12; tr->Dtmax12_eoo = S->Dtmax12_eoo; tr->snrdB_3k_est = S->snr_est;
+            }
+            S->n_calls = nc + 1; S->calls_inv++;
+        }
+        __syncthreads();
+    }
+
+    // ---- write the stream state back
+    __syncthreads();
+    for (int i = tid; i < RD_RXBUF; i += NT_RX) { st->rx_buf[i][0] = sh->rxb[i].x; st->rx_buf[i][1] = sh->rxb[i].y; }
+    for (int i = tid; i < RD_NMF; i += NT_RX) { st->rowsum1[i] = sh->rowsum1[i]; st->rowsum2[i] = sh->rowsum2[i]; }
+    for (int i = tid; i < 102; i += NT_RX) { st->bpf_mem[i][0] = sh->bmem[i].x; st->bpf_mem[i][1] = sh->bmem[i].y; }
+    if (tid == 0) {
+        st->state = S->state; st->nin = S->nin; st->tmax = S->tmax; st->tmax_candidate = S->tmax_candidate; st->valid_count = S->valid_count;
+        st->uw_errors = S->uw_errors; st->synced_count = S->synced_count; st->mf = S->mf; st->f_ind_max = S->f_ind_max;
+        st->dec_reset_pending = S->dec_reset_pending; st->bpf_mem_len = S->bpf_mem_len; st->has_eoo = S->has_eoo; st->lcg = S->lcg;
+        st->fmax = S->fmax; st->foff_err = S->foff_err; st->rx_phase[0] = S->rph_r; st->rx_phase[1] = S->rph_i;
+        st->Dthresh = S->Dthresh; st->Dtmax12 = S->Dtmax12; st->Dtmax12_eoo = S->Dtmax12_eoo; st->snr_est = S->snr_est;
+        st->bpf_phase[0] = S->bpf_phase.x; st->bpf_phase[1] = S->bpf_phase.y; st->consumed += S->consumed_round;
+        rnd->n_calls = S->n_calls; rnd->n_rows = S->n_rows; rnd->uw_from_row = S->uw_from_row; rnd->consumed = S->consumed_round;
+        rnd->blocked = S->blocked; rnd->out_base = S->out_base;
+        a.acc[b * 4 + 0] = S->consumed_inv; a.acc[b * 4 + 1] = S->calls_inv; a.acc[b * 4 + 2] = S->valid_inv; a.acc[b * 4 + 3] = S->eoo_inv;
+        a.n_rows[b] = S->n_rows;
+        a.status[b * 4 + 0] = S->nin; a.status[b * 4 + 1] = S->state == ST_SYNC; a.status[b * 4 + 2] = (int)S->snr_est; a.status[b * 4 + 3] = S->state;
+        if (S->n_calls) atomicAdd(&a.progress[0], S->n_calls);
+        if (S->n_rows) atomicMax(&a.progress[1], S->n_rows);
+    }
+}
+
+extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
+{
+    if (a->B <= 0) return 0;
+    static int attr_set = 0;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_rx_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared)); attr_set = 1; }
+    hipLaunchKernelGGL(k_rx_sync, dim3(a->B), dim3(NT_RX), sizeof(RxShared), (hipStream_t)s, *a);
+    return (int)hipGetLastError();
+}
+
+// decoder output rows -> feature frames + UW accounting (rade_api.c:488-513, radae_rxe.py:300-319)
+__global__ __launch_bounds__(256) void k_rx_post(rd_post_args a)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    rd_rx_round *rnd = a.round + b;
+    rd_rx_stream *st = a.st + b;
+    const int n_rows = rnd->n_rows;
+    __shared__ int err[RD_DEC_ROWS];
+    if (n_rows == 0) return;
+    const float *f84 = a.feat84 + (size_t)b * RD_DEC_ROWS * 84;
+    if (tid < n_rows) err[tid] = f84[tid * 84 + 20] > 0.0f ? 1 : 0;      // first aux symbol of each group of 4
+    __syncthreads();
+    // scatter: valid frame v (3 rows) -> 12 feature frames x 36 floats, 20 used + 16 zeros
+    float *out = a.features_out + (size_t)b * a.feat_stride + (size_t)rnd->out_base * RD_FEAT_MF;
+    for (int i = tid; i < (n_rows / 3) * RD_FEAT_MF; i += blockDim.x) {
+        const int fr = i / 36, j = i - fr * 36;          // fr = 10 ms frame index within this round's output
+        const int row = fr >> 2, sub = fr & 3;
+        out[i] = j < 20 ? f84[row * 84 + sub * 21 + j] : 0.0f;
+    }
+    if (tid == 0) {
+        int add = 0;
+        for (int r = rnd->uw_from_row; r < n_rows; r++) add += err[r];
+        st->uw_errors += add;
+        if (a.trace) {
+            for (int c = 0; c < rnd->n_calls; c++) {
+                const int idx = rnd->call_trace_idx[c];
+                if (idx >= a.trace_cap) continue;
+                int e = 0;
+                for (int r = rnd->call_row_lo[c]; r < rnd->call_row_hi[c]; r++) e += err[r];
+                a.trace[(size_t)b * a.trace_cap + idx].uw_errors += e;
+            }
+        }
+    }
+}
+extern "C" int rd_launch_rx_post(const rd_post_args *a, rd_stream_t s)
+{
+    if (a->B <= 0) return 0;
+    hipLaunchKernelGGL(k_rx_post, dim3(a->B), dim3(256), 0, (hipStream_t)s, *a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,231 @@
+"""Python binding of the batched HIP engine (include/rade_batch.h) over ctypes.
+
+PyTorch is used only as plumbing: device tensors own the HBM buffers whose raw pointers are handed
+to the C ABI, and `torch.cuda.current_stream()` supplies the hipStream_t.  All compute happens in
+radae_amd/libradehip.so (radae_amd/csrc); there is no CPU or PyTorch fallback -- if the shared
+library or a GPU is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libradehip.so")
+DEFAULT_BLOB = os.path.join(os.path.dirname(_HERE), "weights", "model19_check3.bin")
+
+NMF, NEOO, NIN_MAX, FEAT_MF, NEOO_BITS, ZMF = 960, 1152, 1120, 432, 180, 240
+
+
+class BatchConfig(C.Structure):
+    _fields_ = [("n_streams", C.c_int), ("max_tx_mf", C.c_int), ("device", C.c_int), ("flags", C.c_int), ("rx_trace_calls", C.c_int)]
+
+
+class ChannelParams(C.Structure):
+    _fields_ = [("n_sig", C.c_int), ("n_pre", C.c_int), ("n_post", C.c_int), ("with_eoo", C.c_int), ("sigma", C.c_float), ("freq_offset", C.c_float),
+                ("df_dt", C.c_float), ("G_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("seed", C.c_ulonglong)]
+
+
+class RxStatus(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("consumed", "n_calls", "n_valid", "has_eoo", "nin", "sync", "snr_dB", "state")]
+
+
+class RxTrace(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count",
+                                        "uw_errors", "synced_count", "snr_int", "pad")] + \
+               [(n, C.c_double) for n in ("fmax", "Dthresh", "Dtmax12", "Dtmax12_eoo")] + [("snrdB_3k_est", C.c_float), ("pad2", C.c_float)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen radae_amd/libradehip.so and declare the C ABI.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      f"or `make -C radae_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rade_batch_open.restype = vp; L.rade_batch_open.argtypes = [C.c_char_p, C.POINTER(BatchConfig)]
+    L.rade_batch_open_mem.restype = vp; L.rade_batch_open_mem.argtypes = [vp, C.c_size_t, C.POINTER(BatchConfig)]
+    L.rade_batch_close.argtypes = [vp]
+    L.rade_batch_n_streams.argtypes = [vp]
+    L.rade_batch_tx.argtypes = [vp, vp, C.c_int, vp, C.c_long, vp, vp]
+    L.rade_batch_tx_set_eoo_bits.argtypes = [vp, vp]
+    L.rade_batch_tx_eoo.argtypes = [vp, vp, C.c_long, vp]
+    L.rade_batch_tx_reset.argtypes = [vp]
+    L.rade_batch_channel.argtypes = [vp, vp, C.c_long, vp, C.c_long, C.POINTER(ChannelParams), vp]
+    L.rade_sigma_from_EbNodB.restype = C.c_float; L.rade_sigma_from_EbNodB.argtypes = [C.c_float]
+    L.rade_batch_rx.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_int), C.c_int, vp, C.c_long, vp, C.POINTER(RxStatus), vp]
+    L.rade_batch_rx_reset.argtypes = [vp]
+    L.rade_batch_rx_set_lcg.argtypes = [vp, C.POINTER(C.c_uint)]
+    L.rade_batch_rx_get_trace.argtypes = [vp, C.c_int, C.POINTER(RxTrace), vp, C.c_int]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    # include/rade_api.h
+    "rade_initialize", "rade_finalize", "rade_open", "rade_close", "rade_version", "rade_n_tx_out", "rade_n_tx_eoo_out", "rade_nin_max",
+    "rade_n_features_in_out", "rade_n_eoo_bits", "rade_tx", "rade_tx_set_eoo_bits", "rade_tx_eoo", "rade_nin", "rade_rx", "rade_sync",
+    "rade_freq_offset", "rade_snrdB_3k_est",
+    # include/rade_batch.h
+    "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_set_eoo_bits",
+    "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
+    "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace",
+]
+
+
+def sigma_from_EbNodB(EbNodB: float) -> float:
+    return float(load_library().rade_sigma_from_EbNodB(EbNodB))
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BatchEngine:
+    """B independent RADE streams on one GPU (one engine per process/GPU)."""
+
+    def __init__(self, n_streams: int, max_tx_mf: int = 1, device: int = 0, flags: int = 0, blob: Optional[str] = None,
+                 blob_bytes: Optional[bytes] = None, rx_trace_calls: int = 0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("radae_amd.BatchEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.lib = load_library()
+        self.B = n_streams
+        self.device = torch.device("cuda", device)
+        self.trace_calls = rx_trace_calls
+        cfg = BatchConfig(n_streams, max_tx_mf, device, flags, rx_trace_calls)
+        if blob_bytes is not None:
+            buf = C.create_string_buffer(blob_bytes, len(blob_bytes))
+            self.h = self.lib.rade_batch_open_mem(C.cast(buf, C.c_void_p), len(blob_bytes), C.byref(cfg))
+        else:
+            self.h = self.lib.rade_batch_open((blob or DEFAULT_BLOB).encode(), C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("rade_batch_open failed (see stderr)")
+        self.max_tx_mf = max_tx_mf
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rade_batch_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- transmit ---------------------------------------------------------------------------
+    def tx(self, features, want_z: bool = False):
+        """features: cuda float32 [B, n_mf*12, 36] -> iq complex64 [B, n_mf*960] (+ z [B, n_mf*3, 80])."""
+        import torch
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        B, nfr, w = features.shape
+        assert B == self.B and w == 36 and nfr % 12 == 0
+        n_mf = nfr // 12
+        iq = torch.empty((B, n_mf * NMF), dtype=torch.complex64, device=features.device)
+        z = torch.empty((B, n_mf * 3, 80), dtype=torch.float32, device=features.device) if want_z else None
+        done = 0
+        while done < n_mf:                       # chunk by the engine's capacity; state carries across chunks
+            k = min(self.max_tx_mf, n_mf - done)
+            f = features[:, done * 12:(done + k) * 12, :].contiguous()
+            zc = torch.empty((B, k * 3, 80), dtype=torch.float32, device=features.device) if want_z else None
+            r = self.lib.rade_batch_tx(self.h, f.data_ptr(), k, iq.data_ptr() + done * NMF * 8, n_mf * NMF, zc.data_ptr() if want_z else None, _stream_ptr())
+            if r != k * NMF:
+                raise RuntimeError("rade_batch_tx failed")
+            if want_z:
+                z[:, done * 3:(done + k) * 3] = zc
+            done += k
+        return (iq, z) if want_z else iq
+
+    def tx_reset(self):
+        self.lib.rade_batch_tx_reset(self.h)
+
+    def set_eoo_bits(self, bits: Optional[np.ndarray]):
+        if bits is None:
+            r = self.lib.rade_batch_tx_set_eoo_bits(self.h, None)
+        else:
+            b = np.ascontiguousarray(bits, dtype=np.float32).reshape(self.B, NEOO_BITS)
+            r = self.lib.rade_batch_tx_set_eoo_bits(self.h, b.ctypes.data_as(C.c_void_p))
+        if r:
+            raise RuntimeError("rade_batch_tx_set_eoo_bits failed")
+
+    def tx_eoo(self):
+        import torch
+        out = torch.empty((self.B, NEOO), dtype=torch.complex64, device=self.device)
+        if self.lib.rade_batch_tx_eoo(self.h, out.data_ptr(), NEOO, _stream_ptr()) != NEOO:
+            raise RuntimeError("rade_batch_tx_eoo failed")
+        return out
+
+    # ---- channel ----------------------------------------------------------------------------
+    def channel(self, tx, sigma: float, freq_offset: float = 0.0, n_pre: int = 0, n_post: int = 0, with_eoo: bool = False,
+                G=None, noise=None, seed: int = 0, df_dt: float = 0.0):
+        """tx complex64 [B, n_sig]; G complex64 [B, n_sig, 2] or None; noise complex64 [B, n_total] or None."""
+        import torch
+        assert tx.is_cuda and tx.dtype == torch.complex64 and tx.is_contiguous() and tx.shape[0] == self.B
+        n_sig = tx.shape[1]
+        n_total = n_pre + n_sig + (NEOO if with_eoo else 0) + n_post
+        rx = torch.empty((self.B, n_total), dtype=torch.complex64, device=tx.device)
+        p = ChannelParams(n_sig, n_pre, n_post, int(with_eoo), sigma, freq_offset, df_dt, None, None, seed)
+        if G is not None:
+            assert G.is_cuda and G.dtype == torch.complex64 and G.is_contiguous() and tuple(G.shape) == (self.B, n_sig, 2)
+            p.G_dev = G.data_ptr()
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.complex64 and noise.is_contiguous() and tuple(noise.shape) == (self.B, n_total)
+            p.noise_dev = noise.data_ptr()
+        r = self.lib.rade_batch_channel(self.h, tx.data_ptr(), n_sig, rx.data_ptr(), n_total, C.byref(p), _stream_ptr())
+        if r != n_total:
+            raise RuntimeError("rade_batch_channel failed")
+        return rx
+
+    # ---- receive ----------------------------------------------------------------------------
+    def rx_reset(self, lcg_seeds: Optional[Sequence[int]] = None):
+        if lcg_seeds is None:
+            self.lib.rade_batch_rx_reset(self.h)
+        else:
+            arr = (C.c_uint * self.B)(*[int(s) for s in lcg_seeds])
+            self.lib.rade_batch_rx_set_lcg(self.h, arr)
+
+    def rx(self, rx, n_avail=None, max_calls: int = 1 << 20, features_out=None):
+        """rx complex64 [B, N] holding each stream's not-yet-consumed samples.  Returns
+        (features [B, cap, 432], status list[RxStatus], eoo [B, 180])."""
+        import torch
+        assert rx.is_cuda and rx.dtype == torch.complex64 and rx.is_contiguous() and rx.shape[0] == self.B
+        N = rx.shape[1]
+        avail = np.full(self.B, N, np.int32) if n_avail is None else np.ascontiguousarray(n_avail, dtype=np.int32)
+        cap = min(max_calls, int(avail.max()) // 800 + 1)
+        if features_out is None:
+            features_out = torch.zeros((self.B, cap, FEAT_MF), dtype=torch.float32, device=rx.device)
+        eoo = torch.zeros((self.B, NEOO_BITS), dtype=torch.float32, device=rx.device)
+        status = (RxStatus * self.B)()
+        r = self.lib.rade_batch_rx(self.h, rx.data_ptr(), N, avail.ctypes.data_as(C.POINTER(C.c_int)), max_calls, features_out.data_ptr(),
+                                   features_out.shape[1] * FEAT_MF, eoo.data_ptr(), status, _stream_ptr())
+        if r:
+            raise RuntimeError("rade_batch_rx failed")
+        return features_out, list(status), eoo
+
+    def rx_trace(self, b: int = 0):
+        """Per-call trace of stream b in the layout of tests/golden/rxtrace_*.npz."""
+        n = self.trace_calls
+        tr = (RxTrace * n)()
+        z = np.zeros((n, ZMF), np.float32)
+        got = self.lib.rade_batch_rx_get_trace(self.h, b, tr, z.ctypes.data_as(C.c_void_p), n)
+        if got < 0:
+            raise RuntimeError("trace not enabled")
+        ints = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
+        flts = ["fmax", "Dthresh", "Dtmax12", "Dtmax12_eoo", "snrdB_3k_est"]
+        d = {k: np.array([getattr(tr[i], k) for i in range(got)], np.int32) for k in ints}
+        d.update({k: np.array([getattr(tr[i], k) for i in range(got)], np.float64) for k in flts})
+        d["z_all"] = z[:got]
+        d["z_hat"] = z[:got][(d["ret"] & 1) == 1]
+        d["eoo_out"] = z[:got][(d["ret"] & 2) == 2][:, :NEOO_BITS]
+        return d
