@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- vocoder-feature frames/s through encode -> OFDM mod -> MPP channel -> sync/demod/EQ -> decode.
+
+Workload (BASELINE.json configs[2]): 256 synthetic utterances per GPU, 1008 feature
+frames (84 modem frames, 10.08 s) each, model19_check3 weights, MPP Doppler-spread two-path channel,
+AWGN at Eb/No = 3 dB, -11 Hz offset, 1 s of noise prepended, EOO frame + 1152 samples appended.
+A "step" = that whole batch once, starting from reset encoder/receiver state, inputs (features, G)
+already resident in HBM.  N > 1: one process per GPU (torchrun), utterances sharded with no data-path
+collective; the only collective is the RCCL broadcast of the weight blob.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+NMF = 960
+F32_PEAK_TFLOPS = 157.3          # MI355X f32 matrix == f32 vector peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0      # detect_pilots: 98.3 MFLOP per call
+SYNC_CALL_FLOP = 866560 * 8.0                    # in-sync DSP per modem frame: 6.93 MFLOP
+ALGO_BYTES_PER_FRAME = 4128
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1008, help="10 ms feature frames per utterance (multiple of 12)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from radae_amd.channel_tools import multipath_g, synth_features
+    from radae_amd.engine import BatchEngine, DEFAULT_BLOB, sigma_from_EbNodB
+    from radae_amd.parallel import broadcast_blob
+
+    B, T = args.streams, args.frames
+    n_mf = T // 12
+    n_sig, n_pre, n_post = n_mf * NMF, 8000, 1152
+
+    # ---- weights: rank 0 reads the blob, every other rank receives it over RCCL/xGMI
+    blob = broadcast_blob(DEFAULT_BLOB if rank == 0 else None, dev, world)
+    eng = BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob)
+
+    # ---- synthetic inputs, resident in HBM before the clock starts
+    u0 = rank * B
+    feats_np = np.stack([synth_features(1000 + u0 + b, T) for b in range(B)])
+    feats = torch.tensor(feats_np, device=dev)
+    G = torch.empty((B, n_sig, 2), dtype=torch.complex64, device=dev)
+    for b in range(B):
+        G[b] = torch.from_numpy(multipath_g("mpp", 8000, n_sig, 5000 + u0 + b)).to(dev)
+    sigma = sigma_from_EbNodB(3.0)
+
+    def step(seed):
+        eng.reset()
+        iq = eng.tx(feats)
+        rx = eng.channel(iq, sigma, -11.0, n_pre=n_pre, n_post=n_post, with_eoo=True, G=G, seed=seed)
+        return eng.rx(rx)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        step(100 + w)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        fo, st, _ = step(1 + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_frames = B * T * args.steps * world
+    value = total_frames / dt
+
+    out = {
+        "metric": "vocoder-feature frames/sec (enc+chan+dec), model19", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "model19_check3 streaming radae_txe -> OFDM + MPP multipath/AWGN 3 dB/-11 Hz -> radae_rxe (configs[2])",
+                   "streams_per_gpu": B, "frames_per_stream": T, "global_streams": B * world, "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
+    }
+    if rank == 0:
+        # sanity of what was timed: decoded frames and the loss.py-style aligned loss of stream 0
+        from radae_amd.loss import find_loss
+        nv = np.array([s.n_valid for s in st])
+        out["decoded_modem_frames_per_stream"] = {"min": int(nv.min()), "mean": float(nv.mean()), "max": int(nv.max())}
+        if nv[0] > 0:
+            l, start = find_loss(feats_np[0], fo[0, :nv[0]].cpu().numpy().reshape(-1, 36))
+            out["loss_stream0"] = {"loss": float(l), "start_frame": int(start)}
+
+    if rank == 0 and not args.no_roofline:
+        # ---- roofline leg: per-kernel-class HIP-event timing of one extra (untimed) step
+        eng.profile(True)
+        fo, st, _ = step(999)
+        torch.cuda.synchronize()
+        eng.profile(False)
+        prof = eng.profile_get()
+        calls = sum(s.n_calls for s in st); sync_calls = sum(s.n_valid + s.has_eoo for s in st)
+        prof["rx_sync"]["flops"] = (calls - sync_calls) * SEARCH_CALL_FLOP + sync_calls * SYNC_CALL_FLOP
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        p = prof[dom]
+        achieved = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
+                           "traffic": None, "avg_launch_ms": p["ms"] / max(p["launches"], 1), "launches_per_step": p["launches"],
+                           "note": "f32: matrix (MFMA) and vector FMA peaks are both 157.3 TFLOP/s on gfx950",
+                           "per_class_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
+                           "hbm_frac_whole_job": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(feats_np, T)
+
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(feats_np, T):
+    """The oracle (plain-C restatement, oracle/) timed on one host core over a bounded sample of the same
+    workload.  kind 'port': the reference's own C core cannot be built here (needs xiph/opus)."""
+    from oracle import oracle_py as O
+    from radae_amd.channel_tools import multipath_g
+    O.build()
+    m = O.Model()
+    n_mf = T // 12
+    sigma = float(O.lib().orc_sigma_from_EbNodB(3.0))
+    rng = np.random.default_rng(11)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        u = done
+        tx = O.Tx(m)
+        sig = np.concatenate([tx.frame(feats_np[u % len(feats_np), 12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+        G = multipath_g("mpp", 8000, len(sig), 5000 + u)
+        n = len(sig)
+        nz = ((rng.standard_normal(n + 1152) + 1j * rng.standard_normal(n + 1152)) / np.sqrt(2)).astype(np.complex64)
+        r, fin = O.channel(sig, G, nz[:n], sigma, -11.0)
+        e = O.channel_eoo(tx.eoo(), nz[n:], sigma, -11.0, 0.0, fin)
+        full = np.concatenate([sigma * rng.standard_normal(8000), r, e, sigma * rng.standard_normal(1152)]).astype(np.complex64)
+        O.run_rx_stream(m, full)
+        done += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or done >= 64:
+            break
+    return {"value": done * T / el, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{done} utterance(s) x {T} frames through oracle enc+mod+MPP channel+rx+dec in {el:.1f} s, 1 thread"}
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,8 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
                   float *features_out_dev, long feat_stride, float *eoo_out_dev, rade_rx_status *status_host,
                   void *stream);
 void rade_batch_rx_reset(rade_batch *h);
+/* stream-ordered reset of encoder and receiver state of every stream (a new batch of utterances starts) */
+void rade_batch_reset(rade_batch *h, void *stream);
 /* seed of the documented LCG that picks the 48 rows check_pilots refreshes (dsp.py:291-295 uses an
  * unseeded np.random.randint); seeds_host[B] or NULL for all-ones */
 void rade_batch_rx_set_lcg(rade_batch *h, const unsigned *seeds_host);
@@ -107,6 +109,12 @@ typedef struct {
 } rade_rx_trace;
 /* copies up to max_calls records + 240-float z_hat rows per call of stream b to host; returns #calls traced */
 int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls);
+
+/* ---- measurement hook (bench.py): per-kernel-class HIP-event timing, off by default ---------- */
+enum { RADE_PROF_GEMM = 0, RADE_PROF_SCAN, RADE_PROF_MOD, RADE_PROF_CHAN, RADE_PROF_SYNC, RADE_PROF_POST, RADE_PROF_NCLASS };
+void rade_batch_profile(rade_batch *h, int enable);
+/* accumulated since enable: device milliseconds, algorithmic FLOPs, launches */
+int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches);
 
 #ifdef __cplusplus
 }

@@ -156,6 +156,8 @@ typedef struct {
 } rd_sync_args;
 int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
 
+int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
+
 typedef struct {
     rd_rx_stream *st; rd_rx_round *round; const float *feat84;   /* [B][RD_DEC_ROWS][84] */
     float *features_out; long feat_stride; rd_rx_trace *trace; int trace_cap;

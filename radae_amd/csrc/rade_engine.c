@@ -41,6 +41,11 @@ struct rade_batch {
     rd_rx_trace *trace; float *trace_z;
     int *h_small;                    /* pinned host scratch */
     unsigned *lcg_seeds;             /* host copy for resets */
+    unsigned *d_lcg_seeds;
+    /* optional per-kernel-class timing with HIP events (bench.py roofline leg; never on in timed runs) */
+    int prof_on; hipEvent_t prof_ev[2];
+    double prof_ms[RADE_PROF_NCLASS], prof_flops[RADE_PROF_NCLASS]; long prof_n[RADE_PROF_NCLASS];
+    long rx_calls_search, rx_calls_sync;
 };
 
 static const int ENC_IN[5] = { 64, 224, 384, 544, 704 };    /* GRU input widths (radae_base.py:240-248) */
@@ -81,39 +86,35 @@ static int upload_lin(dev_lin *d, const float *w, const float *b, int N, int K, 
     return (d->wp && (!b || d->bias)) ? 0 : -1;
 }
 
-static void rx_state_init_host(rd_rx_stream *s, unsigned seed, int flags)
-{   /* radae_rxe.py:128-142 */
-    memset(s, 0, sizeof *s);
-    s->state = 0; s->nin = RD_NMF; s->mf = 1; s->bpf_mem_len = 100; s->lcg = seed;
-    s->rx_phase[0] = 1.0; s->bpf_phase[0] = 1.0f;
-    s->foff_err = (flags & RADE_FOFF_TEST) ? 10.0 : 0.0;      /* rade_api.c:263-264 */
+static void rx_reset_on(rade_batch *h, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    rd_launch_rx_reset(h->rx_st, h->d_lcg_seeds, (h->flags & RADE_FOFF_TEST) ? 10.0 : 0.0 /* rade_api.c:263-264 */, h->B, st);
+    for (int l = 0; l < 5; l++) hipMemsetAsync(h->dec_h[l], 0, sizeof(float) * h->B * 96, st);
+    hipMemsetAsync(h->dec_x, 0, sizeof(float) * (size_t)h->B * (1 + RD_DEC_ROWS) * RD_DEC_W, st);
+    hipMemsetAsync(h->rx_rowreset, 0, sizeof(int) * h->B * RD_DEC_ROWS, st);
+    if (h->trace) { hipMemsetAsync(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap, st); hipMemsetAsync(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF, st); }
+}
+static void tx_reset_on(rade_batch *h, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < 5; l++) hipMemsetAsync(h->enc_h[l], 0, sizeof(float) * h->B * 64, st);
+    hipMemsetAsync(h->enc_x, 0, sizeof(float) * (size_t)h->B * (2 + h->Tcap) * RD_ENC_W, st);
 }
 
-void rade_batch_rx_reset(rade_batch *h)
-{
-    rd_rx_stream *tmp = malloc(sizeof(rd_rx_stream));
-    for (int b = 0; b < h->B; b++) {
-        rx_state_init_host(tmp, h->lcg_seeds[b], h->flags);
-        hipMemcpy(h->rx_st + b, tmp, sizeof *tmp, hipMemcpyHostToDevice);
-    }
-    free(tmp);
-    for (int l = 0; l < 5; l++) hipMemset(h->dec_h[l], 0, sizeof(float) * h->B * 96);
-    hipMemset(h->dec_x, 0, sizeof(float) * (size_t)h->B * (1 + RD_DEC_ROWS) * RD_DEC_W);
-    hipMemset(h->rx_rowreset, 0, sizeof(int) * h->B * RD_DEC_ROWS);
-    if (h->trace) { hipMemset(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap); hipMemset(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF); }
-}
+void rade_batch_rx_reset(rade_batch *h) { rx_reset_on(h, NULL); hipDeviceSynchronize(); }
+
+/* stream-ordered reset of both directions (start of a new batch of utterances) */
+void rade_batch_reset(rade_batch *h, void *stream) { tx_reset_on(h, stream); rx_reset_on(h, stream); }
 
 void rade_batch_rx_set_lcg(rade_batch *h, const unsigned *seeds_host)
 {
     for (int b = 0; b < h->B; b++) h->lcg_seeds[b] = seeds_host ? seeds_host[b] : 1u;
+    hipMemcpy(h->d_lcg_seeds, h->lcg_seeds, sizeof(unsigned) * h->B, hipMemcpyHostToDevice);
     rade_batch_rx_reset(h);
 }
 
-void rade_batch_tx_reset(rade_batch *h)
-{
-    for (int l = 0; l < 5; l++) hipMemset(h->enc_h[l], 0, sizeof(float) * h->B * 64);
-    hipMemset(h->enc_x, 0, sizeof(float) * (size_t)h->B * (2 + h->Tcap) * RD_ENC_W);
-}
+void rade_batch_tx_reset(rade_batch *h) { tx_reset_on(h, NULL); hipDeviceSynchronize(); }
 
 rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_batch_config *cfg)
 {
@@ -187,6 +188,9 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     CHK(hipHostMalloc((void **)&h->h_small, sizeof(int) * (8 + B * 8), 0));
     h->lcg_seeds = malloc(sizeof(unsigned) * B);
     for (size_t b = 0; b < B; b++) h->lcg_seeds[b] = 1u;
+    h->d_lcg_seeds = dev_upload(h->lcg_seeds, sizeof(unsigned) * B);
+    if (!h->d_lcg_seeds) goto fail;
+    CHK(hipEventCreate(&h->prof_ev[0])); CHK(hipEventCreate(&h->prof_ev[1]));
     rade_batch_rx_reset(h);
     if (rd_launch_eoo_build(h->d_tab, NULL, h->eoo, h->B, NULL)) goto fail;
     CHK(hipDeviceSynchronize());
@@ -216,7 +220,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z };
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -225,14 +229,33 @@ void rade_batch_close(rade_batch *h)
         for (int i = 0; i < 6; i++) if (p[i]) hipFree(p[i]);
     }
     if (h->h_small) hipHostFree(h->h_small);
+    if (h->prof_ev[0]) hipEventDestroy(h->prof_ev[0]);
+    if (h->prof_ev[1]) hipEventDestroy(h->prof_ev[1]);
     free(h->lcg_seeds);
     free(h);
 }
 
 int rade_batch_n_streams(const rade_batch *h) { return h->B; }
 
+/* ---- per-kernel-class timing (HIP events on the launch stream) -------------------------------- */
+#define PROF_BEGIN(h, st) do { if ((h)->prof_on) hipEventRecord((h)->prof_ev[0], (hipStream_t)(st)); } while (0)
+#define PROF_END(h, st, cls, fl) do { if ((h)->prof_on) { float ms_ = 0; hipEventRecord((h)->prof_ev[1], (hipStream_t)(st)); hipEventSynchronize((h)->prof_ev[1]); \
+    hipEventElapsedTime(&ms_, (h)->prof_ev[0], (h)->prof_ev[1]); (h)->prof_ms[cls] += ms_; (h)->prof_flops[cls] += (fl); (h)->prof_n[cls]++; } } while (0)
+
+void rade_batch_profile(rade_batch *h, int enable)
+{
+    h->prof_on = enable;
+    if (enable) { memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_flops, 0, sizeof h->prof_flops); memset(h->prof_n, 0, sizeof h->prof_n); }
+}
+int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches)
+{
+    if (cls < 0 || cls >= RADE_PROF_NCLASS) return -1;
+    *ms = h->prof_ms[cls]; *work = h->prof_flops[cls]; *launches = h->prof_n[cls];
+    return 0;
+}
+
 /* ---- one GEMM launch helper ------------------------------------------------------------------ */
-static int gemm(const dev_lin *w, const float *a1, long a1_sb, long a1_st, int K1, const float *a0, long a0_sb, long a0_st, int K0,
+static int gemm(rade_batch *hh, const dev_lin *w, const float *a1, long a1_sb, long a1_st, int K1, const float *a0, long a0_sb, long a0_st, int K0,
                 const int *reset, const int *n_rows, float *y, long y_sb, long y_st, int B, int T, int act, void *stream)
 {
     rd_gemm_args g;
@@ -240,7 +263,10 @@ static int gemm(const dev_lin *w, const float *a1, long a1_sb, long a1_st, int K
     g.a1 = a1; g.a1_sb = a1_sb; g.a1_st = a1_st; g.K1 = K1; g.a0 = a0; g.a0_sb = a0_sb; g.a0_st = a0_st; g.K0 = K0;
     g.reset = reset; g.n_rows = n_rows; g.Wp = w->wp; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
     if (K0 + K1 != w->K) { fprintf(stderr, "rade: internal GEMM shape error (%d+%d != %d)\n", K0, K1, w->K); return -1; }
-    return rd_launch_gemm(&g, stream);
+    PROF_BEGIN(hh, stream);
+    const int rc = rd_launch_gemm(&g, stream);
+    PROF_END(hh, stream, RADE_PROF_GEMM, 2.0 * (double)B * T * (K0 + K1) * w->N);
+    return rc;
 }
 
 /* ---- transmit (radae_txe.py:108-135 for n_mf modem frames and B streams at once) -------------- */
@@ -253,18 +279,18 @@ int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_o
     float *z = z_out_dev ? z_out_dev : h->enc_z;
     int e = 0;
     e |= rd_launch_enc_pack(features_dev, h->enc_xin, B, T, stream);
-    e |= gemm(&h->enc_dense1, h->enc_xin, (long)T * RD_ENC_IN, RD_ENC_IN, RD_ENC_IN, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
+    e |= gemm(h, &h->enc_dense1, h->enc_xin, (long)T * RD_ENC_IN, RD_ENC_IN, RD_ENC_IN, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = ENC_IN[l];
-        e |= gemm(&h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, h->enc_gi, (long)T * 192, 192, B, T, 0, stream);
+        e |= gemm(h, &h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, h->enc_gi, (long)T * 192, 192, B, T, 0, stream);
         rd_scan_args s = { h->enc_gi, (long)T * 192, 192, h->enc_whh[l], h->enc_bhh[l], h->enc_h[l], x + in, xsb, W, NULL, NULL, B, T, 64 };
-        e |= rd_launch_gru_scan(&s, stream);
+        PROF_BEGIN(h, stream); e |= rd_launch_gru_scan(&s, stream); PROF_END(h, stream, RADE_PROF_SCAN, 2.0 * B * T * 192 * 64);
         const int cin = in + 64;
-        e |= gemm(&h->enc_conv[l], x, xsb, W, cin, x - (long)ENC_DIL[l] * W, xsb, W, cin, NULL, NULL, x + cin, xsb, W, B, T, 1, stream);
+        e |= gemm(h, &h->enc_conv[l], x, xsb, W, cin, x - (long)ENC_DIL[l] * W, xsb, W, cin, NULL, NULL, x + cin, xsb, W, B, T, 1, stream);
     }
-    e |= gemm(&h->enc_zdense, x, xsb, W, 864, NULL, 0, 0, 0, NULL, NULL, z, (long)T * RD_LATENT, RD_LATENT, B, T, 0, stream);
+    e |= gemm(h, &h->enc_zdense, x, xsb, W, 864, NULL, 0, 0, 0, NULL, NULL, z, (long)T * RD_LATENT, RD_LATENT, B, T, 0, stream);
     e |= rd_launch_carry_rows(h->enc_x, B, h->Tcap, W, 2, T, NULL, stream);
-    e |= rd_launch_ofdm_mod(h->d_tab, z, iq_out_dev, iq_stride, B, n_mf, stream);
+    PROF_BEGIN(h, stream); e |= rd_launch_ofdm_mod(h->d_tab, z, iq_out_dev, iq_stride, B, n_mf, stream); PROF_END(h, stream, RADE_PROF_MOD, 8.0 * B * n_mf * 5 * 30 * 160);
     return e ? -1 : n_mf * RD_NMF;
 }
 
@@ -294,7 +320,9 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
     a.tab = h->d_tab; a.tx = tx_dev; a.tx_stride = tx_stride; a.rx = rx_out_dev; a.rx_stride = rx_stride; a.G = p->G_dev; a.noise = p->noise_dev;
     a.eoo = h->eoo; a.scratch = h->chan_scratch; a.B = h->B; a.n_sig = p->n_sig; a.n_pre = p->n_pre; a.n_post = p->n_post; a.with_eoo = p->with_eoo;
     a.sigma = p->sigma; a.freq_offset = p->freq_offset; a.df_dt = p->df_dt; a.seed = p->seed;
+    PROF_BEGIN(h, stream);
     if (rd_launch_channel(&a, stream)) return -1;
+    PROF_END(h, stream, RADE_PROF_CHAN, 0.0);
     return p->n_pre + p->n_sig + (p->with_eoo ? RD_NEOO : 0) + p->n_post;
 }
 
@@ -306,17 +334,17 @@ static int decoder_round(rade_batch *h, void *stream)
     float *x = h->dec_x + W;                    /* slot 0 of each stream = conv history (previous valid step) */
     const int *nr = h->rx_nrows, *rst = h->rx_rowreset;
     int e = 0;
-    e |= gemm(&h->dec_dense1, h->zrows, (long)T * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
+    e |= gemm(h, &h->dec_dense1, h->zrows, (long)T * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = DEC_IN[l];
-        e |= gemm(&h->dec_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, nr, h->dec_gi, (long)T * 288, 288, B, T, 0, stream);
+        e |= gemm(h, &h->dec_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, nr, h->dec_gi, (long)T * 288, 288, B, T, 0, stream);
         rd_scan_args s = { h->dec_gi, (long)T * 288, 288, h->dec_whh[l], h->dec_bhh[l], h->dec_h[l], h->dec_hbuf, (long)T * 96, 96, rst, nr, B, T, 96 };
-        e |= rd_launch_gru_scan(&s, stream);
-        e |= gemm(&h->dec_glu[l], h->dec_hbuf, (long)T * 96, 96, 96, NULL, 0, 0, 0, NULL, nr, x + in, xsb, W, B, T, 2, stream);
+        PROF_BEGIN(h, stream); e |= rd_launch_gru_scan(&s, stream); PROF_END(h, stream, RADE_PROF_SCAN, 2.0 * B * T * 288 * 96);
+        e |= gemm(h, &h->dec_glu[l], h->dec_hbuf, (long)T * 96, 96, 96, NULL, 0, 0, 0, NULL, nr, x + in, xsb, W, B, T, 2, stream);
         const int cin = in + 96;
-        e |= gemm(&h->dec_conv[l], x, xsb, W, cin, x - W, xsb, W, cin, rst, nr, x + cin, xsb, W, B, T, 1, stream);
+        e |= gemm(h, &h->dec_conv[l], x, xsb, W, cin, x - W, xsb, W, cin, rst, nr, x + cin, xsb, W, B, T, 1, stream);
     }
-    e |= gemm(&h->dec_output, x, xsb, W, 736, NULL, 0, 0, 0, NULL, nr, h->feat84, (long)T * 84, 84, B, T, 0, stream);
+    e |= gemm(h, &h->dec_output, x, xsb, W, 736, NULL, 0, 0, 0, NULL, nr, h->feat84, (long)T * 84, 84, B, T, 0, stream);
     return e;
 }
 
@@ -340,13 +368,17 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     pa.trace = h->trace; pa.trace_cap = h->trace_cap; pa.B = B;
     for (;;) {
         CHK(hipMemsetAsync(h->rx_progress, 0, sizeof(int) * 4, st));
+        PROF_BEGIN(h, st);
         if (rd_launch_rx_sync(&sa, st)) goto fail;
+        PROF_END(h, st, RADE_PROF_SYNC, 0.0);
         CHK(hipMemcpyAsync(hs, h->rx_progress, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
         CHK(hipStreamSynchronize(st));
         if (hs[0] == 0) break;                  /* no stream could make a call: out of samples or budget */
         if (hs[1] > 0) {
             if (decoder_round(h, st)) goto fail;
+            PROF_BEGIN(h, st);
             if (rd_launch_rx_post(&pa, st)) goto fail;
+            PROF_END(h, st, RADE_PROF_POST, 0.0);
             if (rd_launch_carry_rows(h->dec_x, B, RD_DEC_ROWS, RD_DEC_W, 1, 0, h->rx_nrows, st)) goto fail;
         }
     }

@@ -913,6 +913,25 @@ extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
     return (int)hipGetLastError();
 }
 
+// (re)initialise every stream's receiver state on the device (radae_rxe.py:128-142)
+__global__ __launch_bounds__(256) void k_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err)
+{
+    rd_rx_stream *s = st + blockIdx.x;
+    float *raw = (float *)s;
+    for (int i = threadIdx.x; i < (int)(sizeof(rd_rx_stream) / 4); i += blockDim.x) raw[i] = 0.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s->state = ST_SEARCH; s->nin = RD_NMF; s->mf = 1; s->bpf_mem_len = 100; s->lcg = seeds ? seeds[blockIdx.x] : 1u;
+        s->rx_phase[0] = 1.0; s->bpf_phase[0] = 1.0f; s->foff_err = foff_err;
+    }
+}
+extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err, int B, rd_stream_t s)
+{
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_rx_reset, dim3(B), dim3(256), 0, (hipStream_t)s, st, seeds, foff_err);
+    return (int)hipGetLastError();
+}
+
 // decoder output rows -> feature frames + UW accounting (rade_api.c:488-513, radae_rxe.py:300-319)
 __global__ __launch_bounds__(256) void k_rx_post(rd_post_args a)
 {

@@ -64,6 +64,9 @@ def load_library() -> C.CDLL:
     L.rade_sigma_from_EbNodB.restype = C.c_float; L.rade_sigma_from_EbNodB.argtypes = [C.c_float]
     L.rade_batch_rx.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_int), C.c_int, vp, C.c_long, vp, C.POINTER(RxStatus), vp]
     L.rade_batch_rx_reset.argtypes = [vp]
+    L.rade_batch_reset.argtypes = [vp, vp]
+    L.rade_batch_profile.argtypes = [vp, C.c_int]
+    L.rade_batch_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.rade_batch_rx_set_lcg.argtypes = [vp, C.POINTER(C.c_uint)]
     L.rade_batch_rx_get_trace.argtypes = [vp, C.c_int, C.POINTER(RxTrace), vp, C.c_int]
     _lib = L
@@ -78,7 +81,7 @@ EXPORTED_SYMBOLS = [
     # include/rade_batch.h
     "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_set_eoo_bits",
     "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
-    "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace",
+    "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get",
 ]
 
 
@@ -123,6 +126,23 @@ class BatchEngine:
             self.close()
         except Exception:
             pass
+
+    def reset(self):
+        """Stream-ordered reset of encoder and receiver state (a new batch of utterances)."""
+        self.lib.rade_batch_reset(self.h, _stream_ptr())
+
+    PROF_CLASSES = ("gemm", "gru_scan", "ofdm_mod", "channel", "rx_sync", "rx_post")
+
+    def profile(self, enable: bool):
+        self.lib.rade_batch_profile(self.h, int(enable))
+
+    def profile_get(self):
+        out = {}
+        for i, name in enumerate(self.PROF_CLASSES):
+            ms, wk, n = C.c_double(), C.c_double(), C.c_long()
+            self.lib.rade_batch_profile_get(self.h, i, C.byref(ms), C.byref(wk), C.byref(n))
+            out[name] = {"ms": ms.value, "flops": wk.value, "launches": n.value}
+        return out
 
     # ---- transmit ---------------------------------------------------------------------------
     def tx(self, features, want_z: bool = False):
