@@ -445,7 +445,17 @@ extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
 // receiver: one workgroup (256 threads) per stream, up to RD_RX_ROUND do_radae_rx calls per launch
 // =====================================================================================================
 enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
-#define NT_RX 256
+
+#ifdef RD_PHASE_TIMING   // developer aid: per-phase shader-clock totals of workgroup 0 (make EXTRA=-DRD_PHASE_TIMING)
+__device__ long long g_phase_cycles[16];
+#define PH_T0() long long ph_t_ = clock64()
+#define PH(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); atomicAdd((unsigned long long *)&g_phase_cycles[i], (unsigned long long)(n_ - ph_t_)); ph_t_ = n_; } } while (0)
+extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 16); long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
+#else
+#define PH_T0() do { } while (0)
+#define PH(i) do { } while (0)
+#endif
+#define NT_RX 512
 
 struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
@@ -459,6 +469,8 @@ struct RxScalars {
 struct RxShared {
     RxScalars S;
     float2 bmem[102];                     // BPF memory (dsp.py:55,96)
+    double2 pd[RD_M], pendd[RD_M];        // pilot / end-of-over replicas as doubles (refine, check_pilots)
+    float2 wfwd[RD_M][RD_NC];             // forward DFT matrix (dsp.py:501)
     float2 rxb[RD_RXBUF];                 // rx_buf (radae_rxe.py:141)
     float2 xm[102 + RD_NINMAX + 2];       // BPF [mem | mixed-down new]; reused as rx1[1152] for the demod
     float2 pw[RD_M][RD_NFC];              // acquisition.p_w
@@ -468,7 +480,7 @@ struct RxShared {
     float absd[96][RD_NFC + 1];           // check_pilots scratch |Dt| rows
     float rowsum1[RD_NMF], rowsum2[RD_NMF]; // sum_f |Dt1[t,f]|, |Dt2[t,f]|
     int rows48[48];
-    double redd[NT_RX];                   // block reductions (double)
+    double redd[(NT_RX / 64 + 1) * 10 > NT_RX ? (NT_RX / 64 + 1) * 10 : NT_RX];   // block reductions (double)
     float redf[NT_RX]; int redi[NT_RX]; int redj[NT_RX];
 };
 
@@ -488,45 +500,68 @@ __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
         __syncthreads();
     }
 }
-__device__ double block_sum_d(RxShared *sh, double v)
-{
-    const int tid = threadIdx.x;
-    sh->redd[tid] = v; __syncthreads();
-    for (int w = NT_RX / 2; w > 0; w >>= 1) { if (tid < w) sh->redd[tid] += sh->redd[tid + w]; __syncthreads(); }
-    const double r = sh->redd[0]; __syncthreads();
-    return r;
-}
 
-// correlate conj(rx[t..t+160)) and conj(rx[t+Nmf..)) with p_w[:, f0..f0+NF) -> |Dt1|, |Dt2| (dsp.py:207-209).
-// Both modem frames share the p_w reads, which keeps the loop VALU-bound instead of LDS-bound.
-template <int NF>
-__device__ __forceinline__ void corr_rows2(const RxShared *sh, int t, int f0, float *abs1, float *abs2)
+// Pilot correlation on the matrix cores.  Dt[t,f] = sum_m conj(rx[t+m]) p_w[m,f] (dsp.py:207-208) is the real
+// GEMM  C[n,t] = sum_k Pm[n,k] X[k,t]  with k = 2m+c (re/im of rx), n = 2f+c' (re/im of Dt),
+//   X[k,t]  = rxf[2t + k]            (the interleaved float view of rx_buf: a Hankel matrix, never materialised)
+//   Pm[n,k] = {pr, pi; pi, -pr}[c'][c] of p_w[m,f]
+// One v_mfma_f32_16x16x4_f32 tile = 16 n x 16 t, K = 320 in 80 steps; both modem frames (t, t+Nmf) share the
+// Pm fragment.  Lane l feeds Pm[n = 16nt + (l&15)][k = 4s + (l>>4)] and X[k = 4s + (l>>4)][t = tl], and ends up
+// with C rows n = 16nt + 4(l>>4) + r, i.e. (re,im) of f = 8nt + 2(l>>4) and f+1, for its column t.
+__device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int t_lane, int nt, f32x4 &acc1, f32x4 &acc2)
 {
-    float2 a1[NF], a2[NF];
-#pragma unroll
-    for (int f = 0; f < NF; f++) { a1[f] = make_float2(0.0f, 0.0f); a2[f] = make_float2(0.0f, 0.0f); }
-    for (int m = 0; m < RD_M; m++) {
-        const float2 x = sh->rxb[t + m], y = sh->rxb[t + RD_NMF + m];   // conj applied in the product: (xr, -xi)
-#pragma unroll
-        for (int f = 0; f < NF; f++) {
-            const float2 w = sh->pw[m][f0 + f];
-            a1[f].x += x.x * w.x + x.y * w.y; a1[f].y += x.x * w.y - x.y * w.x;
-            a2[f].x += y.x * w.x + y.y * w.y; a2[f].y += y.x * w.y - y.y * w.x;
-        }
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kl = lane >> 4;
+    const float *pwf = (const float *)&sh->pw[0][0];
+    const float *rxf = (const float *)&sh->rxb[0];
+    const int comp = (i ^ kl) & 1;                         // which component of p_w this lane reads
+    const float sgn = (i & kl & 1) ? -1.0f : 1.0f;         // Pm = -pr when c = c' = 1
+    const float *pa = pwf + ((kl >> 1) * RD_NFC + 8 * nt + (i >> 1)) * 2 + comp;   // + s * (2*RD_NFC*2)
+    const float *pb = rxf + 2 * t_lane + kl;                                          // + 4*s ; frame 2 at + 2*RD_NMF
+    acc1 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc2 = acc1;
+#pragma unroll 8
+    for (int s = 0; s < 80; s++) {
+        const float a = pa[s * (4 * RD_NFC)] * sgn;
+        const float b1 = pb[4 * s], b2 = pb[4 * s + 2 * RD_NMF];
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc2, 0, 0, 0);
     }
-#pragma unroll
-    for (int f = 0; f < NF; f++) { abs1[f] = hypotf(a1[f].x, a1[f].y); abs2[f] = hypotf(a2[f].x, a2[f].y); }
 }
 
-__device__ float sigma_r_from_rowsums(RxShared *sh)
+// sum NV doubles per thread over the workgroup: wave shuffles, then one LDS pass; result in sh->redd[0..NV)
+template <int NV>
+__device__ void block_sum_multi(RxShared *sh, double (&v)[NV])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) sh->redd[wave * NV + k] = v[k];
+    }
+    __syncthreads();
+    if (tid < NV) { double t = 0.0; for (int w = 0; w < NT_RX / 64; w++) t += sh->redd[w * NV + tid]; sh->redd[(NT_RX / 64) * NV + tid] = t; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = sh->redd[(NT_RX / 64) * NV + k];
+    __syncthreads();
+}
+
+__device__ __forceinline__ float sigma_r_from_sums(double t1, double t2)
 {   // dsp.py:218-220: (mean|Dt1| + mean|Dt2|)/sqrt(pi/2)/2 in float32
-    const int tid = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = tid; t < RD_NMF; t += NT_RX) { s1 += (double)sh->rowsum1[t]; s2 += (double)sh->rowsum2[t]; }
-    const double t1 = block_sum_d(sh, s1), t2 = block_sum_d(sh, s2);
     const float k = (float)sqrt(PI_D / 2.0);
     const float m1 = (float)(t1 / (RD_NMF * RD_NFC)) / k, m2 = (float)(t2 / (RD_NMF * RD_NFC)) / k;
     return (m1 + m2) / 2.0f;
+}
+__device__ float sigma_r_from_rowsums(RxShared *sh)
+{
+    double v[2] = { 0.0, 0.0 };
+    for (int t = threadIdx.x; t < RD_NMF; t += NT_RX) { v[0] += (double)sh->rowsum1[t]; v[1] += (double)sh->rowsum2[t]; }
+    block_sum_multi<2>(sh, v);
+    return sigma_r_from_sums(v[0], v[1]);
 }
 
 // refine(): fine timing/frequency search maximising |Dt1+Dt2| (dsp.py:233-270); complex128 dots rounded to complex64
@@ -543,10 +578,10 @@ __device__ void rx_refine(RxShared *sh, const rd_tables *tab, int *tmax, double 
         const int t = t0 + ti;
         double sr, cr; sincos(-w, &sr, &cr);                                // per-sample rotation e^{-jw}
         double zr = 1.0, zi = 0.0, ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+#pragma unroll 4
         for (int n = 0; n < RD_M; n++) {
-            if ((n & 31) == 0) sincos(-w * n, &zi, &zr);                    // re-anchor the recurrence
-            const double pr = (double)tab->p[n][0], pi = -(double)tab->p[n][1];
-            const double qr = zr * pr - zi * pi, qi = zr * pi + zi * pr;  // w_vec1 * conj(p)
+            const double2 pp = sh->pd[n];
+            const double qr = zr * pp.x + zi * pp.y, qi = zi * pp.x - zr * pp.y;   // w_vec1 * conj(p)
             const float2 x = sh->rxb[t + n], y = sh->rxb[t + RD_NMF + n];
             ar += (double)x.x * qr - (double)x.y * qi; ai += (double)x.x * qi + (double)x.y * qr;
             br += (double)y.x * qr - (double)y.y * qi; bi += (double)y.x * qi + (double)y.y * qr;
@@ -563,20 +598,14 @@ __device__ void rx_refine(RxShared *sh, const rd_tables *tab, int *tmax, double 
     __syncthreads();
 }
 
-// |dot(conj(w_vec*rx[t0..]), ref)| in complex128 (dsp.py:307-313)
-__device__ double rx_corr_abs(RxShared *sh, int t0, double w, const float (*ref)[2])
+// one term of dot(conj(w_vec*rx[t0..]), ref) in complex128 (dsp.py:307-313); thread n < 160 owns sample n
+__device__ __forceinline__ void rx_corr_term(const RxShared *sh, int t0, double s, double c, const double2 *ref, double &ar, double &ai)
 {
     const int tid = threadIdx.x;
-    double ar = 0.0, ai = 0.0;
-    if (tid < RD_M) {
-        double s, c; sincos(-w * tid, &s, &c);
-        const float2 x = sh->rxb[t0 + tid];
-        const double qr = c * x.x - s * x.y, qi = -(c * x.y + s * x.x);    // conj(w_vec*rx)
-        const double rr = ref[tid][0], ri = ref[tid][1];
-        ar = qr * rr - qi * ri; ai = qr * ri + qi * rr;
-    }
-    const double sr = block_sum_d(sh, ar), si = block_sum_d(sh, ai);
-    return hypot(sr, si);
+    const float2 x = sh->rxb[t0 + tid];
+    const double qr = c * x.x - s * x.y, qi = -(c * x.y + s * x.x);    // conj(w_vec*rx)
+    const double2 r = ref[tid];
+    ar = qr * r.x - qi * r.y; ai = qr * r.y + qi * r.x;
 }
 
 // Scalar receiver state lives in LDS (sh->S): thread 0 is the only writer, everybody reads it after a
@@ -597,6 +626,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
     for (int i = tid; i < RD_RXBUF; i += NT_RX) sh->rxb[i] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]);
     for (int i = tid; i < RD_M * RD_NFC; i += NT_RX) sh->pw[i / RD_NFC][i % RD_NFC] = make_float2(tab->p_w[i / RD_NFC][i % RD_NFC][0], tab->p_w[i / RD_NFC][i % RD_NFC][1]);
     for (int i = tid; i < RD_NTAP; i += NT_RX) sh->bpf_h[i] = tab->bpf_h[i];
+    for (int i = tid; i < RD_M; i += NT_RX) { sh->pd[i] = make_double2(tab->p[i][0], tab->p[i][1]); sh->pendd[i] = make_double2(tab->pend[i][0], tab->pend[i][1]); }
+    for (int i = tid; i < RD_M * RD_NC; i += NT_RX) sh->wfwd[i / RD_NC][i % RD_NC] = make_float2(tab->Wfwd[i / RD_NC][i % RD_NC][0], tab->Wfwd[i / RD_NC][i % RD_NC][1]);
     for (int i = tid; i < RD_NMF; i += NT_RX) { sh->rowsum1[i] = st->rowsum1[i]; sh->rowsum2[i] = st->rowsum2[i]; }
     for (int i = tid; i < 102; i += NT_RX) sh->bmem[i] = make_float2(st->bpf_mem[i][0], st->bpf_mem[i][1]);
     if (tid == 0) {
@@ -612,6 +643,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
     }
     const int avail = a.avail[b];
     __syncthreads();
+    PH_T0(); PH(0);
 
     for (int it = 0; it < RD_RX_ROUND; it++) {
         // ---- can this stream make another call right now?  (decided once, by thread 0)
@@ -632,9 +664,12 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // ---- complex_bpf.bpf (dsp.py:63-102)
         const float2 *xin = rxin + S->consumed_inv;
         for (int i = tid; i < ml; i += NT_RX) sh->xm[i] = sh->bmem[i];
-        for (int i = tid; i < nin; i += NT_RX) {
-            const float2 pv = cmul(bpf_phase, ld2(tab->bpf_E, i));
-            sh->xm[ml + i] = cmul(xin[i], pv);
+        float2 pvr[(RD_NINMAX + NT_RX - 1) / NT_RX];          // mixing phasors of this thread's samples (used twice)
+#pragma unroll
+        for (int q = 0; q < (RD_NINMAX + NT_RX - 1) / NT_RX; q++) {
+            const int i = tid + q * NT_RX;
+            pvr[q] = make_float2(0.0f, 0.0f);
+            if (i < nin) { pvr[q] = cmul(bpf_phase, ld2(tab->bpf_E, i)); sh->xm[ml + i] = cmul(xin[i], pvr[q]); }
         }
         __syncthreads();
         float2 filt[(RD_NINMAX + NT_RX - 1) / NT_RX];
@@ -643,9 +678,15 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const int i = tid + q * NT_RX;
             float ar = 0.0f, ai = 0.0f;
             if (i < nin) {
-                for (int k = 0; k < RD_NTAP; k++) { const float2 x = sh->xm[i + k]; const float h = sh->bpf_h[k]; ar += x.x * h; ai += x.y * h; }
-                const float2 pv = cmul(bpf_phase, ld2(tab->bpf_E, i));
-                const float2 o = cmul(make_float2(ar, ai), cconj(pv));
+                float pr[4] = { 0, 0, 0, 0 }, pi[4] = { 0, 0, 0, 0 };
+#pragma unroll 5
+                for (int k = 0; k < 100; k += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const float2 x = sh->xm[i + k + u]; const float h = sh->bpf_h[k + u]; pr[u] += x.x * h; pi[u] += x.y * h; }
+                }
+                { const float2 x = sh->xm[i + 100]; const float h = sh->bpf_h[100]; pr[0] += x.x * h; pi[0] += x.y * h; }
+                ar = (pr[0] + pr[1]) + (pr[2] + pr[3]); ai = (pi[0] + pi[1]) + (pi[2] + pi[3]);
+                const float2 o = cmul(make_float2(ar, ai), cconj(pvr[q]));
                 ar = o.x; ai = o.y;
             }
             filt[q] = make_float2(ar, ai);
@@ -668,21 +709,40 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         }
         __syncthreads();
 
+        PH(1);
         if (state == ST_SEARCH || state == ST_CANDIDATE) {
-            // ---- acquisition.detect_pilots (dsp.py:178-231): rows t and t+Nmf by the same thread
+            // ---- acquisition.detect_pilots (dsp.py:178-231): each wave owns 16-row t tiles, all 40 bins, both frames
             float best = -1.0f; int bt = 0x7fffffff, bfi = 0;
-            for (int t = tid; t < RD_NMF; t += NT_RX) {
-                float rs1 = 0.0f, rs2 = 0.0f, lmax = -1.0f; int larg = 0;
+            {
+                const int wave = tid >> 6, lane = tid & 63, q = lane >> 4;
+                for (int tile = wave; tile < RD_NMF / 16; tile += NT_RX / 64) {
+                    const int t = tile * 16 + (lane & 15);
+                    float rs1 = 0.0f, rs2 = 0.0f, lmax = -1.0f; int larg = 0;
 #pragma unroll 1
-                for (int f0 = 0; f0 < RD_NFC; f0 += 8) {
-                    float a1[8], a2[8];
-                    corr_rows2<8>(sh, t, f0, a1, a2);
+                    for (int nt = 0; nt < 5; nt++) {
+                        f32x4 c1, c2;
+                        corr_tile_mfma(sh, t, nt, c1, c2);
+                        const float a10 = hypotf(c1[0], c1[1]), a11 = hypotf(c1[2], c1[3]), a20 = hypotf(c2[0], c2[1]), a21 = hypotf(c2[2], c2[3]);
+                        rs1 += a10 + a11; rs2 += a20 + a21;
+                        const int f = 8 * nt + 2 * q;
+                        const float v0 = a10 + a20, v1 = a11 + a21;
+                        if (v0 > lmax) { lmax = v0; larg = f; }
+                        if (v1 > lmax) { lmax = v1; larg = f + 1; }
+                    }
+                    // combine the four lane groups (same t, different f) in a fixed order
 #pragma unroll
-                    for (int f = 0; f < 8; f++) { rs1 += a1[f]; rs2 += a2[f]; const float v = a1[f] + a2[f]; if (v > lmax) { lmax = v; larg = f0 + f; } }
+                    for (int off = 16; off <= 32; off <<= 1) {
+                        rs1 += __shfl_xor(rs1, off); rs2 += __shfl_xor(rs2, off);
+                        const float ov = __shfl_xor(lmax, off); const int oa = __shfl_xor(larg, off);
+                        if (ov > lmax || (ov == lmax && oa < larg)) { lmax = ov; larg = oa; }
+                    }
+                    if (lane < 16) {
+                        sh->rowsum1[t] = rs1; sh->rowsum2[t] = rs2;
+                        if (lmax > best) { best = lmax; bt = t; bfi = larg; }   // tiles ascend per wave: first max kept
+                    }
                 }
-                sh->rowsum1[t] = rs1; sh->rowsum2[t] = rs2;
-                if (lmax > best) { best = lmax; bt = t; bfi = larg; }     // t ascending per thread: first max kept
             }
+            PH(2);
             block_argmax(sh, best, bt, bfi);
             const float Dmax = sh->redf[0]; const int tbest = sh->redi[0], fbest = sh->redj[0];
             __syncthreads();
@@ -694,6 +754,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 S->candidate = S->Dtmax12 > S->Dthresh;
             }
             __syncthreads();
+            PH(3);
         } else {
             // ---- in sync: refine, check_pilots, slips, UW, frequency correction, demod
             {
@@ -703,12 +764,21 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 rx_refine(sh, tab, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1);
                 if (tid == 0) { S->tmax = tnew; S->fmax = 0.9 * fm + 0.1 * fhat; }
             }
+            PH(4);
             // check_pilots (dsp.py:273-320): refresh 48 pseudo-random rows
             if (tid == 0) { uint32_t x = S->lcg; for (int i = 0; i < 48; i++) { x = x * 1664525u + 1013904223u; sh->rows48[i] = (int)((x >> 8) % RD_NMF); } S->lcg = x; }
             __syncthreads();
-            for (int task = tid; task < 48 * 5; task += NT_RX) {
-                const int row = task / 5, fg = task - row * 5;
-                corr_rows2<8>(sh, sh->rows48[row], fg * 8, &sh->absd[2 * row][fg * 8], &sh->absd[2 * row + 1][fg * 8]);
+            {
+                const int wave = tid >> 6, lane = tid & 63, q = lane >> 4;
+                for (int task = wave; task < 15; task += NT_RX / 64) {
+                    const int tile = task / 5, nt = task - tile * 5;
+                    const int row = tile * 16 + (lane & 15);
+                    f32x4 c1, c2;
+                    corr_tile_mfma(sh, sh->rows48[row], nt, c1, c2);
+                    const int f = 8 * nt + 2 * q;
+                    sh->absd[2 * row][f] = hypotf(c1[0], c1[1]); sh->absd[2 * row][f + 1] = hypotf(c1[2], c1[3]);
+                    sh->absd[2 * row + 1][f] = hypotf(c2[0], c2[1]); sh->absd[2 * row + 1][f + 1] = hypotf(c2[2], c2[3]);
+                }
             }
             __syncthreads();
             // duplicates in rows48 are harmless: every copy writes the same value
@@ -719,10 +789,21 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 if (tid & 1) sh->rowsum2[t] = s; else sh->rowsum1[t] = s;
             }
             __syncthreads();
-            const float sr = sigma_r_from_rowsums(sh);
+            PH(5);
             const int tm = S->tmax; const double w = 2.0 * PI_D * S->fmax / 8000.0;
-            const double D = rx_corr_abs(sh, tm, w, tab->p) + rx_corr_abs(sh, tm + RD_NMF, w, tab->p);
-            const double De = rx_corr_abs(sh, tm + RD_M + RD_NCP, w, tab->pend) + rx_corr_abs(sh, tm + RD_NMF, w, tab->pend);
+            double red[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            for (int t = tid; t < RD_NMF; t += NT_RX) { red[0] += (double)sh->rowsum1[t]; red[1] += (double)sh->rowsum2[t]; }
+            if (tid < RD_M) {
+                double sn, cs; sincos(-w * tid, &sn, &cs);
+                rx_corr_term(sh, tm, sn, cs, sh->pd, red[2], red[3]);
+                rx_corr_term(sh, tm + RD_NMF, sn, cs, sh->pd, red[4], red[5]);
+                rx_corr_term(sh, tm + RD_M + RD_NCP, sn, cs, sh->pendd, red[6], red[7]);
+                rx_corr_term(sh, tm + RD_NMF, sn, cs, sh->pendd, red[8], red[9]);
+            }
+            block_sum_multi<10>(sh, red);
+            const float sr = sigma_r_from_sums(red[0], red[1]);
+            const double D = hypot(red[2], red[3]) + hypot(red[4], red[5]);
+            const double De = hypot(red[6], red[7]) + hypot(red[8], red[9]);
             if (tid == 0) {
                 S->Dthresh = (double)(2.0f * sr) * sqrt(-log(0.0001 / 5.0));
                 const double Dthresh_eoo = (double)(2.0f * sr) * sqrt(-log(0.00001 / 5.0));
@@ -736,6 +817,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 if (S->synced_count % 8 == 0) { if (S->uw_errors > 7) S->uw_fail = 1; S->uw_errors = 0; S->uw_from_row = S->n_rows; }
             }
             __syncthreads();
+            PH(6);
             const int tmax = S->tmax, endofover = S->endofover, n_rows = S->n_rows;
             const double rph_r = S->rph_r, rph_i = S->rph_i;
             // frequency correction (:227-233): rx_phase advances e^{-jw} per sample in complex128
@@ -747,15 +829,17 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             __syncthreads();
             if (tid == 0) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
+            PH(7);
             // receiver_one (dsp.py:487-526): window [16:176] of each 192-sample symbol, 160->30 DFT
             if (tid < 6 * RD_NC) {
                 const int s = tid / RD_NC, c = tid - s * RD_NC;
                 const float2 *x = rx1 + s * RD_SYM + RD_NCP - 16;
                 float2 acc = make_float2(0.0f, 0.0f);
-                for (int n = 0; n < RD_M; n++) acc = cadd(acc, cmul(x[n], ld2(tab->Wfwd[n], c)));
+                for (int n = 0; n < RD_M; n++) acc = cadd(acc, cmul(x[n], sh->wfwd[n][c]));
                 sh->sym[s][c] = acc;
             }
             __syncthreads();
+            PH(8);
             float *zrow = a.zrows + ((size_t)b * RD_DEC_ROWS + n_rows) * RD_LATENT;   // 3 rows = 240 contiguous floats
             float *eoo_dst = a.eoo_out ? a.eoo_out + (size_t)b * RD_NEOOBITS : nullptr;
             const int call_idx0 = S->mf - 1;
@@ -834,6 +918,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             __syncthreads();
         }
 
+        PH(9);
         // ---- state machine (radae_rxe.py:248-297).  Sync entry needs the whole workgroup for refine().
         const int do_entry = (state == ST_CANDIDATE) && S->candidate && (abs(S->tmax - S->tmax_candidate) < RD_NCP) && (S->valid_count + 1 > 3);
         if (do_entry) {
@@ -880,10 +965,12 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             S->n_calls = nc + 1; S->calls_inv++;
         }
         __syncthreads();
+        PH(10);
     }
 
     // ---- write the stream state back
     __syncthreads();
+    PH(11);
     for (int i = tid; i < RD_RXBUF; i += NT_RX) { st->rx_buf[i][0] = sh->rxb[i].x; st->rx_buf[i][1] = sh->rxb[i].y; }
     for (int i = tid; i < RD_NMF; i += NT_RX) { st->rowsum1[i] = sh->rowsum1[i]; st->rowsum2[i] = sh->rowsum2[i]; }
     for (int i = tid; i < 102; i += NT_RX) { st->bpf_mem[i][0] = sh->bmem[i].x; st->bpf_mem[i][1] = sh->bmem[i].y; }

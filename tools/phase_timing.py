@@ -1,0 +1,19 @@
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from radae_amd.engine import BatchEngine, load_library, sigma_from_EbNodB
+from radae_amd.channel_tools import synth_features, multipath_g
+B, T = 256, 1008; n_mf = T // 12
+eng = BatchEngine(B, max_tx_mf=n_mf)
+dev = torch.device('cuda')
+feats = torch.tensor(np.stack([synth_features(1000 + b, T) for b in range(B)]), device=dev)
+iq = eng.tx(feats)
+rx = eng.channel(iq, sigma_from_EbNodB(3.0), -11.0, n_pre=8000, n_post=1152, with_eoo=True, seed=5)
+lib = load_library(); lib.rd_debug_phase_cycles.argtypes = [C.c_void_p]
+buf = (C.c_longlong * 16)(); lib.rd_debug_phase_cycles(buf)
+fo, st, _ = eng.rx(rx); torch.cuda.synchronize()
+lib.rd_debug_phase_cycles(buf)
+names = ["load", "bpf+shift", "detect corr", "detect reduce", "refine", "check rows", "sigma+corr+slip", "freqcorr", "demod dft", "eq", "statemachine", "store"]
+tot = sum(buf[:12])
+print("stream0 calls", st[0].n_calls, "valid", st[0].n_valid)
+for i, n in enumerate(names): print(f"{n:18s} {buf[i]:12d} cyc  {100*buf[i]/tot:5.1f}%  {buf[i]/100e6*1e3:8.3f} ms (100MHz clk?)")
