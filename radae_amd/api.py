@@ -1,0 +1,119 @@
+"""Host-side mirror of the reference's streaming classes over the C ABI (include/rade_api.h).
+
+`radae_tx` / `radae_rx` keep the method names, argument meaning and return conventions of
+/root/reference/radae_txe.py:47-144 and /root/reference/radae_rxe.py:56-330 (the classes
+rade_api.c drives through CPython), but every call goes through libradehip.so's `rade_*` C entry
+points -- i.e. the same boundary freedv-gui / radae_tx.c / radae_rx.c bind to -- and runs on the GPU.
+One `rade_open()` handle carries one Tx and one Rx, as in the reference ("single context only").
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import engine
+
+RADE_USE_C_ENCODER, RADE_USE_C_DECODER, RADE_FOFF_TEST, RADE_VERBOSE_0 = 0x1, 0x2, 0x4, 0x8
+
+
+def _bind():
+    L = engine.load_library()
+    if getattr(L, "_rade_api_bound", False):
+        return L
+    vp = C.c_void_p
+    L.rade_open.restype = vp; L.rade_open.argtypes = [C.c_char_p, C.c_int]
+    L.rade_close.argtypes = [vp]
+    for n in ("rade_n_tx_out", "rade_n_tx_eoo_out", "rade_nin_max", "rade_n_features_in_out", "rade_n_eoo_bits", "rade_nin", "rade_sync", "rade_snrdB_3k_est"):
+        getattr(L, n).argtypes = [vp]
+    L.rade_freq_offset.restype = C.c_float; L.rade_freq_offset.argtypes = [vp]
+    L.rade_tx.argtypes = [vp, vp, vp]
+    L.rade_tx_set_eoo_bits.argtypes = [vp, vp]
+    L.rade_tx_eoo.argtypes = [vp, vp]
+    L.rade_rx.argtypes = [vp, vp, C.POINTER(C.c_int), vp, vp]
+    L._rade_api_bound = True
+    return L
+
+
+class Rade:
+    """Thin RAII wrapper of `struct rade *`."""
+
+    def __init__(self, model_file: str = "", flags: int = RADE_VERBOSE_0):
+        self.L = _bind()
+        self.L.rade_initialize()
+        self.r = self.L.rade_open(model_file.encode(), flags)
+        if not self.r:
+            raise RuntimeError("rade_open failed: no GPU or no weight blob (libradehip.so has no CPU fallback)")
+
+    def close(self):
+        if getattr(self, "r", None):
+            self.L.rade_close(self.r); self.r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class radae_tx:
+    """radae_txe.radae_tx: 12 feature frames x 36 floats in -> 960 IQ samples out per call."""
+
+    def __init__(self, model_name: str = "", handle: Rade | None = None, flags: int = RADE_VERBOSE_0):
+        self.h = handle or Rade(model_name, flags)
+        L, r = self.h.L, self.h.r
+        self.n_floats_in = L.rade_n_features_in_out(r)
+        self.Nmf = L.rade_n_tx_out(r)
+        self.Neoo = L.rade_n_tx_eoo_out(r)
+
+    def get_n_features_in(self): return self.n_floats_in
+    def get_n_floats_in(self): return self.n_floats_in
+    def get_Nmf(self): return self.Nmf
+    def get_Neoo(self): return self.Neoo
+    def get_Neoo_bits(self): return self.h.L.rade_n_eoo_bits(self.h.r)
+
+    def set_eoo_bits(self, eoo_bits):
+        b = np.ascontiguousarray(eoo_bits, dtype=np.float32)
+        assert b.size == self.get_Neoo_bits()
+        self.h.L.rade_tx_set_eoo_bits(self.h.r, b.ctypes.data_as(C.c_void_p))
+
+    def do_radae_tx(self, buffer_f32, tx_out):
+        f = np.ascontiguousarray(buffer_f32, dtype=np.float32)
+        assert f.size == self.n_floats_in and tx_out.dtype == np.complex64 and tx_out.size == self.Nmf
+        n = self.h.L.rade_tx(self.h.r, tx_out.ctypes.data_as(C.c_void_p), f.ctypes.data_as(C.c_void_p))
+        assert n == self.Nmf
+
+    def do_eoo(self, tx_out):
+        assert tx_out.dtype == np.complex64 and tx_out.size == self.Neoo
+        n = self.h.L.rade_tx_eoo(self.h.r, tx_out.ctypes.data_as(C.c_void_p))
+        assert n == self.Neoo
+
+
+class radae_rx:
+    """radae_rxe.radae_rx: `get_nin()` samples in per call; returns valid | endofover<<1."""
+
+    def __init__(self, model_name: str = "", handle: Rade | None = None, flags: int = RADE_VERBOSE_0, foff_err: float = 0.0):
+        if foff_err:
+            flags |= RADE_FOFF_TEST      # the C ABI only offers the 10 Hz developer test (rade_api.c:263-264)
+        self.h = handle or Rade(model_name, flags)
+        L, r = self.h.L, self.h.r
+        self.n_floats_out = L.rade_n_features_in_out(r)
+        self._eoo = np.zeros(L.rade_n_eoo_bits(r), np.float32)
+
+    def get_n_features_out(self): return self.n_floats_out
+    def get_n_floats_out(self): return self.n_floats_out
+    def get_nin_max(self): return self.h.L.rade_nin_max(self.h.r)
+    def get_nin(self): return self.h.L.rade_nin(self.h.r)
+    def get_sync(self): return bool(self.h.L.rade_sync(self.h.r))
+    def get_snrdB_3k_est(self): return self.h.L.rade_snrdB_3k_est(self.h.r)
+    def get_Neoo_bits(self): return self.h.L.rade_n_eoo_bits(self.h.r)
+
+    def do_radae_rx(self, buffer_complex, floats_out):
+        x = np.ascontiguousarray(buffer_complex, dtype=np.complex64)
+        assert x.size >= self.get_nin() and floats_out.dtype == np.float32 and floats_out.size == self.n_floats_out
+        has_eoo = C.c_int(0)
+        n = self.h.L.rade_rx(self.h.r, floats_out.ctypes.data_as(C.c_void_p), C.byref(has_eoo), self._eoo.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+        if has_eoo.value:
+            floats_out[:] = 0
+            floats_out[:self._eoo.size] = self._eoo        # radae_rxe.py:321-323
+        return (1 if n else 0) | (2 if has_eoo.value else 0)

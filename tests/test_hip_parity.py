@@ -1,0 +1,272 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C ABI (rade_batch.h / rade_api.h),
+against (1) golden vectors captured from the imported reference and (2) the CPU oracle on fresh inputs.
+
+Bars (BASELINE.json north_star): discrete sync outputs bit-exact; float32 features within 1e-4 RMS."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
+RX_CASES = ["awgn", "mpp", "slip_plus", "slip_minus", "foff"]
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean(np.abs(np.asarray(a, np.complex128) - np.asarray(b, np.complex128)) ** 2)))
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from radae_amd.engine import BatchEngine
+    return BatchEngine
+
+
+def test_encoder_tx_golden(Engine, torch_dev, golden):
+    import torch
+    e = golden("enc_tx")
+    f = torch.tensor(e["features"], device=torch_dev)
+    eng = Engine(2, max_tx_mf=10)
+    iq, z = eng.tx(f, want_z=True)
+    zr, txr = e["z"], e["tx"]
+    assert rms(z.cpu().numpy(), zr) < 1e-4
+    assert np.abs(z.cpu().numpy() - zr).max() < 2e-6 * np.abs(zr).max() + 1e-5
+    assert np.abs(iq.cpu().numpy().reshape(2, 10, 960) - txr).max() < 2e-5
+    # streaming == whole utterance, bit for bit (stateful == stateless, ctest stateful_encoder)
+    eng.tx_reset()
+    parts = [eng.tx(f[:, 12 * k:12 * k + 12].contiguous(), want_z=True) for k in range(10)]
+    assert torch.equal(torch.cat([p[0] for p in parts], 1), iq)
+    assert torch.equal(torch.cat([p[1] for p in parts], 1), z)
+    eng.tx_reset()
+    parts = [eng.tx(f[:, 12 * a:12 * b].contiguous()) for a, b in ((0, 3), (3, 4), (4, 10))]
+    assert torch.equal(torch.cat(parts, 1), iq)
+    eng.close()
+
+
+def test_eoo_frames(Engine, golden):
+    c = golden("consts")
+    eng = Engine(3, max_tx_mf=1)
+    assert np.abs(eng.tx_eoo().cpu().numpy()[2] - c["eoo_default"]).max() < 1e-6
+    bits = np.stack([c["eoo_bits_in"], -c["eoo_bits_in"], c["eoo_bits_in"]])
+    eng.set_eoo_bits(bits)
+    out = eng.tx_eoo().cpu().numpy()
+    assert np.abs(out[0] - c["eoo_with_bits"]).max() < 1e-6 and np.abs(out[2] - c["eoo_with_bits"]).max() < 1e-6
+    assert np.abs(out[1] - c["eoo_with_bits"]).max() > 0.1
+    eng.set_eoo_bits(None)
+    assert np.abs(eng.tx_eoo().cpu().numpy()[0] - c["eoo_default"]).max() < 1e-6
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["mpp", "awgn"])
+def test_channel_golden(Engine, torch_dev, golden, name):
+    import torch
+    g = golden("chan_" + name)
+    eng = Engine(1, max_tx_mf=1)
+    sigma = float(g["sigma"])
+    from radae_amd.engine import sigma_from_EbNodB
+    assert sigma_from_EbNodB(float(g["EbNodB"])) == pytest.approx(sigma, rel=1e-6)
+    noise = np.concatenate([g["noise_pre"].astype(np.complex64), g["noise"], g["noise_eoo"], g["noise_post"].astype(np.complex64)])
+    rx = eng.channel(torch.tensor(g["tx"][None], device=torch_dev), sigma, float(g["freq_offset"]), len(g["noise_pre"]), len(g["noise_post"]), True,
+                     G=torch.tensor(g["G"][None], device=torch_dev), noise=torch.tensor(noise[None], device=torch_dev))
+    assert np.abs(rx.cpu().numpy()[0] - g["rx_full"]).max() < 1e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("name", RX_CASES)
+def test_rx_trace_golden(Engine, torch_dev, golden, name):
+    import torch
+    g = golden("rxtrace_" + name)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=4 if name == "foff" else 0)
+    feats, st, eoo = eng.rx(torch.tensor(g["rx_in"][None], device=torch_dev))
+    d = eng.rx_trace(0)
+    for k in INT_KEYS:
+        assert np.array_equal(d[k], g[k]), k                       # discrete outputs: bit-exact
+    assert np.abs(d["fmax"] - g["fmax"]).max() < 1e-9
+    for k in ["Dthresh", "Dtmax12", "Dtmax12_eoo", "snrdB_3k_est"]:
+        assert np.abs(d[k] - g[k]).max() < 3e-5, k
+    assert rms(d["z_hat"], g["z_hat"]) < 1e-4
+    nv = st[0].n_valid
+    assert nv == len(g["features_out"])
+    fo = feats.cpu().numpy()[0, :nv]
+    assert rms(fo, g["features_out"]) < 1e-5 and np.abs(fo - g["features_out"]).max() < 1e-4     # north star: 1e-4 RMS
+    if g["eoo_out"].size:
+        assert st[0].has_eoo
+        assert np.abs(eoo.cpu().numpy()[0] - g["eoo_out"][-1]).max() < 1e-4
+        assert np.array_equal(eoo.cpu().numpy()[0] > 0, g["eoo_out"][-1] > 0)                   # EOO bit decisions
+    eng.close()
+
+
+def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden):
+    """One do_radae_rx call per invocation (the rade_rx() usage) == the whole stream at once."""
+    import torch
+    g = golden("rxtrace_slip_plus")
+    x = torch.tensor(g["rx_in"][None], device=torch_dev)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
+    fa, sa, _ = eng.rx(x)
+    ta = eng.rx_trace(0)
+    eng.rx_reset()
+    pos, outs = 0, []
+    nin = 960
+    while pos + nin <= x.shape[1]:
+        f, s, _ = eng.rx(x[:, pos:pos + nin].contiguous(), max_calls=1)
+        assert s[0].n_calls == 1 and s[0].consumed == nin
+        if s[0].n_valid:
+            outs.append(f[0, 0].cpu().numpy())
+        pos += nin; nin = s[0].nin
+    tb = eng.rx_trace(0)
+    for k in INT_KEYS:
+        assert np.array_equal(ta[k], tb[k]), k
+    assert np.array_equal(np.array(outs), fa.cpu().numpy()[0, :sa[0].n_valid])
+    eng.close()
+
+
+def _make_stream(seed, n_mf, EbNodB, fo, chan):
+    from radae_amd.channel_tools import multipath_g, synth_features
+    rng = np.random.default_rng(seed)
+    feats = synth_features(seed, n_mf * 12)
+    n_sig = n_mf * 960
+    G = multipath_g(chan, 8000, n_sig, seed + 1) if chan != "awgn" else None
+    n_pre = int(rng.integers(2000, 6000))
+    n_tot = n_pre + n_sig + 1152 + 1152
+    noise = ((rng.standard_normal(n_tot) + 1j * rng.standard_normal(n_tot)) / np.sqrt(2)).astype(np.complex64)
+    return feats, G, n_pre, noise
+
+
+def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_model):
+    """4 streams with different channels/offsets, inputs never seen by the golden generator."""
+    import torch
+    from radae_amd.engine import sigma_from_EbNodB
+    n_mf = 16
+    cases = [(21, 10.0, 11.0, "awgn"), (22, 6.0, -11.0, "mpp"), (23, 8.0, -28.0, "mpd"), (24, 10.0, 31.0, "mpg")]
+    for seed, eb, fo, chan in cases:           # one engine per case: channel parameters are per call, not per stream
+        feats, G, n_pre, noise = _make_stream(seed, n_mf, eb, fo, chan)
+        sigma = sigma_from_EbNodB(eb)
+        eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=48)
+        iq = eng.tx(torch.tensor(feats[None], device=torch_dev))
+        Gd = torch.tensor(G[None], device=torch_dev) if G is not None else None
+        rx = eng.channel(iq, sigma, fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=Gd, noise=torch.tensor(noise[None], device=torch_dev))
+        fo_dev, st, _ = eng.rx(rx)
+        t = eng.rx_trace(0)
+        # oracle
+        tx = oracle.Tx(oracle_model)
+        sig = np.concatenate([tx.frame(feats[12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+        assert np.abs(iq.cpu().numpy()[0] - sig).max() < 5e-5
+        r, fin = oracle.channel(sig, G, noise[n_pre:n_pre + len(sig)], sigma, fo)
+        e = oracle.channel_eoo(tx.eoo(), noise[n_pre + len(sig):n_pre + len(sig) + 1152], sigma, fo, 0.0, fin)
+        full = np.concatenate([sigma * noise[:n_pre], r, e, sigma * noise[-1152:]]).astype(np.complex64)
+        assert np.abs(rx.cpu().numpy()[0] - full).max() < 5e-5
+        d = oracle.run_rx_stream(oracle_model, full)
+        for k in INT_KEYS:
+            assert np.array_equal(t[k], d[k]), (chan, k)
+        nv = st[0].n_valid
+        assert nv == len(d["features_out"])
+        if nv:
+            assert rms(fo_dev.cpu().numpy()[0, :nv], d["features_out"]) < 1e-4
+        eng.close()
+
+
+def test_streams_are_independent_and_ragged(Engine, torch_dev, golden):
+    """Identical streams give bit-identical outputs whatever their slot; ragged / empty inputs are handled."""
+    import torch
+    g = golden("rxtrace_awgn")
+    x = g["rx_in"]
+    B = 5
+    buf = np.zeros((B, len(x)), np.complex64)
+    avail = np.array([len(x), len(x), 5000, 0, 959], np.int32)
+    for b in range(B):
+        buf[b, :avail[b]] = x[:avail[b]]
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64)
+    feats, st, _ = eng.rx(torch.tensor(buf, device=torch_dev), n_avail=avail)
+    assert st[0].n_calls == len(g["ret"]) and st[1].n_calls == st[0].n_calls
+    assert torch.equal(feats[0], feats[1])
+    assert st[2].n_calls == 5 and st[2].consumed == 4800        # whole calls only
+    assert st[3].n_calls == 0 and st[3].consumed == 0 and st[3].nin == 960
+    assert st[4].n_calls == 0
+    t0, t2 = eng.rx_trace(0), eng.rx_trace(2)
+    for k in INT_KEYS:
+        assert np.array_equal(t0[k][:5], t2[k]), k
+    eng.close()
+
+
+def test_single_stream_c_abi(golden):
+    """rade_api.h entry points (what radae_tx.c / radae_rx.c / freedv-gui call), via radae_amd.api."""
+    from radae_amd import api
+    e = golden("enc_tx"); c = golden("consts"); g = golden("rxtrace_awgn")
+    h = api.Rade()
+    L = h.L
+    assert L.rade_version() == 1
+    assert (L.rade_n_tx_out(h.r), L.rade_n_tx_eoo_out(h.r), L.rade_nin_max(h.r), L.rade_n_features_in_out(h.r), L.rade_n_eoo_bits(h.r)) == (960, 1152, 1120, 432, 180)
+    assert L.rade_freq_offset(h.r) == 0.0 and L.rade_sync(h.r) == 0
+    tx = api.radae_tx(handle=h)
+    out = np.zeros(960, np.complex64)
+    for k in range(10):
+        tx.do_radae_tx(e["features"][0, 12 * k:12 * k + 12].ravel(), out)
+        assert np.abs(out - e["tx"][0, k]).max() < 2e-5
+    eo = np.zeros(1152, np.complex64)
+    tx.do_eoo(eo); assert np.abs(eo - c["eoo_default"]).max() < 1e-6
+    tx.set_eoo_bits(c["eoo_bits_in"]); tx.do_eoo(eo); assert np.abs(eo - c["eoo_with_bits"]).max() < 1e-6
+    rx = api.radae_rx(handle=h)
+    x = g["rx_in"]; pos = 0; rets, nins, feats, snrs = [], [], [], []
+    fo = np.zeros(432, np.float32)
+    while pos + rx.get_nin() <= len(x):
+        nin = rx.get_nin()
+        buf = np.zeros(rx.get_nin_max(), np.complex64); buf[:nin] = x[pos:pos + nin]; pos += nin
+        r = rx.do_radae_rx(buf, fo)
+        rets.append(r); nins.append(rx.get_nin()); snrs.append(rx.get_snrdB_3k_est())
+        if r & 1:
+            feats.append(fo.copy())
+        if r & 2:
+            assert np.abs(fo[:180] - g["eoo_out"][-1]).max() < 1e-4
+    assert np.array_equal(rets, g["ret"]) and np.array_equal(nins, g["nin_after"]) and np.array_equal(snrs, g["snr_int"])
+    assert rms(np.array(feats), g["features_out"]) < 1e-5
+    h.close()
+
+
+def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model):
+    """BASELINE workload size (256 x 1008 frames): properties that do not need the oracle at full size,
+    plus the oracle on two of the streams (loss delta < 1e-4)."""
+    import torch
+    from radae_amd.channel_tools import synth_features
+    from radae_amd.engine import sigma_from_EbNodB
+    from radae_amd.loss import find_loss
+    B, T = 256, 1008
+    n_mf = T // 12
+    base = [synth_features(3000 + u, T) for u in range(8)]
+    feats = np.stack([base[b % 8] for b in range(B)])                 # 8 distinct utterances, replicated 32x
+    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=0)
+    iq = eng.tx(torch.tensor(feats, device=torch_dev))
+    assert torch.equal(iq[:8], iq[248:256])                           # replicas bit-identical
+    mag = iq.abs()
+    assert float(mag.max()) <= 1.0 + 1e-6                             # tanh PA limiter
+    papr = 20 * np.log10(float(mag.max()) / float(torch.sqrt((mag ** 2).mean())))
+    assert papr < 1.0                                                 # README.md:434 "PAPR < 1 dB"
+    rng = np.random.default_rng(9)
+    n_tot = 4000 + n_mf * 960 + 1152 + 1152
+    nz = ((rng.standard_normal((8, n_tot)) + 1j * rng.standard_normal((8, n_tot))) / np.sqrt(2)).astype(np.complex64)
+    noise = torch.tensor(np.concatenate([nz] * 32), device=torch_dev)
+    sigma = sigma_from_EbNodB(10.0)
+    rx = eng.channel(iq, sigma, 11.0, n_pre=4000, n_post=1152, with_eoo=True, noise=noise)
+    fo, st, eoo = eng.rx(rx)
+    nv = np.array([s.n_valid for s in st])
+    assert nv.min() >= n_mf - 4 and all(s.has_eoo for s in st)        # every stream syncs and sees the end of over
+    assert torch.equal(fo[:8], fo[248:256])
+    for b in (0, 5):
+        tx = oracle.Tx(oracle_model)
+        sig = np.concatenate([tx.frame(feats[b, 12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+        r, fin = oracle.channel(sig, None, nz[b, 4000:4000 + len(sig)], sigma, 11.0)
+        e = oracle.channel_eoo(tx.eoo(), nz[b, 4000 + len(sig):4000 + len(sig) + 1152], sigma, 11.0, 0.0, fin)
+        full = np.concatenate([sigma * nz[b, :4000], r, e, sigma * nz[b, -1152:]]).astype(np.complex64)
+        d = oracle.run_rx_stream(oracle_model, full)
+        assert len(d["features_out"]) == nv[b]
+        got = fo[b, :nv[b]].cpu().numpy()
+        assert rms(got, d["features_out"]) < 1e-4
+        l_o, s_o = find_loss(feats[b], d["features_out"].reshape(-1, 36))
+        l_g, s_g = find_loss(feats[b], got.reshape(-1, 36))
+        assert s_o == s_g and abs(l_o - l_g) < 1e-4                   # loss.py delta vs the oracle < 1e-4
+    eng.close()

@@ -1,0 +1,147 @@
+"""CPU-only tests of the product's host side: the C ABI library loads and exports every symbol the
+headers declare, the plain-C model preparation (tables, DNNw reader, weight packing) matches the golden
+vectors, the library refuses to run without a GPU, and the host tools (loss, channel generators)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from radae_amd import engine
+    return engine.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = set()
+    for hdr in ("rade_api.h", "rade_batch.h"):
+        src = open(os.path.join(REPO, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        declared |= set(re.findall(r"\b(rade_[a-zA-Z0-9_]+)\s*\(", src))
+    declared -= {"rade_batch", "rade_batch_config", "rade_channel_params", "rade_rx_status", "rade_rx_trace"}
+    assert len(declared) >= 35
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    from radae_amd import engine
+    assert set(engine.EXPORTED_SYMBOLS) <= declared
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from radae_amd import engine
+    cfg = engine.BatchConfig(1, 1, 0, 0, 0)
+    h = lib.rade_batch_open(engine.DEFAULT_BLOB.encode(), C.byref(cfg))
+    assert not h                                     # fails loudly (message on stderr), never computes on the CPU
+    with pytest.raises(RuntimeError):
+        engine.BatchEngine(1)
+
+
+class Tables(C.Structure):
+    _fields_ = [("Winv", C.c_float * (30 * 160 * 2)), ("Wfwd", C.c_float * (160 * 30 * 2)), ("P", C.c_float * 30), ("Pend", C.c_float * 30),
+                ("p", C.c_float * 320), ("pend", C.c_float * 320), ("eoo", C.c_float * 2304), ("Pmat", C.c_float * 360), ("eq_rot", C.c_float * 60),
+                ("bpf_h", C.c_float * 104), ("bpf_E", C.c_float * 2240), ("p_w", C.c_float * 12800), ("fcoarse", C.c_double * 40),
+                ("pilot_gain", C.c_float), ("snr_c1", C.c_float), ("snr_c2", C.c_float), ("pad", C.c_float)]
+
+
+def _c(a):
+    return np.ctypeslib.as_array(a).view(np.complex64)
+
+
+def test_host_tables_match_reference_constants(lib, golden):
+    c = golden("consts")
+    T = Tables()
+    lib.rd_tables_fill.argtypes = [C.POINTER(Tables)]
+    lib.rd_tables_fill(C.byref(T))
+    assert np.abs(_c(T.Winv) - c["Winv"].ravel()).max() < 2e-9
+    assert np.abs(_c(T.Wfwd) - c["Wfwd"].ravel()).max() < 2e-7
+    assert np.array_equal(np.ctypeslib.as_array(T.P), c["P"].real) and np.array_equal(np.ctypeslib.as_array(T.Pend), c["Pend"].real)
+    assert np.abs(_c(T.p) - c["p"]).max() < 5e-8 and np.abs(_c(T.pend) - c["pend"]).max() < 5e-8
+    assert np.abs(_c(T.eoo) - c["eoo_default"]).max() < 1e-6
+    assert np.abs(_c(T.Pmat) - c["Pmat"].ravel()).max() < 2e-6
+    assert np.abs(np.ctypeslib.as_array(T.bpf_h)[:101] - c["bpf_h"].real).max() < 5e-9
+    assert np.abs(_c(T.bpf_E)[:1120] - c["bpf_phase_vec_exp"]).max() < 2e-7
+    assert np.abs(_c(T.p_w) - c["acq_p_w"].ravel()).max() < 5e-8
+    assert np.array_equal(np.ctypeslib.as_array(T.fcoarse), c["acq_fcoarse"])
+    assert T.pilot_gain == pytest.approx(float(c["pilot_gain"]), rel=1e-7)
+
+
+class Lin(C.Structure):
+    _fields_ = [("n_in", C.c_int), ("n_out", C.c_int), ("w", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float))]
+
+
+class Gru(C.Structure):
+    _fields_ = [("n_in", C.c_int), ("hid", C.c_int), ("w_ih", C.POINTER(C.c_float)), ("w_hh", C.POINTER(C.c_float)), ("b_ih", C.POINTER(C.c_float)), ("b_hh", C.POINTER(C.c_float))]
+
+
+class Model(C.Structure):
+    _fields_ = [("enc_dense1", Lin), ("enc_zdense", Lin), ("dec_dense1", Lin), ("dec_output", Lin), ("enc_gru", Gru * 5), ("dec_gru", Gru * 5),
+                ("enc_conv", Lin * 5), ("dec_conv", Lin * 5), ("dec_glu", Lin * 5)]
+
+
+def test_host_blob_reader_and_packing(lib, golden):
+    from radae_amd import dnnw, engine
+    blob = open(engine.DEFAULT_BLOB, "rb").read()
+    m = Model()
+    lib.rd_model_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Model)]
+    assert lib.rd_model_parse(blob, len(blob), C.byref(m)) == 0
+    ref = dnnw.load_model(engine.DEFAULT_BLOB)
+    arr = lambda p, n: np.ctypeslib.as_array(p, shape=(n,))
+    assert np.array_equal(arr(m.enc_dense1.w, 64 * 84).reshape(64, 84), ref.enc_dense1.w)
+    assert np.array_equal(arr(m.dec_output.w, 84 * 736).reshape(84, 736), ref.dec_output.w)
+    for i in range(5):
+        g, r = m.enc_gru[i], ref.enc_gru[i]
+        assert np.array_equal(arr(g.w_ih, 192 * g.n_in).reshape(192, -1), r.w_ih) and np.array_equal(arr(g.w_hh, 192 * 64).reshape(192, 64), r.w_hh)
+        assert np.array_equal(arr(g.b_ih, 192), r.b_ih) and np.array_equal(arr(g.b_hh, 192), r.b_hh)
+        g, r = m.dec_gru[i], ref.dec_gru[i]
+        assert np.array_equal(arr(g.w_ih, 288 * g.n_in).reshape(288, -1), r.w_ih) and np.array_equal(arr(g.w_hh, 288 * 96).reshape(288, 96), r.w_hh)
+        cw = ref.enc_conv[i].w.transpose(0, 2, 1).reshape(96, -1)         # [out][tap][in]
+        assert np.array_equal(arr(m.enc_conv[i].w, cw.size).reshape(cw.shape), cw)
+        assert np.array_equal(arr(m.dec_glu[i].w, 96 * 96).reshape(96, 96), ref.dec_glu[i].w)
+    w = golden("weights_check")
+    t = arr(m.enc_zdense.w, 80 * 864).astype(np.float64)
+    assert np.allclose([t.size, t.sum(), np.abs(t).sum()], w["enc_zdense_w"][:3], rtol=1e-12)
+    # truncated / corrupt blobs are rejected, not mis-parsed
+    assert lib.rd_model_parse(blob[:100000], 100000, C.byref(Model())) != 0
+    assert lib.rd_model_parse(b"XXXX" + blob[4:], len(blob), C.byref(Model())) != 0
+    # packing: every weight lands exactly once where k_gemm's lane expects it
+    lib.rd_packed_size.restype = C.c_long; lib.rd_packed_size.argtypes = [C.c_int, C.c_int]
+    lib.rd_pack_weights.restype = C.c_long; lib.rd_pack_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    N, K = 84, 88
+    W = np.arange(N * K, dtype=np.float32).reshape(N, K) + 1
+    n = lib.rd_packed_size(N, K)
+    out = np.zeros(n, np.float32)
+    assert lib.rd_pack_weights(W.ctypes.data_as(C.c_void_p), N, K, out.ctypes.data_as(C.c_void_p)) == n
+    ntt = 3
+    for kb, nt, lane, s in [(0, 0, 0, 0), (3, 2, 45, 1), (10, 1, 63, 3), (5, 2, 31, 2)]:
+        nn, k = nt * 32 + (lane & 31), kb * 8 + 4 * (lane >> 5) + s
+        exp = W[nn, k] if nn < N else 0.0
+        assert out[((kb * ntt + nt) * 64 + lane) * 4 + s] == exp
+    assert np.sort(out[out != 0]).tolist() == np.sort(W.ravel()).tolist()
+
+
+def test_loss_tool_matches_reference(golden):
+    from radae_amd.loss import distortion_loss, find_loss
+    g = golden("dec_loss")
+    assert distortion_loss(g["la"], g["lb"]) == pytest.approx(float(g["loss20"]), rel=2e-6)
+    assert distortion_loss(g["la21"], g["lb21"]) == pytest.approx(float(g["loss21"]), rel=2e-6)
+    t = golden("rxtrace_awgn")
+    l, s = find_loss(t["features_in"], t["features_out"].reshape(-1, 36))
+    assert 0 < l < 2.0 and s % 12 in range(12)
+
+
+def test_channel_tools_are_deterministic_and_normalised():
+    from radae_amd.channel_tools import multipath_g, synth_features
+    a, b = multipath_g("mpp", 8000, 16000, 3), multipath_g("mpp", 8000, 16000, 3)
+    assert np.array_equal(a, b) and a.shape == (16000, 2) and a.dtype == np.complex64
+    assert np.var(a[:, 0]) + np.var(a[:, 1]) == pytest.approx(1.0, rel=1e-3)       # hf_gain (multipath_samples.m:31)
+    f = synth_features(5, 24)
+    assert f.shape == (24, 36) and not f[:, 20:].any() and np.abs(f[:, 19]).max() <= 0.5
