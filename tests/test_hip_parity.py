@@ -270,3 +270,34 @@ def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model):
         l_g, s_g = find_loss(feats[b], got.reshape(-1, 36))
         assert s_o == s_g and abs(l_o - l_g) < 1e-4                   # loss.py delta vs the oracle < 1e-4
     eng.close()
+
+
+def _pipe(exe, args, data, cwd):
+    import subprocess
+    p = subprocess.run([exe] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return p.stdout
+
+
+@pytest.mark.parametrize("which", ["own", "reference"])
+def test_stdin_stdout_hosts(golden, tmp_path, which):
+    """features.f32 | radae_tx > iq.f32 and iq.f32 | radae_rx > features.f32 over the C ABI: our own hosts
+    (hosts/) and, when built, the reference's radae_tx.c / radae_rx.c compiled unmodified (oracle/_ref/)."""
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if which == "own":
+        txe, rxe, args = os.path.join(repo, "hosts", "rade_tx_filter"), os.path.join(repo, "hosts", "rade_rx_filter"), [""]
+    else:
+        txe, rxe, args = os.path.join(repo, "oracle", "_ref", "radae_tx"), os.path.join(repo, "oracle", "_ref", "radae_rx"), []
+    if not (os.path.exists(txe) and os.path.exists(rxe)):
+        pytest.skip(f"{txe} not built")
+    e = golden("enc_tx"); c = golden("consts"); g = golden("rxtrace_awgn")
+    c["eoo_bits_in"].astype(np.float32).tofile(tmp_path / "eoo_tx.f32")
+    iq = np.frombuffer(_pipe(txe, args, e["features"][0].astype(np.float32).tobytes(), tmp_path), np.complex64)
+    assert len(iq) == 10 * 960 + 2 * 1152
+    assert np.abs(iq[:9600].reshape(10, 960) - e["tx"][0]).max() < 2e-5
+    assert np.abs(iq[9600:9600 + 1152] - c["eoo_with_bits"]).max() < 1e-6 and not iq[9600 + 1152:].any()
+    feats = np.frombuffer(_pipe(rxe, args, g["rx_in"].astype(np.complex64).tobytes(), tmp_path), np.float32).reshape(-1, 432)
+    assert feats.shape == g["features_out"].shape and rms(feats, g["features_out"]) < 1e-5
+    eoo = np.fromfile(tmp_path / "eoo_rx.f32", np.float32)
+    assert eoo.shape == (180,) and np.abs(eoo - g["eoo_out"][-1]).max() < 1e-4
