@@ -57,7 +57,7 @@ typedef struct {
 typedef struct {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf;
     int f_ind_max, dec_reset_pending, bpf_mem_len, n_out_frames;
-    uint32_t lcg; int has_eoo, pad0, pad1;
+    uint32_t lcg; int has_eoo, dt_valid, pad1;
     double fmax, foff_err, rx_phase[2];
     double Dthresh, Dtmax12, Dtmax12_eoo;
     float snr_est, bpf_phase[2], pad2;
@@ -148,6 +148,7 @@ typedef struct {
     int max_calls;                                       /* call budget per stream per invocation */
     float *zrows;                                        /* [B][RD_DEC_ROWS][80] */
     int *n_rows; int *row_reset;                         /* flat [B], [B][RD_DEC_ROWS] copies for the decoder kernels */
+    float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */
     int *status;                                         /* [B][4]: nin, sync, snr_int, state */
     float *eoo_out;                                      /* [B][180] or NULL */
     rd_rx_trace *trace; float *trace_z; int trace_cap;   /* optional */

@@ -37,7 +37,7 @@ struct rade_batch {
     /* receive side */
     rd_rx_stream *rx_st; rd_rx_round *rx_round;
     int *rx_avail, *rx_acc, *rx_progress, *rx_nrows, *rx_rowreset, *rx_status;
-    float *zrows, *dec_x, *dec_gi, *dec_hbuf, *dec_h[5], *feat84;
+    float *zrows, *dec_x, *dec_gi, *dec_hbuf, *dec_h[5], *feat84, *dtcache;
     rd_rx_trace *trace; float *trace_z;
     int *h_small;                    /* pinned host scratch */
     unsigned *lcg_seeds;             /* host copy for resets */
@@ -176,8 +176,9 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->dec_gi = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 288);
     h->dec_hbuf = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 96);
     h->feat84 = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 84);
+    h->dtcache = dev_zeros(sizeof(float) * B * RD_NMF * RD_NFC);
     if (!h->enc_xin || !h->enc_x || !h->enc_gi || !h->enc_z || !h->eoo || !h->eoo_bits || !h->chan_scratch || !h->rx_st || !h->rx_round || !h->rx_avail ||
-        !h->rx_acc || !h->rx_progress || !h->rx_nrows || !h->rx_rowreset || !h->rx_status || !h->zrows || !h->dec_x || !h->dec_gi || !h->dec_hbuf || !h->feat84) {
+        !h->rx_acc || !h->rx_progress || !h->rx_nrows || !h->rx_rowreset || !h->rx_status || !h->zrows || !h->dec_x || !h->dec_gi || !h->dec_hbuf || !h->feat84 || !h->dtcache) {
         fprintf(stderr, "rade: device allocation failed\n"); goto fail;
     }
     if (h->trace_cap > 0) {
@@ -220,7 +221,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds };
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -360,7 +361,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
-    sa.max_calls = max_calls; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev;
+    sa.max_calls = max_calls; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     rd_post_args pa;
     memset(&pa, 0, sizeof pa);

@@ -121,16 +121,103 @@ __global__ __launch_bounds__(64) void k_gemm(rd_gemm_args a)
     }
 }
 
+// Small-M variant (decoder rounds, single-stream API): the K loop is the latency, so 8 wavefronts of one
+// workgroup split it (k-blocks interleaved), partial accumulators meet in LDS, and each wave finishes two of the
+// sixteen accumulator registers of every tile (bias / activation / store).
+#define SK_WAVES 8
+template <int NT>
+__global__ __launch_bounds__(64 * SK_WAVES) void k_gemm_splitk(rd_gemm_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sk_red[];       // [SK_WAVES][NT][16][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rows = a.B * a.T;
+    const int r0 = blockIdx.x * 32;
+    const int ntt = (a.N + 31) >> 5;
+    const int nt0 = blockIdx.y * NT;
+    int r = r0 + (lane & 31);
+    if (r >= rows) r = rows - 1;
+    const int b = r / a.T, t = r - b * a.T;
+    const int half = lane >> 5;
+    const float *p1 = a.a1 + b * a.a1_sb + t * a.a1_st + 4 * half;
+    const float *p0 = nullptr;
+    if (a.K0) {
+        const bool rst = a.reset && a.reset[r];
+        p0 = (rst ? g_zero_row : a.a0 + b * a.a0_sb + t * a.a0_st) + 4 * half;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+    const int nkb0 = a.K0 >> 3, nkb = nkb0 + (a.K1 >> 3);
+    const float *wbase = a.Wp + ((size_t)nt0 * 64 + lane) * 4;
+    const size_t wstep = (size_t)ntt * 256;
+#pragma unroll 2
+    for (int kb = wave; kb < nkb; kb += SK_WAVES) {
+        const float *p = kb < nkb0 ? p0 + kb * 8 : p1 + (kb - nkb0) * 8;
+        const f32x4 av = *(const f32x4 *)p;
+        f32x4 bv[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) bv[i] = *(const f32x4 *)(wbase + kb * wstep + i * 256);
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[i][s], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) sk_red[((wave * NT + i) * 16 + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int col = (nt0 + i) * 32 + (lane & 31);
+        if (col >= a.N) continue;
+        const float bias = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int j = wave * 2 + jj;
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < SK_WAVES; w++) v += sk_red[((w * NT + i) * 16 + j) * 64 + lane];
+            const int rr = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
+            if (rr >= rows) continue;
+            const int bb = rr / a.T, tt = rr - bb * a.T;
+            if (a.n_rows && tt >= a.n_rows[bb]) continue;
+            v += bias;
+            if (a.act == 1) v = clamp1(tanhf(v));
+            else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * sigmoid_f(v));
+            a.y[bb * a.y_sb + tt * a.y_st + col] = v;
+        }
+    }
+}
+
 extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
 {
     const int rows = a->B * a->T;
     if (rows <= 0) return 0;
     const int ntt = (a->N + 31) >> 5;
     hipStream_t st = (hipStream_t)s;
+    const int gx = (rows + 31) / 32;
+    if (rows <= 16384) {                       // too few row tiles to fill the chip: split K inside the workgroup
+        dim3 block(64 * SK_WAVES);
+        static int attr_done = 0;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)k_gemm_splitk<3>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 3 * 16 * 64 * 4);
+            (void)hipFuncSetAttribute((const void *)k_gemm_splitk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 2 * 16 * 64 * 4);
+            (void)hipFuncSetAttribute((const void *)k_gemm_splitk<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 1 * 16 * 64 * 4);
+            attr_done = 1;
+        }
+        if (ntt % 3 == 0) hipLaunchKernelGGL(k_gemm_splitk<3>, dim3(gx, ntt / 3), block, SK_WAVES * 3 * 16 * 64 * 4, st, *a);
+        else if (ntt % 2 == 0) hipLaunchKernelGGL(k_gemm_splitk<2>, dim3(gx, ntt / 2), block, SK_WAVES * 2 * 16 * 64 * 4, st, *a);
+        else hipLaunchKernelGGL(k_gemm_splitk<1>, dim3(gx, ntt), block, SK_WAVES * 1 * 16 * 64 * 4, st, *a);
+        return (int)hipGetLastError();
+    }
     dim3 block(64);
-    if (ntt % 3 == 0) { dim3 grid((rows + 31) / 32, ntt / 3); hipLaunchKernelGGL(k_gemm<3>, grid, block, 0, st, *a); }
-    else if (ntt % 2 == 0) { dim3 grid((rows + 31) / 32, ntt / 2); hipLaunchKernelGGL(k_gemm<2>, grid, block, 0, st, *a); }
-    else { dim3 grid((rows + 31) / 32, ntt); hipLaunchKernelGGL(k_gemm<1>, grid, block, 0, st, *a); }
+    if (ntt % 3 == 0) { dim3 grid(gx, ntt / 3); hipLaunchKernelGGL(k_gemm<3>, grid, block, 0, st, *a); }
+    else if (ntt % 2 == 0) { dim3 grid(gx, ntt / 2); hipLaunchKernelGGL(k_gemm<2>, grid, block, 0, st, *a); }
+    else { dim3 grid(gx, ntt); hipLaunchKernelGGL(k_gemm<1>, grid, block, 0, st, *a); }
     return (int)hipGetLastError();
 }
 
@@ -461,7 +548,7 @@ struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
     uint32_t lcg;
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, blocked, pending_valid, out_base;
-    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate;
+    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, units;
     float snr_est, mag; float2 bpf_phase;
     double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
 };
@@ -505,10 +592,11 @@ __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
 // GEMM  C[n,t] = sum_k Pm[n,k] X[k,t]  with k = 2m+c (re/im of rx), n = 2f+c' (re/im of Dt),
 //   X[k,t]  = rxf[2t + k]            (the interleaved float view of rx_buf: a Hankel matrix, never materialised)
 //   Pm[n,k] = {pr, pi; pi, -pr}[c'][c] of p_w[m,f]
-// One v_mfma_f32_16x16x4_f32 tile = 16 n x 16 t, K = 320 in 80 steps; both modem frames (t, t+Nmf) share the
-// Pm fragment.  Lane l feeds Pm[n = 16nt + (l&15)][k = 4s + (l>>4)] and X[k = 4s + (l>>4)][t = tl], and ends up
+// One v_mfma_f32_16x16x4_f32 tile = 16 n x 16 t, K = 320 in 80 steps; two column sets (tA, tB) share the Pm
+// fragment (two independent accumulator chains keep the matrix pipe issuing back to back).  Every Dt value is
+// produced by the same k-ordered chain whichever pairing computed it, so results do not depend on the pairing.  Lane l feeds Pm[n = 16nt + (l&15)][k = 4s + (l>>4)] and X[k = 4s + (l>>4)][t = tl], and ends up
 // with C rows n = 16nt + 4(l>>4) + r, i.e. (re,im) of f = 8nt + 2(l>>4) and f+1, for its column t.
-__device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int t_lane, int nt, f32x4 &acc1, f32x4 &acc2)
+__device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int tA_lane, int tB_lane, int nt, f32x4 &acc1, f32x4 &acc2)
 {
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, kl = lane >> 4;
@@ -517,12 +605,12 @@ __device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int t_lane, i
     const int comp = (i ^ kl) & 1;                         // which component of p_w this lane reads
     const float sgn = (i & kl & 1) ? -1.0f : 1.0f;         // Pm = -pr when c = c' = 1
     const float *pa = pwf + ((kl >> 1) * RD_NFC + 8 * nt + (i >> 1)) * 2 + comp;   // + s * (2*RD_NFC*2)
-    const float *pb = rxf + 2 * t_lane + kl;                                          // + 4*s ; frame 2 at + 2*RD_NMF
+    const float *pbA = rxf + 2 * tA_lane + kl, *pbB = rxf + 2 * tB_lane + kl;         // + 4*s
     acc1 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc2 = acc1;
 #pragma unroll 8
     for (int s = 0; s < 80; s++) {
         const float a = pa[s * (4 * RD_NFC)] * sgn;
-        const float b1 = pb[4 * s], b2 = pb[4 * s + 2 * RD_NMF];
+        const float b1 = pbA[4 * s], b2 = pbB[4 * s];
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc2, 0, 0, 0);
     }
@@ -639,7 +727,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
         S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->blocked = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0;
+        S->go = 0; S->dt_valid = st->dt_valid; S->units = 0;
     }
     const int avail = a.avail[b];
     __syncthreads();
@@ -649,7 +737,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // ---- can this stream make another call right now?  (decided once, by thread 0)
         if (tid == 0) {
             int go = 1;
-            if (S->calls_inv >= a.max_calls) go = 0;
+            if (S->calls_inv >= a.max_calls || S->units >= RD_RX_ROUND) go = 0;
             else if (S->consumed_inv + S->nin > avail) go = 0;
             else if (S->state == ST_SYNC && S->pending_valid > 0 && ((S->synced_count + 1) % 8) == 0) { S->blocked = 1; go = 0; }  // UW decision needs the decoder
             S->go = go;
@@ -711,34 +799,57 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 
         PH(1);
         if (state == ST_SEARCH || state == ST_CANDIDATE) {
-            // ---- acquisition.detect_pilots (dsp.py:178-231): each wave owns 16-row t tiles, all 40 bins, both frames
+            // ---- acquisition.detect_pilots (dsp.py:178-231).  While searching nin == Nmf, so this call's Dt1 surface is
+            // the previous call's Dt2 surface: |Dt2| is cached in HBM ([960][40] f32 per stream) and only the new
+            // Dt2 is correlated (two adjacent t tiles per MFMA pairing).  First call after (re)entering search: both.
             float best = -1.0f; int bt = 0x7fffffff, bfi = 0;
             {
-                const int wave = tid >> 6, lane = tid & 63, q = lane >> 4;
-                for (int tile = wave; tile < RD_NMF / 16; tile += NT_RX / 64) {
-                    const int t = tile * 16 + (lane & 15);
-                    float rs1 = 0.0f, rs2 = 0.0f, lmax = -1.0f; int larg = 0;
+                const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
+                float *cache = a.dtcache + (size_t)b * RD_NMF * RD_NFC;
+                const bool cached = S->dt_valid != 0;
+                if (cached) { for (int t = tid; t < RD_NMF; t += NT_RX) sh->rowsum1[t] = sh->rowsum2[t]; __syncthreads(); }
+                const int npair = cached ? RD_NMF / 32 : RD_NMF / 16;
+                for (int pr = wave; pr < npair; pr += NT_RX / 64) {
+                    const int tA = (cached ? pr * 32 : pr * 16) + j, tB = tA + 16;      // tB only used when cached
+                    float rsA1 = 0, rsA2 = 0, rsB2 = 0, lmaxA = -1.0f, lmaxB = -1.0f; int largA = 0, largB = 0;
 #pragma unroll 1
                     for (int nt = 0; nt < 5; nt++) {
-                        f32x4 c1, c2;
-                        corr_tile_mfma(sh, t, nt, c1, c2);
-                        const float a10 = hypotf(c1[0], c1[1]), a11 = hypotf(c1[2], c1[3]), a20 = hypotf(c2[0], c2[1]), a21 = hypotf(c2[2], c2[3]);
-                        rs1 += a10 + a11; rs2 += a20 + a21;
                         const int f = 8 * nt + 2 * q;
-                        const float v0 = a10 + a20, v1 = a11 + a21;
-                        if (v0 > lmax) { lmax = v0; larg = f; }
-                        if (v1 > lmax) { lmax = v1; larg = f + 1; }
+                        f32x4 c1, c2;
+                        if (cached) {
+                            const float2 oA = *(const float2 *)(cache + (size_t)tA * RD_NFC + f), oB = *(const float2 *)(cache + (size_t)tB * RD_NFC + f);
+                            corr_tile_mfma(sh, tA + RD_NMF, tB + RD_NMF, nt, c1, c2);
+                            const float nA0 = hypotf(c1[0], c1[1]), nA1 = hypotf(c1[2], c1[3]), nB0 = hypotf(c2[0], c2[1]), nB1 = hypotf(c2[2], c2[3]);
+                            *(float2 *)(cache + (size_t)tA * RD_NFC + f) = make_float2(nA0, nA1);
+                            *(float2 *)(cache + (size_t)tB * RD_NFC + f) = make_float2(nB0, nB1);
+                            rsA2 += nA0 + nA1; rsB2 += nB0 + nB1;
+                            float v = oA.x + nA0; if (v > lmaxA) { lmaxA = v; largA = f; }
+                            v = oA.y + nA1; if (v > lmaxA) { lmaxA = v; largA = f + 1; }
+                            v = oB.x + nB0; if (v > lmaxB) { lmaxB = v; largB = f; }
+                            v = oB.y + nB1; if (v > lmaxB) { lmaxB = v; largB = f + 1; }
+                        } else {
+                            corr_tile_mfma(sh, tA, tA + RD_NMF, nt, c1, c2);
+                            const float a10 = hypotf(c1[0], c1[1]), a11 = hypotf(c1[2], c1[3]), a20 = hypotf(c2[0], c2[1]), a21 = hypotf(c2[2], c2[3]);
+                            *(float2 *)(cache + (size_t)tA * RD_NFC + f) = make_float2(a20, a21);
+                            rsA1 += a10 + a11; rsA2 += a20 + a21;
+                            float v = a10 + a20; if (v > lmaxA) { lmaxA = v; largA = f; }
+                            v = a11 + a21; if (v > lmaxA) { lmaxA = v; largA = f + 1; }
+                        }
                     }
                     // combine the four lane groups (same t, different f) in a fixed order
 #pragma unroll
                     for (int off = 16; off <= 32; off <<= 1) {
-                        rs1 += __shfl_xor(rs1, off); rs2 += __shfl_xor(rs2, off);
-                        const float ov = __shfl_xor(lmax, off); const int oa = __shfl_xor(larg, off);
-                        if (ov > lmax || (ov == lmax && oa < larg)) { lmax = ov; larg = oa; }
+                        rsA1 += __shfl_xor(rsA1, off); rsA2 += __shfl_xor(rsA2, off); rsB2 += __shfl_xor(rsB2, off);
+                        float ov = __shfl_xor(lmaxA, off); int oa = __shfl_xor(largA, off);
+                        if (ov > lmaxA || (ov == lmaxA && oa < largA)) { lmaxA = ov; largA = oa; }
+                        ov = __shfl_xor(lmaxB, off); oa = __shfl_xor(largB, off);
+                        if (ov > lmaxB || (ov == lmaxB && oa < largB)) { lmaxB = ov; largB = oa; }
                     }
                     if (lane < 16) {
-                        sh->rowsum1[t] = rs1; sh->rowsum2[t] = rs2;
-                        if (lmax > best) { best = lmax; bt = t; bfi = larg; }   // tiles ascend per wave: first max kept
+                        sh->rowsum2[tA] = rsA2;
+                        if (cached) sh->rowsum2[tB] = rsB2; else sh->rowsum1[tA] = rsA1;
+                        if (lmaxA > best) { best = lmaxA; bt = tA; bfi = largA; }   // tiles ascend per wave: first max kept
+                        if (cached && lmaxB > best) { best = lmaxB; bt = tB; bfi = largB; }
                     }
                 }
             }
@@ -774,7 +885,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     const int tile = task / 5, nt = task - tile * 5;
                     const int row = tile * 16 + (lane & 15);
                     f32x4 c1, c2;
-                    corr_tile_mfma(sh, sh->rows48[row], nt, c1, c2);
+                    corr_tile_mfma(sh, sh->rows48[row], sh->rows48[row] + RD_NMF, nt, c1, c2);
                     const int f = 8 * nt + 2 * q;
                     sh->absd[2 * row][f] = hypotf(c1[0], c1[1]); sh->absd[2 * row][f + 1] = hypotf(c1[2], c1[3]);
                     sh->absd[2 * row + 1][f] = hypotf(c2[0], c2[1]); sh->absd[2 * row + 1][f + 1] = hypotf(c2[2], c2[3]);
@@ -944,6 +1055,9 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 else { S->valid_count--; if (S->valid_count == 0) next_state = ST_SEARCH; }
                 if (S->endofover || S->uw_fail) next_state = ST_SEARCH;
             }
+            // work units keep a round's duration similar for searching and synchronised streams
+            S->units += (state == ST_SYNC) ? 1 : (S->dt_valid ? 2 : 4);
+            S->dt_valid = (state != ST_SYNC && next_state != ST_SYNC) ? 1 : 0;   // next call's Dt1 == this call's Dt2
             S->state = next_state;
             if (next_state == ST_SEARCH) S->nin = RD_NMF;
             S->mf++;
@@ -977,7 +1091,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
     if (tid == 0) {
         st->state = S->state; st->nin = S->nin; st->tmax = S->tmax; st->tmax_candidate = S->tmax_candidate; st->valid_count = S->valid_count;
         st->uw_errors = S->uw_errors; st->synced_count = S->synced_count; st->mf = S->mf; st->f_ind_max = S->f_ind_max;
-        st->dec_reset_pending = S->dec_reset_pending; st->bpf_mem_len = S->bpf_mem_len; st->has_eoo = S->has_eoo; st->lcg = S->lcg;
+        st->dec_reset_pending = S->dec_reset_pending; st->bpf_mem_len = S->bpf_mem_len; st->has_eoo = S->has_eoo; st->lcg = S->lcg; st->dt_valid = S->dt_valid;
         st->fmax = S->fmax; st->foff_err = S->foff_err; st->rx_phase[0] = S->rph_r; st->rx_phase[1] = S->rph_i;
         st->Dthresh = S->Dthresh; st->Dtmax12 = S->Dtmax12; st->Dtmax12_eoo = S->Dtmax12_eoo; st->snr_est = S->snr_est;
         st->bpf_phase[0] = S->bpf_phase.x; st->bpf_phase[1] = S->bpf_phase.y; st->consumed += S->consumed_round;
