@@ -28,12 +28,13 @@ extern "C" {
 #endif
 
 typedef struct rade_batch rade_batch;
+#define RADE_BATCH_BOTTLENECK1 0x100
 
 typedef struct {
     int n_streams;        /* B */
     int max_tx_mf;        /* largest n_mf a single rade_batch_tx call may carry */
     int device;           /* HIP device ordinal */
-    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured */
+    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm) */
     int rx_trace_calls;   /* >0: keep a per-call trace of this many do_radae_rx calls per stream (tests) */
 } rade_batch_config;
 
@@ -55,6 +56,20 @@ int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host);
 /* writes the 1152-sample end-of-over frame of every stream; returns 1152 */
 int rade_batch_tx_eoo(rade_batch *h, void *iq_out_dev, long iq_stride, void *stream);
 void rade_batch_tx_reset(rade_batch *h);
+
+/* ---- core encoder / decoder alone ---------------------------------------------------------------
+ * The rade_core_encoder / rade_core_decoder level (src/rade_core.h:42-46, test_rade_enc.c / test_rade_dec.c),
+ * and what the non-OFDM configurations (inference.py rate-Rs, bbfm.py) run.  The feature width comes from
+ * the blob: 4 x 21 (model19: caller supplies the aux symbol) or 4 x 20 (model05, bbfm).
+ * features_dev: [B][n_steps][4*feat_dim] -> z_out_dev [B][n_steps][80]; state carried across calls
+ * (rade_batch_tx_reset clears it).  rade_batch_decode: z [B][n_steps][80] -> features [B][n_steps][4*feat_dim]. */
+int rade_batch_encode(rade_batch *h, const float *features_dev, int n_steps, float *z_out_dev, void *stream);
+int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *features_out_dev, int reset_state, void *stream);
+/* symbol-domain channels: mode 0 = rate-Rs AWGN/multipath magnitudes (radae.py:604-634; H_dev [B][n_steps*40] per
+ * QPSK symbol or NULL, p0 = sigma); mode 1 = BBFM FM-demodulator SNR model (bbfm.py:157-197; H_dev [B][n_steps*80]
+ * or NULL, p0 = CNRdB, p1 = Gfm dB).  noise_dev: [B][n_steps*80] float32 (already scaled per component) or NULL -> Philox(seed) */
+int rade_batch_channel_symbol(rade_batch *h, const float *z_dev, const float *H_dev, const float *noise_dev, float *z_hat_dev, int n_steps,
+                              int mode, float p0, float p1, unsigned long long seed, void *stream);
 
 /* ---- channel simulator ---------------------------------------------------------------------- */
 typedef struct {

@@ -342,10 +342,44 @@ def gen_dec_loss():
     print(f"dec ok (stateful vs stateless max diff {np.abs(feats - stateless).max():.2e})")
 
 
+def gen_model05():
+    """Config 1: inference.py plumbing with model05 -- RADAE(20, 80, EbNodB) defaults: rate Rs, Nc=20, Ns=6, no
+    pilots, bottleneck 1 (radae.py:604-634).  H = 1 (AWGN) and a multipath-magnitude H."""
+    m05 = dnnw.load_model(os.path.join(REPO, "weights", "model05.bin"))
+    T = 900                                                  # 9.0 s, stand-in for wav/peter.wav
+    feat36 = synth_features(2000, T)
+    features = torch.tensor(feat36[None, :, :20])
+    out = {}
+    for tag, EbNodB, use_h in (("awgn", 10.0, False), ("mp", 6.0, True)):
+        model = RADAE(20, 80, EbNodB)
+        load_into(model, m05)
+        model.eval()
+        nRs = model.num_timesteps_at_rate_Rs(T)
+        H = torch.ones((1, nRs, model.Nc))
+        if use_h:                                            # inference.py --mp_test style magnitudes (:133-143)
+            for c in range(model.Nc):
+                H[0, :, c] = abs(1 + np.exp(-1j * 2 * np.pi * c * 0.002 * model.Rs))
+        torch.manual_seed(77)
+        with torch.inference_mode():
+            o = model(features, H)
+            z = model.core_encoder(features)
+        torch.manual_seed(77)
+        noise = torch.randn(1, nRs, model.Nc, dtype=torch.complex64)
+        sigma = 10 ** (-EbNodB / 20)
+        nz = torch.view_as_real(noise).numpy().reshape(-1).astype(np.float32)     # (re,im) interleaved == z layout
+        out.update({f"{tag}_H": H.numpy()[0].astype(np.float32), f"{tag}_noise": nz, f"{tag}_sigma": np.float64(sigma),
+                    f"{tag}_z_hat": o["z_hat"].numpy()[0].astype(np.float32), f"{tag}_features_hat": o["features_hat"].numpy()[0].astype(np.float32)})
+        out["z"] = z.numpy()[0].astype(np.float32)
+        out[f"{tag}_loss"] = np.float64(distortion_loss(features, o["features_hat"]).item())
+    np.savez_compressed(os.path.join(OUT, "model05.npz"), features=feat36[:, :20].astype(np.float32), **out)
+    print("model05 ok", {k: float(v) for k, v in out.items() if k.endswith("loss")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec"]
+    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec", "model05"]
     if "consts" in which: gen_consts()
     if "weights" in which: gen_weights_check()
     if "enc" in which: gen_enc_tx()
     if "chanrx" in which: gen_chan_rx()
     if "dec" in which: gen_dec_loss()
+    if "model05" in which: gen_model05()

@@ -50,6 +50,10 @@ def lib():
             getattr(L, n).argtypes = [vp]
         L.orc_core_encoder.argtypes = [vp, vp, vp, vp]
         L.orc_core_decoder.argtypes = [vp, vp, vp, vp]
+        L.orc_core_encoder_b1.argtypes = [vp, vp, vp, vp]
+        L.orc_model_feat_width.argtypes = [vp]
+        L.orc_channel_rs.argtypes = [vp, vp, vp, vp, C.c_int, C.c_float]
+        L.orc_channel_bbfm.argtypes = [vp, vp, vp, vp, C.c_int, C.c_float, C.c_float]
         L.orc_enc_gru_state.restype = fp; L.orc_enc_gru_state.argtypes = [vp, C.c_int]
         L.orc_dec_gru_state.restype = fp; L.orc_dec_gru_state.argtypes = [vp, C.c_int]
         L.orc_tx_new.restype = vp; L.orc_tx_new.argtypes = [vp]
@@ -112,9 +116,10 @@ class Encoder:
     def __init__(self, model):
         self.m = model; self.s = lib().orc_enc_new()
 
-    def step(self, feat84):
+    def step(self, feat84, bottleneck=3):
         z = np.zeros(80, np.float32); f = f32(feat84)
-        lib().orc_core_encoder(self.m.h, self.s, _p(z), _p(f)); return z
+        assert f.size == lib().orc_model_feat_width(self.m.h)
+        (lib().orc_core_encoder_b1 if bottleneck == 1 else lib().orc_core_encoder)(self.m.h, self.s, _p(z), _p(f)); return z
 
     def gru_state(self, layer):
         return np.ctypeslib.as_array(lib().orc_enc_gru_state(self.s, layer), shape=(64,)).copy()
@@ -125,7 +130,7 @@ class Decoder:
         self.m = model; self.s = lib().orc_dec_new()
 
     def step(self, z80):
-        o = np.zeros(84, np.float32); z = f32(z80)
+        o = np.zeros(lib().orc_model_feat_width(self.m.h), np.float32); z = f32(z80)
         lib().orc_core_decoder(self.m.h, self.s, _p(o), _p(z)); return o
 
     def gru_state(self, layer):
@@ -145,6 +150,18 @@ class Tx:
 
     def eoo(self):
         out = np.zeros(1152, np.complex64); lib().orc_tx_eoo(self.h, _p(out)); return out
+
+
+def channel_rs(z, H, noise, sigma):
+    z = f32(z).ravel(); out = np.zeros_like(z)
+    lib().orc_channel_rs(_p(out), _p(z), _p(f32(H).ravel()) if H is not None else None, _p(f32(noise).ravel()) if noise is not None else None, z.size, sigma)
+    return out
+
+
+def channel_bbfm(z, H, noise, CNRdB, Gfm):
+    z = f32(z).ravel(); out = np.zeros_like(z)
+    lib().orc_channel_bbfm(_p(out), _p(z), _p(f32(H).ravel()) if H is not None else None, _p(f32(noise).ravel()) if noise is not None else None, z.size, CNRdB, Gfm)
+    return out
 
 
 def ofdm_mod(z240):

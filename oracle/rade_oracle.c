@@ -407,6 +407,32 @@ void orc_core_encoder(const orc_model *m, orc_enc_state *s, float z[80], const f
     dense(&m->enc_zdense, z, buf);      /* bottleneck 3: linear (radae_base.py:281-284) */
 }
 
+/* bottleneck 1 (model05, bbfm): z = tanh(z_dense(x)) -- radae_base.py:281-282.  features has 4*feature_dim floats
+ * (80 for the 20-feature models), taken from the blob's enc_dense1 width. */
+void orc_core_encoder_b1(const orc_model *m, orc_enc_state *s, float z[80], const float *features)
+{
+    orc_core_encoder(m, s, z, features);
+    for (int i = 0; i < 80; i++) z[i] = tanhf(z[i]);
+}
+int orc_model_feat_width(const orc_model *m) { return m->enc_dense1.n_in; }
+
+/* symbol-domain channels (radae.py:604-634 rate-Rs with bottleneck 1; bbfm.py:157-197) on n real symbols */
+void orc_channel_rs(float *z_hat, const float *z, const float *H /* per QPSK symbol or NULL */, const float *noise, int n, float sigma)
+{
+    for (int i = 0; i < n; i++) z_hat[i] = z[i] * (H ? H[i >> 1] : 1.0f) + sigma * (noise ? noise[i] : 0.0f);
+}
+void orc_channel_bbfm(float *z_hat, const float *z, const float *H, const float *noise, int n, float CNRdB, float Gfm)
+{
+    for (int i = 0; i < n; i++) {
+        float cnr = 20.0f * log10f(H ? H[i] : 1.0f) + CNRdB;
+        float snr = fmaxf(cnr - 12.0f, 0.0f) + 12.0f + Gfm;
+        snr += -fmaxf(-(cnr - 12.0f), 0.0f) * (1.0f + Gfm / 3.0f);
+        float sigma = 1.0f / powf(powf(10.0f, snr / 10.0f), 0.5f);
+        float v = z[i] + sigma * (noise ? noise[i] : 0.0f);
+        z_hat[i] = v < -1.0f ? -1.0f : (v > 1.0f ? 1.0f : v);
+    }
+}
+
 void orc_core_decoder(const orc_model *m, orc_dec_state *s, float features[84], const float z_hat[80])
 {
     float buf[736]; int n = 0; float gate[96];

@@ -49,6 +49,10 @@ void orc_enc_free(orc_enc_state *s);
 void orc_dec_free(orc_dec_state *s);
 void orc_core_encoder(const orc_model *m, orc_enc_state *s, float z[80], const float features[84]);
 void orc_core_decoder(const orc_model *m, orc_dec_state *s, float features[84], const float z_hat[80]);
+void orc_core_encoder_b1(const orc_model *m, orc_enc_state *s, float z[80], const float *features);   /* bottleneck 1 */
+int orc_model_feat_width(const orc_model *m);                                                          /* 84 or 80 */
+void orc_channel_rs(float *z_hat, const float *z, const float *H, const float *noise, int n, float sigma);
+void orc_channel_bbfm(float *z_hat, const float *z, const float *H, const float *noise, int n, float CNRdB, float Gfm);
 /* state peek for tests: layer 1..5 */
 const float *orc_enc_gru_state(const orc_enc_state *s, int layer);
 const float *orc_dec_gru_state(const orc_dec_state *s, int layer);

@@ -126,6 +126,8 @@ int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s);
 
 /* encoder input packing: features [B][T*4][36] -> [B][T][88] = 4 x (20 feats, aux -1), zero pad */
 int rd_launch_enc_pack(const float *features, float *xin, int B, int T, rd_stream_t s);
+int rd_launch_pad_rows(const float *src, float *dst, long R, int K, int Kpad, rd_stream_t s);
+int rd_launch_chan_symbol(const float *z, const float *H, const float *noise, float *out, long n_real, int mode, float p0, float p1, unsigned long long seed, rd_stream_t s);
 /* x is [B][nhist+Tcap][W]: copy time rows [T, T+nhist) (or [n_rows[b], ..)) of each stream to rows [0, nhist) */
 int rd_launch_carry_rows(float *x, int B, int Tcap, int W, int nhist, int T, const int *n_rows, rd_stream_t s);
 /* z [B][n_mf*3][80] -> tx [b*stride + mf*960 ...] (transmitter_one, dsp.py:340-378) */
@@ -146,6 +148,7 @@ typedef struct {
     const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
     int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
     int max_calls;                                       /* call budget per stream per invocation */
+    int unit_budget;                                     /* work units per round (sync call 1, detect 2 or 4) */
     float *zrows;                                        /* [B][RD_DEC_ROWS][80] */
     int *n_rows; int *row_reset;                         /* flat [B], [B][RD_DEC_ROWS] copies for the decoder kernels */
     float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */

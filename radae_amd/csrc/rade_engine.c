@@ -27,6 +27,8 @@ typedef struct { float *wp, *bias; int N, K; } dev_lin;
 
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
+    int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
+    float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
     /* weights */
     dev_lin enc_dense1, enc_zdense, dec_dense1, dec_output, enc_gin[5], dec_gin[5], enc_conv[5], dec_conv[5], dec_glu[5];
@@ -141,10 +143,11 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     if (!h->d_tab) goto fail;
 
     int err = 0;
-    err |= upload_lin(&h->enc_dense1, m.enc_dense1.w, m.enc_dense1.b, 64, 84, RD_ENC_IN);
+    h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 7) & ~7; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
+    err |= upload_lin(&h->enc_dense1, m.enc_dense1.w, m.enc_dense1.b, 64, h->feat_in, h->enc_kpad);
     err |= upload_lin(&h->enc_zdense, m.enc_zdense.w, m.enc_zdense.b, 80, 864, 864);
     err |= upload_lin(&h->dec_dense1, m.dec_dense1.w, m.dec_dense1.b, 96, 80, 80);
-    err |= upload_lin(&h->dec_output, m.dec_output.w, m.dec_output.b, 84, 736, 736);
+    err |= upload_lin(&h->dec_output, m.dec_output.w, m.dec_output.b, h->feat_in, 736, 736);
     for (int l = 0; l < 5 && !err; l++) {
         err |= upload_lin(&h->enc_gin[l], m.enc_gru[l].w_ih, m.enc_gru[l].b_ih, 192, ENC_IN[l], ENC_IN[l]);
         err |= upload_lin(&h->dec_gin[l], m.dec_gru[l].w_ih, m.dec_gru[l].b_ih, 288, DEC_IN[l], DEC_IN[l]);
@@ -176,6 +179,11 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->dec_gi = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 288);
     h->dec_hbuf = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 96);
     h->feat84 = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 84);
+    h->dec2_x = dev_zeros(sizeof(float) * B * (1 + T) * RD_DEC_W);
+    h->dec2_gi = dev_zeros(sizeof(float) * B * T * 288);
+    h->dec2_hbuf = dev_zeros(sizeof(float) * B * T * 96);
+    for (int l = 0; l < 5; l++) { h->dec2_h[l] = dev_zeros(sizeof(float) * B * 96); if (!h->dec2_h[l]) goto fail; }
+    if (!h->dec2_x || !h->dec2_gi || !h->dec2_hbuf) goto fail;
     h->dtcache = dev_zeros(sizeof(float) * B * RD_NMF * RD_NFC);
     if (!h->enc_xin || !h->enc_x || !h->enc_gi || !h->enc_z || !h->eoo || !h->eoo_bits || !h->chan_scratch || !h->rx_st || !h->rx_round || !h->rx_avail ||
         !h->rx_acc || !h->rx_progress || !h->rx_nrows || !h->rx_rowreset || !h->rx_status || !h->zrows || !h->dec_x || !h->dec_gi || !h->dec_hbuf || !h->feat84 || !h->dtcache) {
@@ -221,13 +229,13 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache };
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
         free_lin(&h->enc_gin[l]); free_lin(&h->dec_gin[l]); free_lin(&h->enc_conv[l]); free_lin(&h->dec_conv[l]); free_lin(&h->dec_glu[l]);
-        void *p[] = { h->enc_whh[l], h->enc_bhh[l], h->dec_whh[l], h->dec_bhh[l], h->enc_h[l], h->dec_h[l] };
-        for (int i = 0; i < 6; i++) if (p[i]) hipFree(p[i]);
+        void *p[] = { h->enc_whh[l], h->enc_bhh[l], h->dec_whh[l], h->dec_bhh[l], h->enc_h[l], h->dec_h[l], h->dec2_h[l] };
+        for (int i = 0; i < 7; i++) if (p[i]) hipFree(p[i]);
     }
     if (h->h_small) hipHostFree(h->h_small);
     if (h->prof_ev[0]) hipEventDestroy(h->prof_ev[0]);
@@ -270,17 +278,14 @@ static int gemm(rade_batch *hh, const dev_lin *w, const float *a1, long a1_sb, l
     return rc;
 }
 
-/* ---- transmit (radae_txe.py:108-135 for n_mf modem frames and B streams at once) -------------- */
-int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, float *z_out_dev, void *stream)
+/* ---- CoreEncoderStatefull.forward over T steps for all streams (radae_base.py:260-286); xin = [B][T][enc_kpad] ---- */
+static int encode_core(rade_batch *h, int T, float *z, void *stream)
 {
-    if (!h || n_mf <= 0 || n_mf > h->max_tx_mf) return -1;
-    const int B = h->B, T = 3 * n_mf, W = RD_ENC_W;
+    const int B = h->B, W = RD_ENC_W;
     const long xsb = (long)(2 + h->Tcap) * W;
     float *x = h->enc_x + 2 * W;               /* time row 0 of each stream; rows -2,-1 hold the conv history */
-    float *z = z_out_dev ? z_out_dev : h->enc_z;
     int e = 0;
-    e |= rd_launch_enc_pack(features_dev, h->enc_xin, B, T, stream);
-    e |= gemm(h, &h->enc_dense1, h->enc_xin, (long)T * RD_ENC_IN, RD_ENC_IN, RD_ENC_IN, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
+    e |= gemm(h, &h->enc_dense1, h->enc_xin, (long)T * h->enc_kpad, h->enc_kpad, h->enc_kpad, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = ENC_IN[l];
         e |= gemm(h, &h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, h->enc_gi, (long)T * 192, 192, B, T, 0, stream);
@@ -289,10 +294,32 @@ int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_o
         const int cin = in + 64;
         e |= gemm(h, &h->enc_conv[l], x, xsb, W, cin, x - (long)ENC_DIL[l] * W, xsb, W, cin, NULL, NULL, x + cin, xsb, W, B, T, 1, stream);
     }
-    e |= gemm(h, &h->enc_zdense, x, xsb, W, 864, NULL, 0, 0, 0, NULL, NULL, z, (long)T * RD_LATENT, RD_LATENT, B, T, 0, stream);
+    /* bottleneck 1: z = tanh(z_dense) (radae_base.py:281-284); bottleneck 3: linear */
+    e |= gemm(h, &h->enc_zdense, x, xsb, W, 864, NULL, 0, 0, 0, NULL, NULL, z, (long)T * RD_LATENT, RD_LATENT, B, T, h->bottleneck1 ? 1 : 0, stream);
     e |= rd_launch_carry_rows(h->enc_x, B, h->Tcap, W, 2, T, NULL, stream);
+    return e;
+}
+
+/* ---- transmit (radae_txe.py:108-135 for n_mf modem frames and B streams at once) -------------- */
+int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, float *z_out_dev, void *stream)
+{
+    if (!h || n_mf <= 0 || n_mf > h->max_tx_mf || h->feat_in != 84) return -1;
+    const int B = h->B, T = 3 * n_mf;
+    float *z = z_out_dev ? z_out_dev : h->enc_z;
+    int e = 0;
+    e |= rd_launch_enc_pack(features_dev, h->enc_xin, B, T, stream);
+    e |= encode_core(h, T, z, stream);
     PROF_BEGIN(h, stream); e |= rd_launch_ofdm_mod(h->d_tab, z, iq_out_dev, iq_stride, B, n_mf, stream); PROF_END(h, stream, RADE_PROF_MOD, 8.0 * B * n_mf * 5 * 30 * 160);
     return e ? -1 : n_mf * RD_NMF;
+}
+
+/* ---- core encoder / decoder alone (the rade_core_encoder / rade_core_decoder level, src/rade_core.h:42-46) ---- */
+int rade_batch_encode(rade_batch *h, const float *features_dev, int n_steps, float *z_out_dev, void *stream)
+{
+    if (!h || n_steps <= 0 || n_steps > h->Tcap || !z_out_dev) return -1;
+    int e = rd_launch_pad_rows(features_dev, h->enc_xin, (long)h->B * n_steps, h->feat_in, h->enc_kpad, stream);
+    e |= encode_core(h, n_steps, z_out_dev, stream);
+    return e ? -1 : n_steps;
 }
 
 int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host)
@@ -328,31 +355,58 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
 }
 
 /* ---- receive ----------------------------------------------------------------------------------- */
-static int decoder_round(rade_batch *h, void *stream)
-{   /* CoreDecoderStatefull.forward (radae_base.py:400-416) over the rows the sync kernel emitted */
-    const int B = h->B, T = RD_DEC_ROWS, W = RD_DEC_W;
-    const long xsb = (long)(1 + T) * W;
-    float *x = h->dec_x + W;                    /* slot 0 of each stream = conv history (previous valid step) */
-    const int *nr = h->rx_nrows, *rst = h->rx_rowreset;
+/* CoreDecoderStatefull.forward (radae_base.py:400-416) over T time slots of every stream.  x = [B][1+Tcap][736]
+ * (slot 0 = conv history), rows beyond n_rows[b] are skipped, rst flags zero the state before a step. */
+static int decoder_layers(rade_batch *h, const float *z, int T, int Tcap, float *xbuf, float *gi, float *hbuf, float **hstate,
+                          const int *nr, const int *rst, float *out, void *stream)
+{
+    const int B = h->B, W = RD_DEC_W;
+    const long xsb = (long)(1 + Tcap) * W;
+    float *x = xbuf + W;
     int e = 0;
-    e |= gemm(h, &h->dec_dense1, h->zrows, (long)T * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
+    e |= gemm(h, &h->dec_dense1, z, (long)T * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = DEC_IN[l];
-        e |= gemm(h, &h->dec_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, nr, h->dec_gi, (long)T * 288, 288, B, T, 0, stream);
-        rd_scan_args s = { h->dec_gi, (long)T * 288, 288, h->dec_whh[l], h->dec_bhh[l], h->dec_h[l], h->dec_hbuf, (long)T * 96, 96, rst, nr, B, T, 96 };
+        e |= gemm(h, &h->dec_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, nr, gi, (long)T * 288, 288, B, T, 0, stream);
+        rd_scan_args s = { gi, (long)T * 288, 288, h->dec_whh[l], h->dec_bhh[l], hstate[l], hbuf, (long)T * 96, 96, rst, nr, B, T, 96 };
         PROF_BEGIN(h, stream); e |= rd_launch_gru_scan(&s, stream); PROF_END(h, stream, RADE_PROF_SCAN, 2.0 * B * T * 288 * 96);
-        e |= gemm(h, &h->dec_glu[l], h->dec_hbuf, (long)T * 96, 96, 96, NULL, 0, 0, 0, NULL, nr, x + in, xsb, W, B, T, 2, stream);
+        e |= gemm(h, &h->dec_glu[l], hbuf, (long)T * 96, 96, 96, NULL, 0, 0, 0, NULL, nr, x + in, xsb, W, B, T, 2, stream);
         const int cin = in + 96;
         e |= gemm(h, &h->dec_conv[l], x, xsb, W, cin, x - W, xsb, W, cin, rst, nr, x + cin, xsb, W, B, T, 1, stream);
     }
-    e |= gemm(h, &h->dec_output, x, xsb, W, 736, NULL, 0, 0, 0, NULL, nr, h->feat84, (long)T * 84, 84, B, T, 0, stream);
+    e |= gemm(h, &h->dec_output, x, xsb, W, 736, NULL, 0, 0, 0, NULL, nr, out, (long)T * h->feat_in, h->feat_in, B, T, 0, stream);
     return e;
+}
+
+static int decoder_round(rade_batch *h, void *stream)
+{
+    return decoder_layers(h, h->zrows, RD_DEC_ROWS, RD_DEC_ROWS, h->dec_x, h->dec_gi, h->dec_hbuf, h->dec_h, h->rx_nrows, h->rx_rowreset, h->feat84, stream);
+}
+
+int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *features_out_dev, int reset_state, void *stream)
+{
+    if (!h || n_steps <= 0 || n_steps > h->Tcap || !features_out_dev) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    if (reset_state) {
+        for (int l = 0; l < 5; l++) hipMemsetAsync(h->dec2_h[l], 0, sizeof(float) * h->B * 96, st);
+        hipMemsetAsync(h->dec2_x, 0, sizeof(float) * (size_t)h->B * (1 + h->Tcap) * RD_DEC_W, st);
+    }
+    int e = decoder_layers(h, z_dev, n_steps, h->Tcap, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->dec2_h, NULL, NULL, features_out_dev, stream);
+    e |= rd_launch_carry_rows(h->dec2_x, h->B, h->Tcap, RD_DEC_W, 1, n_steps, NULL, stream);
+    return e ? -1 : n_steps;
+}
+
+int rade_batch_channel_symbol(rade_batch *h, const float *z_dev, const float *H_dev, const float *noise_dev, float *z_hat_dev, int n_steps,
+                              int mode, float p0, float p1, unsigned long long seed, void *stream)
+{
+    if (!h || n_steps <= 0 || (mode != 0 && mode != 1)) return -1;
+    return rd_launch_chan_symbol(z_dev, H_dev, noise_dev, z_hat_dev, (long)h->B * n_steps * RD_LATENT, mode, p0, p1, seed, stream) ? -1 : n_steps;
 }
 
 int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *n_avail_host, int max_calls,
                   float *features_out_dev, long feat_stride, float *eoo_out_dev, rade_rx_status *status_host, void *stream)
 {
-    if (!h || !n_avail_host || max_calls <= 0) return -1;
+    if (!h || !n_avail_host || max_calls <= 0 || h->feat_in != 84) return -1;
     const int B = h->B;
     hipStream_t st = (hipStream_t)stream;
     int *hs = h->h_small;
@@ -361,7 +415,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
-    sa.max_calls = max_calls; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+    sa.max_calls = max_calls; sa.unit_budget = getenv("RADE_UNIT_BUDGET") ? atoi(getenv("RADE_UNIT_BUDGET")) : 10; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     rd_post_args pa;
     memset(&pa, 0, sizeof pa);

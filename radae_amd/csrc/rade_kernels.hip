@@ -294,7 +294,7 @@ extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
 // small data-movement kernels
 // =====================================================================================================
 __global__ void k_enc_pack(const float *features, float *xin, int B, int T)
-{
+{   // model19 only: 4 x (20 features + aux symbol -1) padded 84 -> 88
     const long n = (long)B * T * RD_ENC_IN;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % RD_ENC_IN); const long bt = i / RD_ENC_IN;
@@ -308,6 +308,23 @@ extern "C" int rd_launch_enc_pack(const float *features, float *xin, int B, int 
     const long n = (long)B * T * RD_ENC_IN; if (n <= 0) return 0;
     int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(k_enc_pack, dim3(grid), dim3(256), 0, (hipStream_t)s, features, xin, B, T);
+    return (int)hipGetLastError();
+}
+
+// dense rows [R][K] -> [R][Kpad] with zero fill (GEMM K must be a multiple of 8)
+__global__ void k_pad_rows(const float *src, float *dst, long R, int K, int Kpad)
+{
+    const long n = R * Kpad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Kpad); const long r = i / Kpad;
+        dst[i] = c < K ? src[r * K + c] : 0.0f;
+    }
+}
+extern "C" int rd_launch_pad_rows(const float *src, float *dst, long R, int K, int Kpad, rd_stream_t s)
+{
+    const long n = R * Kpad; if (n <= 0) return 0;
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_pad_rows, dim3(grid), dim3(256), 0, (hipStream_t)s, src, dst, R, K, Kpad);
     return (int)hipGetLastError();
 }
 
@@ -514,6 +531,38 @@ __global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double
         }
         rx[j] = v;
     }
+}
+
+// Symbol-domain channels of the non-OFDM configurations.
+//  mode 0 (rate-Rs, radae.py:604-634, bottleneck 1): QPSK symbol k = (z[2k], z[2k+1]) * H[k] + sigma * CN(0,1)
+//  mode 1 (BBFM, bbfm.py:157-197): per real symbol, FM demodulator SNR from the carrier-to-noise ratio:
+//          CNRdB = 20log10(H)+CNR ; SNRdB = relu(CNR-12)+12+Gfm - relu(12-CNR)(1+Gfm/3) ; z_hat = clamp(z + N(0,1)/sqrt(SNR))
+__global__ void k_chan_symbol(const float *z, const float *H, const float *noise, float *out, long n_real, int mode, float p0, float p1, unsigned long long seed)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_real; i += (long)gridDim.x * blockDim.x) {
+        float nz;
+        if (noise) nz = noise[i];
+        else if (seed) { uint32_t r[4]; philox4x32((uint32_t)(i >> 1), (uint32_t)((i >> 1) >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r); const float2 g = gauss_pair(r[0], r[1]); nz = (i & 1) ? g.y : g.x; if (mode == 0) nz *= 0.70710678f; }
+        else nz = 0.0f;
+        float v;
+        if (mode == 0) { const float h = H ? H[i >> 1] : 1.0f; v = z[i] * h + p0 * nz; }            // p0 = sigma; complex noise: 1/2 per component (explicit tensors already are)
+        else {
+            const float h = H ? H[i] : 1.0f;
+            const float cnr = 20.0f * log10f(h) + p0;                                                 // p0 = CNRdB, p1 = Gfm
+            float snr = fmaxf(cnr - 12.0f, 0.0f) + 12.0f + p1;
+            snr += -fmaxf(-(cnr - 12.0f), 0.0f) * (1.0f + p1 / 3.0f);
+            const float sigma = 1.0f / powf(powf(10.0f, snr / 10.0f), 0.5f);
+            v = fminf(fmaxf(z[i] + sigma * nz, -1.0f), 1.0f);
+        }
+        out[i] = v;
+    }
+}
+extern "C" int rd_launch_chan_symbol(const float *z, const float *H, const float *noise, float *out, long n_real, int mode, float p0, float p1, unsigned long long seed, rd_stream_t s)
+{
+    if (n_real <= 0) return 0;
+    int grid = (int)((n_real + 255) / 256); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_chan_symbol, dim3(grid), dim3(256), 0, (hipStream_t)s, z, H, noise, out, n_real, mode, p0, p1, seed);
+    return (int)hipGetLastError();
 }
 
 extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
@@ -733,11 +782,11 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
     __syncthreads();
     PH_T0(); PH(0);
 
-    for (int it = 0; it < RD_RX_ROUND; it++) {
+    for (int it = 0; it < RD_RX_ROUND; it++) {   // <= RD_RX_ROUND calls: sizes of the per-round hand-off arrays
         // ---- can this stream make another call right now?  (decided once, by thread 0)
         if (tid == 0) {
             int go = 1;
-            if (S->calls_inv >= a.max_calls || S->units >= RD_RX_ROUND) go = 0;
+            if (S->calls_inv >= a.max_calls || S->units >= a.unit_budget || S->n_calls >= RD_RX_ROUND) go = 0;
             else if (S->consumed_inv + S->nin > avail) go = 0;
             else if (S->state == ST_SYNC && S->pending_valid > 0 && ((S->synced_count + 1) % 8) == 0) { S->blocked = 1; go = 0; }  // UW decision needs the decoder
             S->go = go;

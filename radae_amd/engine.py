@@ -64,6 +64,9 @@ def load_library() -> C.CDLL:
     L.rade_sigma_from_EbNodB.restype = C.c_float; L.rade_sigma_from_EbNodB.argtypes = [C.c_float]
     L.rade_batch_rx.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_int), C.c_int, vp, C.c_long, vp, C.POINTER(RxStatus), vp]
     L.rade_batch_rx_reset.argtypes = [vp]
+    L.rade_batch_encode.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.rade_batch_decode.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.rade_batch_channel_symbol.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, C.c_ulonglong, vp]
     L.rade_batch_reset.argtypes = [vp, vp]
     L.rade_batch_profile.argtypes = [vp, C.c_int]
     L.rade_batch_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
@@ -82,6 +85,7 @@ EXPORTED_SYMBOLS = [
     "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_set_eoo_bits",
     "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get",
+    "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
 ]
 
 
@@ -184,6 +188,39 @@ class BatchEngine:
         out = torch.empty((self.B, NEOO), dtype=torch.complex64, device=self.device)
         if self.lib.rade_batch_tx_eoo(self.h, out.data_ptr(), NEOO, _stream_ptr()) != NEOO:
             raise RuntimeError("rade_batch_tx_eoo failed")
+        return out
+
+    # ---- core encoder / decoder alone, symbol-domain channels (configs 1, 2, 5) -----------------
+    def encode(self, features):
+        """features cuda float32 [B, n_steps, 4*feat_dim] -> z [B, n_steps, 80] (state carried; tx_reset() clears)."""
+        import torch
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous() and features.shape[0] == self.B
+        n = features.shape[1]
+        z = torch.empty((self.B, n, 80), dtype=torch.float32, device=features.device)
+        if self.lib.rade_batch_encode(self.h, features.data_ptr(), n, z.data_ptr(), _stream_ptr()) != n:
+            raise RuntimeError("rade_batch_encode failed (n_steps > 3*max_tx_mf?)")
+        return z
+
+    def decode(self, z, feat_width: int, reset: bool = True):
+        """z cuda float32 [B, n_steps, 80] -> features [B, n_steps, feat_width] (feat_width = 4*feat_dim of the blob)."""
+        import torch
+        assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and tuple(z.shape[::2]) == (self.B, 80)
+        n = z.shape[1]
+        out = torch.empty((self.B, n, feat_width), dtype=torch.float32, device=z.device)
+        if self.lib.rade_batch_decode(self.h, z.data_ptr(), n, out.data_ptr(), int(reset), _stream_ptr()) != n:
+            raise RuntimeError("rade_batch_decode failed")
+        return out
+
+    def channel_symbol(self, z, mode: str, p0: float, p1: float = 0.0, H=None, noise=None, seed: int = 0):
+        """mode 'rs': z*H + sigma*noise (p0 = sigma, H per QPSK symbol [B, n*40]); mode 'bbfm': FM-demod SNR model
+        (p0 = CNRdB, p1 = Gfm dB, H per real symbol [B, n*80]).  noise float32 [B, n*80] or None -> Philox(seed)."""
+        import torch
+        n = z.shape[1]
+        out = torch.empty_like(z)
+        r = self.lib.rade_batch_channel_symbol(self.h, z.data_ptr(), H.data_ptr() if H is not None else None, noise.data_ptr() if noise is not None else None,
+                                               out.data_ptr(), n, 0 if mode == "rs" else 1, p0, p1, seed, _stream_ptr())
+        if r != n:
+            raise RuntimeError("rade_batch_channel_symbol failed")
         return out
 
     # ---- channel ----------------------------------------------------------------------------

@@ -301,3 +301,34 @@ def test_stdin_stdout_hosts(golden, tmp_path, which):
     assert feats.shape == g["features_out"].shape and rms(feats, g["features_out"]) < 1e-5
     eoo = np.fromfile(tmp_path / "eoo_rx.f32", np.float32)
     assert eoo.shape == (180,) and np.abs(eoo - g["eoo_out"][-1]).max() < 1e-4
+
+
+def test_model05_rate_rs_config1(Engine, torch_dev, golden):
+    """BASELINE config 1 on the GPU: model05 blob, bottleneck 1, rate-Rs symbol channel, stand-alone decoder."""
+    import os
+    import torch
+    from radae_amd.engine import DEFAULT_BLOB
+    from radae_amd.loss import distortion_loss
+    g = golden("model05")
+    blob = os.path.join(os.path.dirname(DEFAULT_BLOB), "model05.bin")
+    T = g["features"].shape[0] // 4
+    eng = Engine(1, max_tx_mf=T // 3, blob=blob, flags=0x100)          # RADE_BATCH_BOTTLENECK1
+    z = eng.encode(torch.tensor(g["features"].reshape(1, T, 80), device=torch_dev))
+    assert rms(z.cpu().numpy()[0], g["z"]) < 2e-5
+    for tag in ("awgn", "mp"):
+        zh = eng.channel_symbol(torch.tensor(g["z"][None], device=torch_dev), "rs", float(g[tag + "_sigma"]),
+                                H=torch.tensor(g[tag + "_H"].reshape(1, -1), device=torch_dev), noise=torch.tensor(g[tag + "_noise"][None], device=torch_dev))
+        assert np.abs(zh.cpu().numpy()[0] - g[tag + "_z_hat"]).max() < 1e-6
+        fh = eng.decode(torch.tensor(g[tag + "_z_hat"][None], device=torch_dev), 80).cpu().numpy()[0].reshape(-1, 20)
+        assert rms(fh, g[tag + "_features_hat"]) < 2e-5
+        assert abs(distortion_loss(g["features"], fh) - float(g[tag + "_loss"])) < 1e-4
+    # chunked == whole (stateful == stateless, ctests stateful_encoder / stateful_decoder)
+    eng.tx_reset()
+    f = torch.tensor(g["features"].reshape(1, T, 80), device=torch_dev)
+    zc = torch.cat([eng.encode(f[:, a:b].contiguous()) for a, b in ((0, 1), (1, 4), (4, 100), (100, T))], 1)
+    assert rms(zc.cpu().numpy()[0], z.cpu().numpy()[0]) < 1e-5
+    zt = torch.tensor(g["awgn_z_hat"][None], device=torch_dev)
+    whole = eng.decode(zt, 80)
+    parts = torch.cat([eng.decode(zt[:, a:b].contiguous(), 80, reset=(a == 0)) for a, b in ((0, 3), (3, 4), (4, T))], 1)
+    assert rms(parts.cpu().numpy(), whole.cpu().numpy()) < 1e-5
+    eng.close()

@@ -117,3 +117,21 @@ def test_loopback_loss_alignment(oracle, oracle_model, golden):
     l_ref, s_ref = oracle.find_loss(fi, g["features_out"].reshape(-1, 36))
     l_orc, s_orc = oracle.find_loss(fi, d["features_out"].reshape(-1, 36))
     assert s_ref == s_orc and abs(l_ref - l_orc) < 1e-4
+
+
+def test_model05_rate_rs_config1(oracle, golden):
+    """BASELINE config 1: model05 through the rate-Rs channel (inference.py plumbing), oracle vs the reference."""
+    import os
+    g = golden("model05")
+    m = oracle.Model(os.path.join(os.path.dirname(oracle.BLOB), "model05.bin"))
+    enc = oracle.Encoder(m)
+    f = g["features"].reshape(-1, 80)
+    z = np.array([enc.step(f[t], bottleneck=1) for t in range(len(f))])
+    assert rms(z, g["z"]) < 2e-5 and np.abs(z).max() <= 1.0
+    for tag in ("awgn", "mp"):
+        zh = oracle.channel_rs(g["z"], g[tag + "_H"], g[tag + "_noise"], float(g[tag + "_sigma"])).reshape(-1, 80)
+        assert np.abs(zh - g[tag + "_z_hat"]).max() < 1e-6
+        dec = oracle.Decoder(m)
+        fh = np.array([dec.step(g[tag + "_z_hat"][t]) for t in range(len(f))]).reshape(-1, 20)
+        assert rms(fh, g[tag + "_features_hat"]) < 2e-5
+        assert oracle.distortion_loss(g["features"], fh, 20) == pytest.approx(float(g[tag + "_loss"]), abs=1e-4)
