@@ -375,11 +375,60 @@ def gen_model05():
     print("model05 ok", {k: float(v) for k, v in out.items() if k.endswith("loss")})
 
 
+def gen_bbfm():
+    """Config 5: BBFM(20, 80, CNRdB) (bbfm.py:42-197).  No trained weights exist, so seeded random weights
+    (torch default init + orthogonal weight_hh, radae_base.py:72-77,136-147) are exported to a DNNw blob with
+    radae_amd.dnnw.write_blob, and the de-quantised blob is what both the reference modules and the engine load."""
+    from radae import BBFM
+    from radae_amd.channel_tools import doppler_spread
+    torch.manual_seed(20240501)
+    model = BBFM(20, 80, 20.0)
+    enc, dec = model.core_encoder.module, model.core_decoder.module
+    sd = lambda t: t.detach().numpy().astype(np.float32).copy()
+    mk_gru = lambda g: dnnw.GRU(sd(g.weight_ih_l0), sd(g.weight_hh_l0), sd(g.bias_ih_l0), sd(g.bias_hh_l0))
+    m = dnnw.Model(
+        enc_dense1=dnnw.Dense(sd(enc.dense_1.weight), sd(enc.dense_1.bias)),
+        enc_gru=[mk_gru(getattr(enc, f"gru{i}")) for i in range(1, 6)],
+        enc_conv=[dnnw.Conv(sd(getattr(enc, f"conv{i}").conv.weight), sd(getattr(enc, f"conv{i}").conv.bias), dnnw.ENC_DILATION[i - 1]) for i in range(1, 6)],
+        enc_zdense=dnnw.Dense(sd(enc.z_dense.weight), sd(enc.z_dense.bias)),
+        dec_dense1=dnnw.Dense(sd(dec.dense_1.weight), sd(dec.dense_1.bias)),
+        dec_gru=[mk_gru(getattr(dec, f"gru{i}")) for i in range(1, 6)],
+        dec_glu=[dnnw.Dense(sd(getattr(dec, f"glu{i}").gate.weight), np.zeros(96, np.float32)) for i in range(1, 6)],
+        dec_conv=[dnnw.Conv(sd(getattr(dec, f"conv{i}").conv.weight), sd(getattr(dec, f"conv{i}").conv.bias), 1) for i in range(1, 6)],
+        dec_output=dnnw.Dense(sd(dec.output.weight), sd(dec.output.bias)))
+    blob = os.path.join(REPO, "weights", "bbfm_random_seed20240501.bin")
+    dnnw.write_blob(m, blob)
+    mq = dnnw.load_model(blob)
+    T = 480
+    feat36 = synth_features(2100, T)
+    features = torch.tensor(feat36[None, :, :20])
+    nsym = T * 20
+    rng = np.random.default_rng(4)
+    Hray = np.abs(doppler_spread(50.0, 2000, nsym, rng)); Hray = (Hray / np.sqrt(np.mean(Hray ** 2))).astype(np.float32)
+    out = {}
+    for tag, CNRdB, Hn in (("awgn", 20.0, np.ones(nsym, np.float32)), ("ray", 14.0, Hray)):
+        model = BBFM(20, 80, CNRdB)
+        load_into(model, mq)
+        model.eval()
+        torch.manual_seed(88)
+        with torch.inference_mode():
+            o = model(features, torch.tensor(Hn.reshape(1, nsym, 1)))
+            z = model.core_encoder(features)
+        torch.manual_seed(88)
+        noise = torch.randn(1, nsym, 1).numpy().reshape(-1).astype(np.float32)
+        out.update({f"{tag}_H": Hn, f"{tag}_noise": noise, f"{tag}_CNRdB": np.float64(CNRdB), f"{tag}_z_hat": o["z_hat"].numpy()[0].astype(np.float32),
+                    f"{tag}_features_hat": o["features_hat"].numpy()[0].astype(np.float32), f"{tag}_sigma": o["sigma"].numpy().reshape(-1).astype(np.float32)})
+        out["z"] = z.numpy()[0].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "bbfm.npz"), features=feat36[:, :20].astype(np.float32), Gfm=np.float64(model.Gfm), **out)
+    print("bbfm ok Gfm", model.Gfm, "frac below FM threshold (ray):", float(np.mean(20 * np.log10(Hray) + 14.0 < 12)))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec", "model05"]
+    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec", "model05", "bbfm"]
     if "consts" in which: gen_consts()
     if "weights" in which: gen_weights_check()
     if "enc" in which: gen_enc_tx()
     if "chanrx" in which: gen_chan_rx()
     if "dec" in which: gen_dec_loss()
     if "model05" in which: gen_model05()
+    if "bbfm" in which: gen_bbfm()

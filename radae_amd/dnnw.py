@@ -171,3 +171,98 @@ def load_model(path: str) -> Model:
         dec_conv=[_conv(rec, f"dec_conv{i}", 1) for i in range(1, 6)],
         dec_output=Dense(*_dense_float(rec, "dec_output")),
     )
+
+
+# ---------------------------------------------------------------------------------------------------
+# Writer: fp32 Model -> DNNw blob, i.e. the forward direction of the reference's export
+# (export_rade_weights.py:54-172 + wexchange/c_export/common.py + src/write_rade_weights.c:51-74).
+# Used to give weight-less configurations (BBFM: no checkpoint exists) a deployable blob.
+# ---------------------------------------------------------------------------------------------------
+def _record(name: str, arr: np.ndarray) -> bytes:
+    if arr.dtype == np.float32:
+        typ = _TYPE_F32
+    elif arr.dtype == np.int32:
+        typ = _TYPE_I32
+    elif arr.dtype == np.int8:
+        typ = _TYPE_I8
+    else:
+        raise ValueError(arr.dtype)
+    payload = arr.tobytes()
+    block = (len(payload) + 63) // 64 * 64
+    hdr = struct.pack("<4siiii", b"DNNw", 0, typ, len(payload), block) + name.encode("ascii").ljust(44, b"\0")[:44]
+    return hdr + payload + b"\0" * (block - len(payload))
+
+
+def _scaling(w_io: np.ndarray) -> np.ndarray:
+    """common.py:180-194 on a (n_in, n_out) matrix."""
+    n_in = w_io.shape[0]
+    m_abs = np.max(np.abs(w_io), axis=0)
+    m_sum = np.max(np.abs(w_io[:n_in:2] + w_io[1:n_in:2]), axis=0)
+    return np.maximum(m_abs / 127, m_sum / 129)
+
+
+def _quant(w_io, scale):
+    q = np.round(w_io / scale).astype("int")
+    return np.clip(q, -128, 127)
+
+
+def _emit_dense_float(out, name, w_oi, b):
+    out.append(_record(name + "_weights_float", np.ascontiguousarray(w_oi.T, dtype=np.float32).ravel()))
+    out.append(_record(name + "_bias", b.astype(np.float32)))
+
+
+def _emit_int8(out, name, w_oi, b, sparse):
+    w_io = w_oi.T.astype(np.float64)
+    n_in, n_out = w_io.shape
+    assert n_in % 4 == 0 and n_out % 8 == 0
+    scale = _scaling(w_io)
+    scale = np.where(scale == 0, 1e-12, scale)
+    q = _quant(w_io, scale)
+    bias = np.zeros(n_out) if b is None else b.astype(np.float64)
+    if sparse:   # common.py:140-176, every non-zero 4x8 block kept, block stored output-major (8x4)
+        idx, blocks = [], []
+        for i in range(n_out // 8):
+            pos = len(idx); idx.append(-1); cnt = 0
+            for j in range(n_in // 4):
+                blk = w_io[j * 4:(j + 1) * 4, i * 8:(i + 1) * 8]
+                if np.sum(np.abs(blk)) > 1e-10:
+                    cnt += 1; idx.append(j * 4)
+                    blocks.append(q[j * 4:(j + 1) * 4, i * 8:(i + 1) * 8].T.reshape(-1))
+            idx[pos] = cnt
+        out.append(_record(name + "_weights_int8", np.concatenate(blocks).astype(np.int8)))
+        out.append(_record(name + "_weights_idx", np.array(idx, dtype=np.int32)))
+    else:        # common.py:59-69
+        qq = q.reshape(n_in // 4, 4, n_out // 8, 8).transpose(2, 0, 3, 1)
+        out.append(_record(name + "_weights_int8", np.ascontiguousarray(qq).astype(np.int8).ravel()))
+    out.append(_record(name + "_subias", (bias - np.sum(q * scale, axis=0)).astype(np.float32)))
+    out.append(_record(name + "_scale", (scale / 127).astype(np.float32)))
+    out.append(_record(name + "_bias", bias.astype(np.float32)))
+
+
+def _swap_gates(a):
+    n = a.shape[0] // 3
+    out = a.copy(); out[0:n] = a[n:2 * n]; out[n:2 * n] = a[0:n]
+    return out
+
+
+def write_blob(model: Model, path: str) -> None:
+    """Quantise (int8 + per-output scale, like the reference's exporter) and write a DNNw blob."""
+    out = []
+    _emit_dense_float(out, "enc_dense1", model.enc_dense1.w, model.enc_dense1.b)
+    _emit_dense_float(out, "enc_zdense", model.enc_zdense.w, model.enc_zdense.b)
+    for i, g in enumerate(model.enc_gru, 1):
+        _emit_int8(out, f"enc_gru{i}_input", _swap_gates(g.w_ih), _swap_gates(g.b_ih), sparse=True)
+        _emit_int8(out, f"enc_gru{i}_recurrent", _swap_gates(g.w_hh), _swap_gates(g.b_hh), sparse=False)
+    for i, c in enumerate(model.enc_conv, 1):
+        _emit_int8(out, f"enc_conv{i}", c.w.transpose(0, 2, 1).reshape(c.w.shape[0], -1), c.b, sparse=False)
+    _emit_dense_float(out, "dec_dense1", model.dec_dense1.w, model.dec_dense1.b)
+    for i, g in enumerate(model.dec_glu, 1):
+        _emit_int8(out, f"dec_glu{i}", g.w, None, sparse=False)
+    _emit_dense_float(out, "dec_output", model.dec_output.w, model.dec_output.b)
+    for i, g in enumerate(model.dec_gru, 1):
+        _emit_int8(out, f"dec_gru{i}_input", _swap_gates(g.w_ih), _swap_gates(g.b_ih), sparse=True)
+        _emit_int8(out, f"dec_gru{i}_recurrent", _swap_gates(g.w_hh), _swap_gates(g.b_hh), sparse=False)
+    for i, c in enumerate(model.dec_conv, 1):
+        _emit_int8(out, f"dec_conv{i}", c.w.transpose(0, 2, 1).reshape(c.w.shape[0], -1), c.b, sparse=False)
+    with open(path, "wb") as f:
+        f.write(b"".join(out))

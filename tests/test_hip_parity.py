@@ -332,3 +332,31 @@ def test_model05_rate_rs_config1(Engine, torch_dev, golden):
     parts = torch.cat([eng.decode(zt[:, a:b].contiguous(), 80, reset=(a == 0)) for a, b in ((0, 3), (3, 4), (4, T))], 1)
     assert rms(parts.cpu().numpy(), whole.cpu().numpy()) < 1e-5
     eng.close()
+
+
+def test_bbfm_config5(Engine, torch_dev, golden):
+    """BASELINE config 5 on the GPU: encoder (bottleneck 1) -> FM-demodulator SNR channel -> decoder."""
+    import os
+    import torch
+    from radae_amd.engine import DEFAULT_BLOB
+    g = golden("bbfm")
+    blob = os.path.join(os.path.dirname(DEFAULT_BLOB), "bbfm_random_seed20240501.bin")
+    T = g["features"].shape[0] // 4
+    eng = Engine(1, max_tx_mf=T // 3, blob=blob, flags=0x100)
+    z = eng.encode(torch.tensor(g["features"].reshape(1, T, 80), device=torch_dev))
+    assert rms(z.cpu().numpy()[0], g["z"]) < 1e-5
+    for tag in ("awgn", "ray"):
+        zh = eng.channel_symbol(torch.tensor(g["z"][None], device=torch_dev), "bbfm", float(g[tag + "_CNRdB"]), float(g["Gfm"]),
+                                H=torch.tensor(g[tag + "_H"][None], device=torch_dev), noise=torch.tensor(g[tag + "_noise"][None], device=torch_dev))
+        assert np.abs(zh.cpu().numpy()[0] - g[tag + "_z_hat"]).max() < 5e-6
+        fh = eng.decode(torch.tensor(g[tag + "_z_hat"][None], device=torch_dev), 80).cpu().numpy()[0].reshape(-1, 20)
+        assert rms(fh, g[tag + "_features_hat"]) < 1e-5
+    # on-chip noise: same statistics as the reference's sigma (bbfm.py:182-184), batch of 256 streams
+    eng.close()
+    B = 256
+    eng = Engine(B, max_tx_mf=T // 3, blob=blob, flags=0x100)
+    zz = torch.zeros((B, T, 80), device=torch_dev)
+    zh = eng.channel_symbol(zz, "bbfm", 20.0, float(g["Gfm"]), seed=7)
+    sig = 10 ** (-(20.0 + float(g["Gfm"])) / 20)
+    assert float(zh.std()) == pytest.approx(sig, rel=0.01) and abs(float(zh.mean())) < 1e-4
+    eng.close()

@@ -145,3 +145,29 @@ def test_channel_tools_are_deterministic_and_normalised():
     assert np.var(a[:, 0]) + np.var(a[:, 1]) == pytest.approx(1.0, rel=1e-3)       # hf_gain (multipath_samples.m:31)
     f = synth_features(5, 24)
     assert f.shape == (24, 36) and not f[:, 20:].any() and np.abs(f[:, 19]).max() <= 0.5
+
+
+def test_blob_writer_reproduces_the_reference_format(tmp_path, lib):
+    """dnnw.write_blob emits the record set / sizes of the reference's own blobs, and what it writes is read
+    back identically by the Python reader and by the engine's C reader."""
+    from radae_amd import dnnw, engine
+    ref_path = os.path.join(REPO, "weights", "model05.bin")
+    ref = dnnw.read_records(ref_path)
+    m = dnnw.load_model(ref_path)
+    out = str(tmp_path / "rt.bin")
+    dnnw.write_blob(m, out)
+    got = dnnw.read_records(out)
+    assert list(got) == list(ref)                                            # same records, same order
+    assert all(got[k].shape == ref[k].shape and got[k].dtype == ref[k].dtype for k in ref)
+    assert os.path.getsize(out) == os.path.getsize(ref_path)
+    for k in ("enc_dense1_weights_float", "dec_output_bias", "enc_gru3_input_weights_idx"):
+        assert np.array_equal(got[k], ref[k])
+    m2 = dnnw.load_model(out)                                                # re-quantisation error is within half a step
+    for a, b in ((m.enc_conv[2].w, m2.enc_conv[2].w), (m.dec_gru[1].w_ih, m2.dec_gru[1].w_ih), (m.dec_glu[4].w, m2.dec_glu[4].w)):
+        assert np.abs(a - b).max() <= 0.51 * np.abs(a).max() / 127
+    blob = open(out, "rb").read()
+    cm = Model()
+    lib.rd_model_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Model)]
+    assert lib.rd_model_parse(blob, len(blob), C.byref(cm)) == 0
+    w = np.ctypeslib.as_array(cm.dec_gru[1].w_ih, shape=(288 * 224,)).reshape(288, 224)
+    assert np.array_equal(w, m2.dec_gru[1].w_ih)

@@ -135,3 +135,21 @@ def test_model05_rate_rs_config1(oracle, golden):
         fh = np.array([dec.step(g[tag + "_z_hat"][t]) for t in range(len(f))]).reshape(-1, 20)
         assert rms(fh, g[tag + "_features_hat"]) < 2e-5
         assert oracle.distortion_loss(g["features"], fh, 20) == pytest.approx(float(g[tag + "_loss"]), abs=1e-4)
+
+
+def test_bbfm_config5(oracle, golden):
+    """BASELINE config 5: BBFM.forward (bbfm.py:157-197) with the seeded random-weight blob, oracle vs reference."""
+    import os
+    g = golden("bbfm")
+    m = oracle.Model(os.path.join(os.path.dirname(oracle.BLOB), "bbfm_random_seed20240501.bin"))
+    enc = oracle.Encoder(m)
+    f = g["features"].reshape(-1, 80)
+    z = np.array([enc.step(f[t], bottleneck=1) for t in range(len(f))])
+    assert rms(z, g["z"]) < 1e-5
+    Gfm = float(g["Gfm"])
+    for tag in ("awgn", "ray"):
+        zh = oracle.channel_bbfm(g["z"], g[tag + "_H"], g[tag + "_noise"], float(g[tag + "_CNRdB"]), Gfm).reshape(-1, 80)
+        assert np.abs(zh - g[tag + "_z_hat"]).max() < 2e-6 and np.abs(zh).max() <= 1.0
+        dec = oracle.Decoder(m)
+        fh = np.array([dec.step(g[tag + "_z_hat"][t]) for t in range(len(f))]).reshape(-1, 20)
+        assert rms(fh, g[tag + "_features_hat"]) < 1e-5
