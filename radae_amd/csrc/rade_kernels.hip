@@ -27,6 +27,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define PI_D 3.14159265358979323846
 
@@ -134,6 +135,12 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_gemm_splitk(rd_gemm_args a)
     const int r0 = blockIdx.x * 32;
     const int ntt = (a.N + 31) >> 5;
     const int nt0 = blockIdx.y * NT;
+    if (a.n_rows) {                              // decoder rounds: skip tiles whose rows all lie beyond their stream's count
+        const int rl = min(r0 + 31, rows - 1);
+        bool any = false;
+        for (int bb = r0 / a.T; bb <= rl / a.T; bb++) { const int tlo = max(r0 - bb * a.T, 0); any = any || (tlo < a.n_rows[bb]); }
+        if (!any) return;
+    }
     int r = r0 + (lane & 31);
     if (r >= rows) r = rows - 1;
     const int b = r / a.T, t = r - b * a.T;
@@ -591,6 +598,8 @@ extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out,
 #define PH_T0() do { } while (0)
 #define PH(i) do { } while (0)
 #endif
+
+
 #define NT_RX 512
 
 struct RxScalars {
@@ -613,28 +622,38 @@ struct RxShared {
     float2 sym[6][RD_NC];
     float2 rp[2][RD_NC];
     float bpf_h[RD_NTAP + 3];
-    float absd[96][RD_NFC + 1];           // check_pilots scratch |Dt| rows
+    union {
+        float absd[96][RD_NFC + 1];       // check_pilots scratch |Dt| rows
+        float2 dtr[2][80][16];            // refine(): complex64 Dt1 / Dt2 per (f, t)
+    };
+    double2 rtw[80], rrot[80];            // refine(): e^{-jw_f} and e^{-jw_f Nmf} per candidate frequency
     float rowsum1[RD_NMF], rowsum2[RD_NMF]; // sum_f |Dt1[t,f]|, |Dt2[t,f]|
     int rows48[48];
-    double redd[(NT_RX / 64 + 1) * 10 > NT_RX ? (NT_RX / 64 + 1) * 10 : NT_RX];   // block reductions (double)
-    float redf[NT_RX]; int redi[NT_RX]; int redj[NT_RX];
+    double redd[(NT_RX / 64 + 1) * 10];   // block reductions (double): per-wave partials + totals
+    float redf[16]; int redi[16]; int redj[16];   // arg-max reduction: slot 0 result, 1.. per-wave partials
 };
 
 // max reduction with lexicographic tie-break (smaller k0, then smaller k1 wins); result in sh->redf[0], redi[0], redj[0]
 __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
 {
-    const int tid = threadIdx.x;
-    sh->redf[tid] = v; sh->redi[tid] = k0; sh->redj[tid] = k1;
-    __syncthreads();
-    for (int w = NT_RX / 2; w > 0; w >>= 1) {
-        if (tid < w) {
-            const float ov = sh->redf[tid + w]; const int o0 = sh->redi[tid + w], o1 = sh->redj[tid + w];
-            const float mv = sh->redf[tid]; const int m0 = sh->redi[tid], m1 = sh->redj[tid];
-            const bool take = ov > mv || (ov == mv && (o0 < m0 || (o0 == m0 && o1 < m1)));
-            if (take) { sh->redf[tid] = ov; sh->redi[tid] = o0; sh->redj[tid] = o1; }
-        }
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(v, off); const int o0 = __shfl_xor(k0, off), o1 = __shfl_xor(k1, off);
+        if (ov > v || (ov == v && (o0 < k0 || (o0 == k0 && o1 < k1)))) { v = ov; k0 = o0; k1 = o1; }
     }
+    __syncthreads();                                   // previous readers of slot 0 are done
+    if (lane == 0) { sh->redf[1 + wave] = v; sh->redi[1 + wave] = k0; sh->redj[1 + wave] = k1; }
+    __syncthreads();
+    if (tid == 0) {
+        float bv = sh->redf[1]; int b0 = sh->redi[1], b1 = sh->redj[1];
+        for (int w = 1; w < NT_RX / 64; w++) {
+            const float ov = sh->redf[1 + w]; const int o0 = sh->redi[1 + w], o1 = sh->redj[1 + w];
+            if (ov > bv || (ov == bv && (o0 < b0 || (o0 == b0 && o1 < b1)))) { bv = ov; b0 = o0; b1 = o1; }
+        }
+        sh->redf[0] = bv; sh->redi[0] = b0; sh->redj[0] = b1;
+    }
+    __syncthreads();
 }
 
 // Pilot correlation on the matrix cores.  Dt[t,f] = sum_m conj(rx[t+m]) p_w[m,f] (dsp.py:207-208) is the real
@@ -656,12 +675,24 @@ __device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int tA_lane, 
     const float *pa = pwf + ((kl >> 1) * RD_NFC + 8 * nt + (i >> 1)) * 2 + comp;   // + s * (2*RD_NFC*2)
     const float *pbA = rxf + 2 * tA_lane + kl, *pbB = rxf + 2 * tB_lane + kl;         // + 4*s
     acc1 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc2 = acc1;
-#pragma unroll 8
-    for (int s = 0; s < 80; s++) {
-        const float a = pa[s * (4 * RD_NFC)] * sgn;
-        const float b1 = pbA[4 * s], b2 = pbB[4 * s];
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b2, acc2, 0, 0, 0);
+    // 10 blocks of 8 k-steps; the next block's operands are fetched from LDS while this block's 16 MFMAs issue
+    float ca[8], cb1[8], cb2[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { ca[u] = pa[u * (4 * RD_NFC)]; cb1[u] = pbA[4 * u]; cb2[u] = pbB[4 * u]; }
+#pragma unroll 1
+    for (int blk = 0; blk < 10; blk++) {
+        float na[8], nb1[8], nb2[8];
+        const int sn = blk < 9 ? (blk + 1) * 8 : 0;            // last block re-reads block 0 (harmless) to stay branch-free
+#pragma unroll
+        for (int u = 0; u < 8; u++) { na[u] = pa[(sn + u) * (4 * RD_NFC)]; nb1[u] = pbA[4 * (sn + u)]; nb2[u] = pbB[4 * (sn + u)]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float a = ca[u] * sgn;
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb1[u], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb2[u], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { ca[u] = na[u]; cb1[u] = nb1[u]; cb2[u] = nb2[u]; }
     }
 }
 
@@ -701,38 +732,76 @@ __device__ float sigma_r_from_rowsums(RxShared *sh)
     return sigma_r_from_sums(v[0], v[1]);
 }
 
-// refine(): fine timing/frequency search maximising |Dt1+Dt2| (dsp.py:233-270); complex128 dots rounded to complex64
-__device__ void rx_refine(RxShared *sh, const rd_tables *tab, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep)
+// refine(): fine timing/frequency search maximising |Dt1+Dt2| (dsp.py:233-270).  NumPy evaluates the dot products in
+// complex128 and stores them as complex64, so this runs on the f64 matrix cores (v_mfma_f64_16x16x4_f64):
+//   C[(f,c'), t] = sum_{(n,c)} Q[(f,c'),(n,c)] X[(n,c), t],   Q = realified e^{-jw_f n} conj(p[n]),  X = rx[t+n] (re | im)
+// one 16x16 tile per (8 frequencies, modem frame); the Q fragment is generated in registers by a rotation recurrence.
+__device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nf = (int)ceil((fstop - fstart) / fstep);                 // np.arange length
     const double delta = (fstart + fstep) - fstart;                       // np.arange fill rule
+    const int ntasks = ((2 * nf + 15) >> 4) * 2;
+    const int i = lane & 15, kk = lane >> 4;
+    const float *rxf = (const float *)&sh->rxb[0];
+    PH_T0();
+    if (tid < nf) {                                                       // one sincos pair per candidate frequency
+        const double w = 2.0 * PI_D * (fstart + tid * delta) / 8000.0;
+        double sn, cs; sincos(-w, &sn, &cs); sh->rtw[tid] = make_double2(cs, sn);
+        sincos(-w * RD_NMF, &sn, &cs); sh->rrot[tid] = make_double2(cs, sn);
+    }
+    __syncthreads();
+    PH(12);
+    for (int task = wave; task < ntasks; task += NT_RX / 64) {
+        const int mt = task >> 1, frame = task & 1;
+        const int row = 16 * mt + i, fi = row >> 1, cp = row & 1;
+        const bool rv = fi < nf;
+        const int c = kk & 1, n0 = kk >> 1;                               // this lane feeds k = (n = 2s + n0, c)
+        const double2 z1 = sh->rtw[rv ? fi : 0];                          // e^{-jw}
+        double zc = n0 ? z1.x : 1.0, zs = n0 ? z1.y : 0.0;                // z = e^{-jw n0}
+        const double rc = z1.x * z1.x - z1.y * z1.y, rs = 2.0 * z1.x * z1.y;   // e^{-2jw}: two samples per MFMA step
+        const float *xb = rxf + 2 * (t0 + (i < nt ? i : 0) + frame * RD_NMF + n0) + c;
+        f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll 4
+        for (int s = 0; s < 80; s++) {
+            const double2 pp = sh->pd[2 * s + n0];
+            const double qr = zc * pp.x + zs * pp.y, qi = zs * pp.x - zc * pp.y;      // e^{-jwn} conj(p[n])
+            double av = cp == 0 ? (c == 0 ? qr : -qi) : (c == 0 ? qi : qr);
+            av = rv ? av : 0.0;
+            const double bv = (double)xb[4 * s];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            const double nz = zc * rc - zs * rs; zs = zc * rs + zs * rc; zc = nz;
+        }
+        // C layout (f64 16x16x4): col = lane&15 (t), row = (lane>>4) + 4*reg.  Rows alternate re/im, so the lane 16
+        // positions away holds the other component of the same (f, t).
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double mine = acc[r], other = __shfl_xor(mine, 16);
+            if ((kk & 1) == 0) {
+                const int fo = 8 * mt + (kk >> 1) + 2 * r;
+                double re = mine, im = other;
+                if (frame == 1 && fo < nf) {                              // w_vec2 = w_vec1 * exp(-1j*w*Nmf)
+                    const double2 rt = sh->rrot[fo];
+                    const double tr = re * rt.x - im * rt.y; im = re * rt.y + im * rt.x; re = tr;
+                }
+                if (fo < nf && i < nt) sh->dtr[frame][fo][i] = make_float2((float)re, (float)im);
+            }
+        }
+    }
+    __syncthreads();
+    PH(13);
     float best = -1.0f; int bf = 0x7fffffff, bt = 0x7fffffff;
     for (int task = tid; task < nf * nt; task += NT_RX) {
         const int fi = task / nt, ti = task - fi * nt;
-        const double f = fstart + fi * delta;
-        const double w = 2.0 * PI_D * f / 8000.0;
-        const int t = t0 + ti;
-        double sr, cr; sincos(-w, &sr, &cr);                                // per-sample rotation e^{-jw}
-        double zr = 1.0, zi = 0.0, ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-#pragma unroll 4
-        for (int n = 0; n < RD_M; n++) {
-            const double2 pp = sh->pd[n];
-            const double qr = zr * pp.x + zi * pp.y, qi = zi * pp.x - zr * pp.y;   // w_vec1 * conj(p)
-            const float2 x = sh->rxb[t + n], y = sh->rxb[t + RD_NMF + n];
-            ar += (double)x.x * qr - (double)x.y * qi; ai += (double)x.x * qi + (double)x.y * qr;
-            br += (double)y.x * qr - (double)y.y * qi; bi += (double)y.x * qi + (double)y.y * qr;
-            const double nzr = zr * cr - zi * sr; zi = zr * sr + zi * cr; zr = nzr;
-        }
-        double s2, c2; sincos(-w * RD_NMF, &s2, &c2);                       // w_vec2 = w_vec1*exp(-1j*w*Nmf)
-        const double b2r = br * c2 - bi * s2, b2i = br * s2 + bi * c2;
-        const float vr = (float)ar + (float)b2r, vi = (float)ai + (float)b2i;   // complex64 Dt1 + Dt2
-        const float v = hypotf(vr, vi);
+        const float2 a = sh->dtr[0][fi][ti], b = sh->dtr[1][fi][ti];
+        const float v = hypotf(a.x + b.x, a.y + b.y);                     // |Dt1 + Dt2| in complex64
         if (v > best || (v == best && (fi < bf || (fi == bf && ti < bt)))) { best = v; bf = fi; bt = ti; }
     }
+    PH(14);
     block_argmax(sh, best, bf, bt);
     if (sh->redf[0] > 0.0f) { *tmax = t0 + sh->redj[0]; *fmax = fstart + sh->redi[0] * delta; }
     __syncthreads();
+    PH(15);
 }
 
 // one term of dot(conj(w_vec*rx[t0..]), ref) in complex128 (dsp.py:307-313); thread n < 160 owns sample n
@@ -748,6 +817,8 @@ __device__ __forceinline__ void rx_corr_term(const RxShared *sh, int t0, double 
 // Scalar receiver state lives in LDS (sh->S): thread 0 is the only writer, everybody reads it after a
 // barrier.  (Keeping ~40 loop-carried "uniform" scalars in every thread's registers cost 256 VGPRs
 // and proved fragile under -O3.)
+static_assert(sizeof(RxShared) <= 160 * 1024, "k_rx_sync working set must fit the 160 KiB LDS of a CU");
+
 __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -921,7 +992,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 const int tm = S->tmax; const double fm = S->fmax;
                 const int t0 = max(0, tm - 8);
                 int tnew = tm; double fhat = fm;
-                rx_refine(sh, tab, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1);
+                rx_refine(sh, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1);
                 if (tid == 0) { S->tmax = tnew; S->fmax = 0.9 * fm + 0.1 * fhat; }
             }
             PH(4);
@@ -1085,7 +1156,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const int tm = S->tmax; const double fm = S->fmax;
             const int t0 = max(0, tm - 1);
             int tnew = tm; double fnew = fm;
-            rx_refine(sh, tab, &tnew, &fnew, t0, tm + 2 - t0, fm - 10.0, fm + 10.0, 0.25);
+            rx_refine(sh, &tnew, &fnew, t0, tm + 2 - t0, fm - 10.0, fm + 10.0, 0.25);
             if (tid == 0) { S->tmax = tnew; S->fmax = fnew + S->foff_err; S->foff_err = 0.0; }
             __syncthreads();
         }

@@ -11,9 +11,13 @@ iq = eng.tx(feats)
 rx = eng.channel(iq, sigma_from_EbNodB(3.0), -11.0, n_pre=8000, n_post=1152, with_eoo=True, seed=5)
 lib = load_library(); lib.rd_debug_phase_cycles.argtypes = [C.c_void_p]
 buf = (C.c_longlong * 16)(); lib.rd_debug_phase_cycles(buf)
+eng.profile(True)
 fo, st, _ = eng.rx(rx); torch.cuda.synchronize()
+eng.profile(False); pr = eng.profile_get()['rx_sync']
 lib.rd_debug_phase_cycles(buf)
-names = ["load", "bpf+shift", "detect corr", "detect reduce", "refine", "check rows", "sigma+corr+slip", "freqcorr", "demod dft", "eq", "statemachine", "store"]
+names = ["load", "bpf+shift", "detect corr", "detect reduce", "refine", "check rows", "sigma+corr+slip", "freqcorr", "demod dft", "eq", "statemachine", "store", " refine:tables", " refine:mfma", " refine:scan", " refine:argmax"]
 tot = sum(buf[:12])
-print("stream0 calls", st[0].n_calls, "valid", st[0].n_valid)
+print("stream0 calls", st[0].n_calls, "valid", st[0].n_valid, "rx_sync kernel ms", pr["ms"], "launches", pr["launches"])
 for i, n in enumerate(names): print(f"{n:18s} {buf[i]:12d} cyc  {100*buf[i]/tot:5.1f}%  {buf[i]/100e6*1e3:8.3f} ms (100MHz clk?)")
+
+print("total cycles block0", tot, "=> if block0 were busy the whole time: clock >=", tot/ (pr["ms"]*1e-3)/1e9, "GHz")
