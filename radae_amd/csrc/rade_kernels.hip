@@ -229,70 +229,80 @@ extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
 }
 
 // =====================================================================================================
-// GRU recurrence.  Thread o < 3H owns row o of W_hh in registers; h lives in LDS and is broadcast.
+// GRU recurrence (the only serial part of a layer): h_t = f(gi_t, W_hh h_{t-1}), one workgroup per stream.
+// Four adjacent lanes own hidden unit j; lane part p holds the r/z/n rows of W_hh for k in [p*H/4, (p+1)*H/4)
+// in VGPRs, partial dot products meet through quad shuffles, every lane of the quad evaluates the gates
+// (no divergence) and part 0 publishes h_j to LDS: one barrier per time step.
 // =====================================================================================================
 template <int H>
-__global__ __launch_bounds__(((3 * H + 63) / 64) * 64) void k_gru_scan(rd_scan_args a)
+__global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
 {
-    __shared__ __attribute__((aligned(16))) float hs[H];
-    __shared__ float gh[3 * H];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const bool active = tid < 3 * H;
-    float w[H];
-    float bias = 0.0f;
-    if (active) {
-        const float *wr = a.Whh + (size_t)tid * H;
+    constexpr int KP = H / 4;                       // k range per lane
+    __shared__ __attribute__((aligned(16))) float hs[2][H];   // double-buffered so one barrier per step suffices
+    __shared__ int rst[64];                         // reset flags are only used by the decoder rounds (T <= 64)
+    const int b = blockIdx.x, tid = threadIdx.x, j = tid >> 2, p = tid & 3;
+    float wr[KP], wz[KP], wn[KP];
+    {
+        const float *w0 = a.Whh + (size_t)j * H + p * KP;
 #pragma unroll
-        for (int k = 0; k < H; k += 4) { f32x4 v = *(const f32x4 *)(wr + k); w[k] = v[0]; w[k + 1] = v[1]; w[k + 2] = v[2]; w[k + 3] = v[3]; }
-        bias = a.bhh[tid];
+        for (int k = 0; k < KP; k += 4) {
+            const f32x4 v0 = *(const f32x4 *)(w0 + k), v1 = *(const f32x4 *)(w0 + (size_t)H * H + k), v2 = *(const f32x4 *)(w0 + (size_t)2 * H * H + k);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { wr[k + u] = v0[u]; wz[k + u] = v1[u]; wn[k + u] = v2[u]; }
+        }
     }
+    const float br = a.bhh[j], bz = a.bhh[H + j], bn = a.bhh[2 * H + j];
     const int Tb = a.n_rows ? a.n_rows[b] : a.T;
-    __shared__ int rst[64];                      // reset flags are only used by the decoder rounds (T <= 64)
     if (a.reset && tid < 64) rst[tid] = tid < a.T ? a.reset[b * a.T + tid] : 0;
-    if (tid < H) hs[tid] = a.h[(size_t)b * H + tid];
-    const float *gi = a.gi + (size_t)b * a.gi_sb;
-    float g_r = 0, g_z = 0, g_n = 0, q_r = 0, q_z = 0, q_n = 0;     // gi of step t and t+1 (prefetched)
-    if (tid < H && Tb > 0) { g_r = gi[tid]; g_z = gi[H + tid]; g_n = gi[2 * H + tid]; }
-    if (tid < H && Tb > 1) { const float *g = gi + a.gi_st; q_r = g[tid]; q_z = g[H + tid]; q_n = g[2 * H + tid]; }
+    float hj = a.h[(size_t)b * H + j];
+    if (p == 0) hs[0][j] = hj;
+    const float *gi = a.gi + (size_t)b * a.gi_sb + (p < 3 ? p * H + j : j);   // lane part p < 3 fetches gate p of unit j
+    float g0 = 0.0f, g1 = 0.0f;                      // gi of step t and t+1 (prefetched)
+    if (Tb > 0) g0 = gi[0];
+    if (Tb > 1) g1 = gi[a.gi_st];
     __syncthreads();
+    int cur = 0;
     for (int t = 0; t < Tb; t++) {
         if (a.reset && rst[t]) {                       // uniform over the workgroup
+            hj = 0.0f;
             __syncthreads();
-            if (tid < H) hs[tid] = 0.0f;
+            if (p == 0) hs[cur][j] = 0.0f;
             __syncthreads();
         }
-        float n_r = 0, n_z = 0, n_n = 0;
-        if (tid < H && t + 2 < Tb) { const float *g = gi + (size_t)(t + 2) * a.gi_st; n_r = g[tid]; n_z = g[H + tid]; n_n = g[2 * H + tid]; }
-        if (active) {
-            float s0 = bias, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        float g2 = 0.0f;
+        if (t + 2 < Tb) g2 = gi[(size_t)(t + 2) * a.gi_st];
+        float sr = 0.0f, sz = 0.0f, sn = 0.0f;
+        const float *hp = hs[cur] + p * KP;
 #pragma unroll
-            for (int k = 0; k < H; k += 4) {
-                f32x4 hv = *(const f32x4 *)(hs + k);
-                s0 += w[k] * hv[0]; s1 += w[k + 1] * hv[1]; s2 += w[k + 2] * hv[2]; s3 += w[k + 3] * hv[3];
-            }
-            gh[tid] = (s0 + s1) + (s2 + s3);
+        for (int k = 0; k < KP; k += 4) {
+            const f32x4 hv = *(const f32x4 *)(hp + k);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { sr += wr[k + u] * hv[u]; sz += wz[k + u] * hv[u]; sn += wn[k + u] * hv[u]; }
         }
-        __syncthreads();
-        if (tid < H) {
-            const float r = sigmoid_f(gh[tid] + g_r);
-            const float z = sigmoid_f(gh[H + tid] + g_z);
-            const float n = tanhf(g_n + gh[2 * H + tid] * r);
-            const float hn = (hs[tid] - n) * z + n;
-            a.out[(size_t)b * a.out_sb + (size_t)t * a.out_st + tid] = clamp1(hn);
-            hs[tid] = hn;
-            g_r = q_r; g_z = q_z; g_n = q_n; q_r = n_r; q_z = n_z; q_n = n_n;
+        sr += __shfl_xor(sr, 1); sz += __shfl_xor(sz, 1); sn += __shfl_xor(sn, 1);
+        sr += __shfl_xor(sr, 2); sz += __shfl_xor(sz, 2); sn += __shfl_xor(sn, 2);
+        const float gr = __shfl(g0, (tid & 60) + 0), gz = __shfl(g0, (tid & 60) + 1), gn = __shfl(g0, (tid & 60) + 2);
+        const float r = sigmoid_f((sr + br) + gr);
+        const float z = sigmoid_f((sz + bz) + gz);
+        const float n = tanhf(gn + (sn + bn) * r);
+        hj = (hj - n) * z + n;
+        if (p == 0) {
+            hs[cur ^ 1][j] = hj;
+            a.out[(size_t)b * a.out_sb + (size_t)t * a.out_st + j] = clamp1(hj);
         }
+        g0 = g1; g1 = g2;
+        cur ^= 1;
         __syncthreads();
     }
-    if (tid < H) a.h[(size_t)b * H + tid] = hs[tid];
+    if (p == 0) a.h[(size_t)b * H + j] = hj;
 }
 
 extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
 {
     if (a->B <= 0) return 0;
     hipStream_t st = (hipStream_t)s;
-    if (a->H == 64) hipLaunchKernelGGL(k_gru_scan<64>, dim3(a->B), dim3(192), 0, st, *a);
-    else if (a->H == 96) hipLaunchKernelGGL(k_gru_scan<96>, dim3(a->B), dim3(320), 0, st, *a);
+    if (a->H == 64) hipLaunchKernelGGL(k_gru_scan<64>, dim3(a->B), dim3(256), 0, st, *a);
+    else if (a->H == 96) hipLaunchKernelGGL(k_gru_scan<96>, dim3(a->B), dim3(384), 0, st, *a);
     else return -1;
     return (int)hipGetLastError();
 }
