@@ -130,8 +130,15 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms"])
         p = prof[dom]
         achieved = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        # HBM bytes per launch come from the separate rocprofv3 --pmc passes of this same command (profiles/r01_pmc_summary.json)
+        traffic, mfma_busy = None, None
+        try:
+            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))["kernels"][{"rx_sync": "k_rx_sync", "gemm": "k_gemm<3>", "gru_scan": "k_gru_scan<64>"}.get(dom, dom)]
+            traffic = pm["fetch_bytes_per_dispatch"] + pm["write_bytes_per_dispatch"]; mfma_busy = pm["mfma_busy_pct"]
+        except Exception:
+            pass
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
-                           "traffic": None, "avg_launch_ms": p["ms"] / max(p["launches"], 1), "launches_per_step": p["launches"],
+                           "traffic": traffic, "mfma_busy_pct_pmc": mfma_busy, "avg_launch_ms": p["ms"] / max(p["launches"], 1), "launches_per_step": p["launches"],
                            "note": "f32: matrix (MFMA) and vector FMA peaks are both 157.3 TFLOP/s on gfx950",
                            "per_class_ms": {k: round(v["ms"], 3) for k, v in prof.items()},
                            "hbm_frac_whole_job": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9)}
