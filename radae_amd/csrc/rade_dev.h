@@ -32,8 +32,9 @@ extern "C" {
 #define RD_ENC_W    864   /* encoder concat width */
 #define RD_DEC_W    736
 #define RD_ENC_IN   88    /* 84 padded to a multiple of 8 */
-#define RD_RX_ROUND 8     /* max do_radae_rx calls per stream per sync-kernel launch */
-#define RD_DEC_ROWS 24    /* = 3 * RD_RX_ROUND decoder steps per round */
+#define RD_RX_ROUND_MAX 128   /* capacity: do_radae_rx calls per stream per sync-kernel launch (engine picks R <= this) */
+#define RD_DEC_ROWS_MAX (3 * RD_RX_ROUND_MAX)
+#define RD_CHK_MAX 16          /* speculated UW checks per round (one per 8 synchronised frames) */
 
 /* constant tables, one copy in HBM (filled by rade_tables.c) */
 typedef struct {
@@ -73,11 +74,15 @@ typedef struct {
     int n_rows;                         /* decoder steps emitted (3 per valid call) */
     int uw_from_row;                    /* aux-bit errors count from this row on (sync entry resets) */
     int consumed;                       /* samples consumed this round */
-    int row_reset[RD_DEC_ROWS];         /* 1: decoder state is reset before this step */
-    int call_ret[RD_RX_ROUND];          /* bit0 valid bit1 eoo */
-    int call_row_lo[RD_RX_ROUND], call_row_hi[RD_RX_ROUND]; /* trace patching of uw_errors */
-    int call_trace_idx[RD_RX_ROUND];
-    int blocked;                        /* stopped because a UW decision waits for the decoder */
+    int row_reset[RD_DEC_ROWS_MAX];     /* 1: decoder state is reset before this step */
+    int call_ret[RD_RX_ROUND_MAX];      /* bit0 valid bit1 eoo */
+    int call_row_lo[RD_RX_ROUND_MAX], call_row_hi[RD_RX_ROUND_MAX]; /* trace patching of uw_errors */
+    int call_trace_idx[RD_RX_ROUND_MAX];
+    /* UW checks passed speculatively (their frames were not decoded yet): verified by k_rx_post, which rolls the
+     * stream back to snapshot k when window k really had more than 7 aux-bit errors (radae_rxe.py:220-224) */
+    int n_chk, chk_call[RD_CHK_MAX], chk_from[RD_CHK_MAX], chk_row[RD_CHK_MAX], chk_base[RD_CHK_MAX];
+    int chk_acc[RD_CHK_MAX][8];         /* post-call consumed, calls, valid, eoo, n_rows, n_calls, has_eoo, uw_errors-of-check-frame placeholder */
+    int blocked;                        /* unused */
     int out_base;                       /* valid frames this invocation before this round (features_out slot) */
     int pad[2];
 } rd_rx_round;
@@ -95,12 +100,12 @@ typedef void *rd_stream_t;
 
 /* Y[r, n] = act(sum_k A[r,k] W[n,k] + bias[n]) on f32 MFMA; rows r = b*T + t.
  * A row (b,t) = [tap0 | tap1]: tap1 at a1 + b*a1_sb + t*a1_st (K1 floats), tap0 (K0 floats, may be 0)
- * at a0 + b*a0_sb + t*a0_st, or the zero row when reset[b*T+t] != 0.  Wp = packed weights
+ * at a0 + b*a0_sb + t*a0_st, or the zero row when reset[b*reset_sb+t] != 0.  Wp = packed weights
  * (rd_pack_weights).  act: 0 none, 1 tanh+clamp, 2 GLU (y = a1[r][n] * sigmoid(acc), clamp). */
 typedef struct {
     const float *a1; long a1_sb, a1_st; int K1;
     const float *a0; long a0_sb, a0_st; int K0;
-    const int *reset;                  /* optional [B*T] */
+    const int *reset; int reset_sb;    /* optional [B][reset_sb] (reset_sb >= T) */
     const int *n_rows;                 /* optional [B]: rows t >= n_rows[b] are skipped */
     const float *Wp; const float *bias;
     float *y; long y_sb, y_st; int N;  /* N valid outputs (<= 32*NT) */
@@ -118,7 +123,7 @@ typedef struct {
     const float *Whh; const float *bhh;   /* [3H][H], [3H], torch gate order r,z,n */
     float *h;                             /* [B][H] */
     float *out; long out_sb, out_st;
-    const int *reset;                     /* optional [B*T]: zero h before step */
+    const int *reset; int reset_sb;       /* optional [B][reset_sb]: zero h before step */
     const int *n_rows;                    /* optional [B] */
     int B, T, H;
 } rd_scan_args;
@@ -148,9 +153,10 @@ typedef struct {
     const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
     int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
     int max_calls;                                       /* call budget per stream per invocation */
-    int unit_budget;                                     /* work units per round (sync call 1, detect 2 or 4) */
-    float *zrows;                                        /* [B][RD_DEC_ROWS][80] */
-    int *n_rows; int *row_reset;                         /* flat [B], [B][RD_DEC_ROWS] copies for the decoder kernels */
+    int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
+    rd_rx_stream *snap;                                  /* [B][RD_CHK_MAX] rollback snapshots */
+    float *zrows;                                        /* [B][dec_rows][80] */
+    int *n_rows; int *row_reset;                         /* flat [B], [B][dec_rows] copies for the decoder kernels */
     float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */
     int *status;                                         /* [B][4]: nin, sync, snr_int, state */
     float *eoo_out;                                      /* [B][180] or NULL */
@@ -163,7 +169,8 @@ int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
 int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
 
 typedef struct {
-    rd_rx_stream *st; rd_rx_round *round; const float *feat84;   /* [B][RD_DEC_ROWS][84] */
+    rd_rx_stream *st; rd_rx_round *round; const float *feat84;   /* [B][dec_rows][84] */
+    rd_rx_stream *snap; int *acc; int *n_rows; int *progress; int *status; int dec_rows;
     float *features_out; long feat_stride; rd_rx_trace *trace; int trace_cap;
     int B;
 } rd_post_args;

@@ -27,6 +27,8 @@ typedef struct { float *wp, *bias; int N, K; } dev_lin;
 
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
+    int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
+    rd_rx_stream *rx_snap;
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -93,8 +95,8 @@ static void rx_reset_on(rade_batch *h, void *stream)
     hipStream_t st = (hipStream_t)stream;
     rd_launch_rx_reset(h->rx_st, h->d_lcg_seeds, (h->flags & RADE_FOFF_TEST) ? 10.0 : 0.0 /* rade_api.c:263-264 */, h->B, st);
     for (int l = 0; l < 5; l++) hipMemsetAsync(h->dec_h[l], 0, sizeof(float) * h->B * 96, st);
-    hipMemsetAsync(h->dec_x, 0, sizeof(float) * (size_t)h->B * (1 + RD_DEC_ROWS) * RD_DEC_W, st);
-    hipMemsetAsync(h->rx_rowreset, 0, sizeof(int) * h->B * RD_DEC_ROWS, st);
+    hipMemsetAsync(h->dec_x, 0, sizeof(float) * (size_t)h->B * (1 + h->dec_rows) * RD_DEC_W, st);
+    hipMemsetAsync(h->rx_rowreset, 0, sizeof(int) * h->B * h->dec_rows, st);
     if (h->trace) { hipMemsetAsync(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap, st); hipMemsetAsync(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF, st); }
 }
 static void tx_reset_on(rade_batch *h, void *stream)
@@ -135,6 +137,12 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->B = cfg->n_streams; h->max_tx_mf = cfg->max_tx_mf; h->device = cfg->device; h->flags = cfg->flags;
     h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
     const size_t B = (size_t)h->B, T = (size_t)h->Tcap;
+    /* up to a whole utterance per sync launch (RADE_ROUND_CALLS=1 decodes after every call: no speculated UW checks) */
+    h->R = getenv("RADE_ROUND_CALLS") ? atoi(getenv("RADE_ROUND_CALLS")) : 24;
+    if (h->R < 1) h->R = 1;
+    if (h->R > RD_RX_ROUND_MAX) h->R = RD_RX_ROUND_MAX;
+    h->dec_rows = 3 * h->R;
+    const size_t DR = (size_t)h->dec_rows;
 
     rd_tables *tab = malloc(sizeof *tab);
     rd_tables_fill(tab);
@@ -173,12 +181,14 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->rx_st = dev_zeros(sizeof(rd_rx_stream) * B);
     h->rx_round = dev_zeros(sizeof(rd_rx_round) * B);
     h->rx_avail = dev_zeros(sizeof(int) * B); h->rx_acc = dev_zeros(sizeof(int) * B * 4); h->rx_progress = dev_zeros(sizeof(int) * 4);
-    h->rx_nrows = dev_zeros(sizeof(int) * B); h->rx_rowreset = dev_zeros(sizeof(int) * B * RD_DEC_ROWS); h->rx_status = dev_zeros(sizeof(int) * B * 4);
-    h->zrows = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * RD_LATENT);
-    h->dec_x = dev_zeros(sizeof(float) * B * (1 + RD_DEC_ROWS) * RD_DEC_W);
-    h->dec_gi = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 288);
-    h->dec_hbuf = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 96);
-    h->feat84 = dev_zeros(sizeof(float) * B * RD_DEC_ROWS * 84);
+    h->rx_nrows = dev_zeros(sizeof(int) * B); h->rx_rowreset = dev_zeros(sizeof(int) * B * DR); h->rx_status = dev_zeros(sizeof(int) * B * 4);
+    h->zrows = dev_zeros(sizeof(float) * B * DR * RD_LATENT);
+    h->dec_x = dev_zeros(sizeof(float) * B * (1 + DR) * RD_DEC_W);
+    h->dec_gi = dev_zeros(sizeof(float) * B * DR * 288);
+    h->dec_hbuf = dev_zeros(sizeof(float) * B * DR * 96);
+    h->feat84 = dev_zeros(sizeof(float) * B * DR * 84);
+    h->rx_snap = dev_zeros(sizeof(rd_rx_stream) * B * RD_CHK_MAX);
+    if (!h->rx_snap) goto fail;
     h->dec2_x = dev_zeros(sizeof(float) * B * (1 + T) * RD_DEC_W);
     h->dec2_gi = dev_zeros(sizeof(float) * B * T * 288);
     h->dec2_hbuf = dev_zeros(sizeof(float) * B * T * 96);
@@ -229,7 +239,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf };
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_snap };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -270,7 +280,7 @@ static int gemm(rade_batch *hh, const dev_lin *w, const float *a1, long a1_sb, l
     rd_gemm_args g;
     memset(&g, 0, sizeof g);
     g.a1 = a1; g.a1_sb = a1_sb; g.a1_st = a1_st; g.K1 = K1; g.a0 = a0; g.a0_sb = a0_sb; g.a0_st = a0_st; g.K0 = K0;
-    g.reset = reset; g.n_rows = n_rows; g.Wp = w->wp; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
+    g.reset = reset; g.reset_sb = hh->dec_rows; g.n_rows = n_rows; g.Wp = w->wp; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
     if (K0 + K1 != w->K) { fprintf(stderr, "rade: internal GEMM shape error (%d+%d != %d)\n", K0, K1, w->K); return -1; }
     PROF_BEGIN(hh, stream);
     const int rc = rd_launch_gemm(&g, stream);
@@ -289,7 +299,7 @@ static int encode_core(rade_batch *h, int T, float *z, void *stream)
     for (int l = 0; l < 5 && !e; l++) {
         const int in = ENC_IN[l];
         e |= gemm(h, &h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, h->enc_gi, (long)T * 192, 192, B, T, 0, stream);
-        rd_scan_args s = { h->enc_gi, (long)T * 192, 192, h->enc_whh[l], h->enc_bhh[l], h->enc_h[l], x + in, xsb, W, NULL, NULL, B, T, 64 };
+        rd_scan_args s = { h->enc_gi, (long)T * 192, 192, h->enc_whh[l], h->enc_bhh[l], h->enc_h[l], x + in, xsb, W, NULL, 0, NULL, B, T, 64 };
         PROF_BEGIN(h, stream); e |= rd_launch_gru_scan(&s, stream); PROF_END(h, stream, RADE_PROF_SCAN, 2.0 * B * T * 192 * 64);
         const int cin = in + 64;
         e |= gemm(h, &h->enc_conv[l], x, xsb, W, cin, x - (long)ENC_DIL[l] * W, xsb, W, cin, NULL, NULL, x + cin, xsb, W, B, T, 1, stream);
@@ -357,30 +367,30 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
 /* ---- receive ----------------------------------------------------------------------------------- */
 /* CoreDecoderStatefull.forward (radae_base.py:400-416) over T time slots of every stream.  x = [B][1+Tcap][736]
  * (slot 0 = conv history), rows beyond n_rows[b] are skipped, rst flags zero the state before a step. */
-static int decoder_layers(rade_batch *h, const float *z, int T, int Tcap, float *xbuf, float *gi, float *hbuf, float **hstate,
+static int decoder_layers(rade_batch *h, const float *z, int T, int Tio, int Tcap, float *xbuf, float *gi, float *hbuf, float **hstate,
                           const int *nr, const int *rst, float *out, void *stream)
 {
     const int B = h->B, W = RD_DEC_W;
     const long xsb = (long)(1 + Tcap) * W;
     float *x = xbuf + W;
     int e = 0;
-    e |= gemm(h, &h->dec_dense1, z, (long)T * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
+    e |= gemm(h, &h->dec_dense1, z, (long)Tio * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = DEC_IN[l];
         e |= gemm(h, &h->dec_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, nr, gi, (long)T * 288, 288, B, T, 0, stream);
-        rd_scan_args s = { gi, (long)T * 288, 288, h->dec_whh[l], h->dec_bhh[l], hstate[l], hbuf, (long)T * 96, 96, rst, nr, B, T, 96 };
+        rd_scan_args s = { gi, (long)T * 288, 288, h->dec_whh[l], h->dec_bhh[l], hstate[l], hbuf, (long)T * 96, 96, rst, h->dec_rows, nr, B, T, 96 };
         PROF_BEGIN(h, stream); e |= rd_launch_gru_scan(&s, stream); PROF_END(h, stream, RADE_PROF_SCAN, 2.0 * B * T * 288 * 96);
         e |= gemm(h, &h->dec_glu[l], hbuf, (long)T * 96, 96, 96, NULL, 0, 0, 0, NULL, nr, x + in, xsb, W, B, T, 2, stream);
         const int cin = in + 96;
         e |= gemm(h, &h->dec_conv[l], x, xsb, W, cin, x - W, xsb, W, cin, rst, nr, x + cin, xsb, W, B, T, 1, stream);
     }
-    e |= gemm(h, &h->dec_output, x, xsb, W, 736, NULL, 0, 0, 0, NULL, nr, out, (long)T * h->feat_in, h->feat_in, B, T, 0, stream);
+    e |= gemm(h, &h->dec_output, x, xsb, W, 736, NULL, 0, 0, 0, NULL, nr, out, (long)Tio * h->feat_in, h->feat_in, B, T, 0, stream);
     return e;
 }
 
-static int decoder_round(rade_batch *h, void *stream)
+static int decoder_round(rade_batch *h, int T, void *stream)
 {
-    return decoder_layers(h, h->zrows, RD_DEC_ROWS, RD_DEC_ROWS, h->dec_x, h->dec_gi, h->dec_hbuf, h->dec_h, h->rx_nrows, h->rx_rowreset, h->feat84, stream);
+    return decoder_layers(h, h->zrows, T, h->dec_rows, h->dec_rows, h->dec_x, h->dec_gi, h->dec_hbuf, h->dec_h, h->rx_nrows, h->rx_rowreset, h->feat84, stream);
 }
 
 int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *features_out_dev, int reset_state, void *stream)
@@ -391,7 +401,7 @@ int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *fea
         for (int l = 0; l < 5; l++) hipMemsetAsync(h->dec2_h[l], 0, sizeof(float) * h->B * 96, st);
         hipMemsetAsync(h->dec2_x, 0, sizeof(float) * (size_t)h->B * (1 + h->Tcap) * RD_DEC_W, st);
     }
-    int e = decoder_layers(h, z_dev, n_steps, h->Tcap, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->dec2_h, NULL, NULL, features_out_dev, stream);
+    int e = decoder_layers(h, z_dev, n_steps, n_steps, h->Tcap, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->dec2_h, NULL, NULL, features_out_dev, stream);
     e |= rd_launch_carry_rows(h->dec2_x, h->B, h->Tcap, RD_DEC_W, 1, n_steps, NULL, stream);
     return e ? -1 : n_steps;
 }
@@ -415,12 +425,13 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
-    sa.max_calls = max_calls; sa.unit_budget = getenv("RADE_UNIT_BUDGET") ? atoi(getenv("RADE_UNIT_BUDGET")) : 10; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+    sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.snap = h->rx_snap; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     rd_post_args pa;
     memset(&pa, 0, sizeof pa);
     pa.st = h->rx_st; pa.round = h->rx_round; pa.feat84 = h->feat84; pa.features_out = features_out_dev; pa.feat_stride = feat_stride;
     pa.trace = h->trace; pa.trace_cap = h->trace_cap; pa.B = B;
+    pa.snap = h->rx_snap; pa.acc = h->rx_acc; pa.n_rows = h->rx_nrows; pa.progress = h->rx_progress; pa.status = h->rx_status; pa.dec_rows = h->dec_rows;
     for (;;) {
         CHK(hipMemsetAsync(h->rx_progress, 0, sizeof(int) * 4, st));
         PROF_BEGIN(h, st);
@@ -430,11 +441,11 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
         CHK(hipStreamSynchronize(st));
         if (hs[0] == 0) break;                  /* no stream could make a call: out of samples or budget */
         if (hs[1] > 0) {
-            if (decoder_round(h, st)) goto fail;
+            if (decoder_round(h, hs[1] < h->dec_rows ? hs[1] : h->dec_rows, st)) goto fail;
             PROF_BEGIN(h, st);
             if (rd_launch_rx_post(&pa, st)) goto fail;
             PROF_END(h, st, RADE_PROF_POST, 0.0);
-            if (rd_launch_carry_rows(h->dec_x, B, RD_DEC_ROWS, RD_DEC_W, 1, 0, h->rx_nrows, st)) goto fail;
+            if (rd_launch_carry_rows(h->dec_x, B, h->dec_rows, RD_DEC_W, 1, 0, h->rx_nrows, st)) goto fail;
         }
     }
     if (status_host) {

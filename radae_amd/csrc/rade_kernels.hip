@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void k_gemm(rd_gemm_args a)
     const float *p1 = a.a1 + b * a.a1_sb + t * a.a1_st + 4 * half;
     const float *p0 = nullptr;
     if (a.K0) {
-        const bool rst = a.reset && a.reset[r];
+        const bool rst = a.reset && a.reset[b * a.reset_sb + t];
         p0 = (rst ? g_zero_row : a.a0 + b * a.a0_sb + t * a.a0_st) + 4 * half;
     }
     f32x16 acc[NT];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_gemm_splitk(rd_gemm_args a)
     const float *p1 = a.a1 + b * a.a1_sb + t * a.a1_st + 4 * half;
     const float *p0 = nullptr;
     if (a.K0) {
-        const bool rst = a.reset && a.reset[r];
+        const bool rst = a.reset && a.reset[b * a.reset_sb + t];
         p0 = (rst ? g_zero_row : a.a0 + b * a.a0_sb + t * a.a0_st) + 4 * half;
     }
     f32x16 acc[NT];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
 {
     constexpr int KP = H / 4;                       // k range per lane
     __shared__ __attribute__((aligned(16))) float hs[2][H];   // double-buffered so one barrier per step suffices
-    __shared__ int rst[64];                         // reset flags are only used by the decoder rounds (T <= 64)
+    __shared__ int rst[RD_DEC_ROWS_MAX];            // reset flags are only used by the decoder rounds (T <= 384)
     const int b = blockIdx.x, tid = threadIdx.x, j = tid >> 2, p = tid & 3;
     float wr[KP], wz[KP], wn[KP];
     {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
     }
     const float br = a.bhh[j], bz = a.bhh[H + j], bn = a.bhh[2 * H + j];
     const int Tb = a.n_rows ? a.n_rows[b] : a.T;
-    if (a.reset && tid < 64) rst[tid] = tid < a.T ? a.reset[b * a.T + tid] : 0;
+    if (a.reset) for (int i = tid; i < a.T && i < RD_DEC_ROWS_MAX; i += blockDim.x) rst[i] = a.reset[b * a.reset_sb + i];
     float hj = a.h[(size_t)b * H + j];
     if (p == 0) hs[0][j] = hj;
     const float *gi = a.gi + (size_t)b * a.gi_sb + (p < 3 ? p * H + j : j);   // lane part p < 3 fetches gate p of unit j
@@ -595,7 +595,7 @@ extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
 }
 
 // =====================================================================================================
-// receiver: one workgroup (256 threads) per stream, up to RD_RX_ROUND do_radae_rx calls per launch
+// receiver: one workgroup (512 threads) per stream, up to round_calls do_radae_rx calls per launch
 // =====================================================================================================
 enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
 
@@ -616,7 +616,7 @@ struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
     uint32_t lcg;
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, blocked, pending_valid, out_base;
-    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, units;
+    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, units, n_chk, snap_now;
     float snr_est, mag; float2 bpf_phase;
     double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
 };
@@ -857,19 +857,19 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
         S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->blocked = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0; S->dt_valid = st->dt_valid; S->units = 0;
+        S->go = 0; S->dt_valid = st->dt_valid; S->units = 0; S->n_chk = 0; S->snap_now = -1;
     }
     const int avail = a.avail[b];
     __syncthreads();
     PH_T0(); PH(0);
 
-    for (int it = 0; it < RD_RX_ROUND; it++) {   // <= RD_RX_ROUND calls: sizes of the per-round hand-off arrays
+    for (int it = 0; it < a.round_calls; it++) {   // <= round_calls calls: sizes of the per-round hand-off arrays
         // ---- can this stream make another call right now?  (decided once, by thread 0)
         if (tid == 0) {
             int go = 1;
-            if (S->calls_inv >= a.max_calls || S->units >= a.unit_budget || S->n_calls >= RD_RX_ROUND) go = 0;
+            if (S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls) go = 0;
             else if (S->consumed_inv + S->nin > avail) go = 0;
-            else if (S->state == ST_SYNC && S->pending_valid > 0 && ((S->synced_count + 1) % 8) == 0) { S->blocked = 1; go = 0; }  // UW decision needs the decoder
+            else if (S->state == ST_SYNC && S->pending_valid > 0 && ((S->synced_count + 1) % 8) == 0 && S->n_chk >= RD_CHK_MAX) go = 0;   // no snapshot slot left
             S->go = go;
             S->state_before = S->state; S->nin_before = S->nin;
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
@@ -1055,7 +1055,15 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 if (t2 < RD_M) { nn = RD_NMF - RD_M; t2 += RD_M; }
                 S->nin = nn; S->tmax = t2;
                 S->synced_count++;                                              // :220-224
-                if (S->synced_count % 8 == 0) { if (S->uw_errors > 7) S->uw_fail = 1; S->uw_errors = 0; S->uw_from_row = S->n_rows; }
+                if (S->synced_count % 8 == 0) {
+                    if (S->uw_errors > 7) S->uw_fail = 1;   // the decoded part of the window already decides
+                    else if (S->n_rows > S->uw_from_row) {  // part of this window is not decoded yet: pass speculatively, k_rx_post verifies
+                        const int k = S->n_chk++;
+                        rnd->chk_call[k] = S->n_calls; rnd->chk_from[k] = S->uw_from_row; rnd->chk_row[k] = S->n_rows; rnd->chk_base[k] = S->uw_errors;
+                        S->snap_now = k;
+                    }
+                    S->uw_errors = 0; S->uw_from_row = S->n_rows;
+                }
             }
             __syncthreads();
             PH(6);
@@ -1081,7 +1089,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             __syncthreads();
             PH(8);
-            float *zrow = a.zrows + ((size_t)b * RD_DEC_ROWS + n_rows) * RD_LATENT;   // 3 rows = 240 contiguous floats
+            float *zrow = a.zrows + ((size_t)b * a.dec_rows + n_rows) * RD_LATENT;   // 3 rows = 240 contiguous floats
             float *eoo_dst = a.eoo_out ? a.eoo_out + (size_t)b * RD_NEOOBITS : nullptr;
             const int call_idx0 = S->mf - 1;
             if (!endofover) {
@@ -1185,8 +1193,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 else { S->valid_count--; if (S->valid_count == 0) next_state = ST_SEARCH; }
                 if (S->endofover || S->uw_fail) next_state = ST_SEARCH;
             }
-            // work units keep a round's duration similar for searching and synchronised streams
-            S->units += (state == ST_SYNC) ? 1 : (S->dt_valid ? 2 : 4);
             S->dt_valid = (state != ST_SYNC && next_state != ST_SYNC) ? 1 : 0;   // next call's Dt1 == this call's Dt2
             S->state = next_state;
             if (next_state == ST_SEARCH) S->nin = RD_NMF;
@@ -1194,7 +1200,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const int ret = S->valid_output | (S->endofover << 1);
             const int call_idx = S->mf - 2;                   // 0-based index of this call since reset
             if (S->valid_output) {
-                for (int k = 0; k < 3; k++) { const int rf = (k == 0) ? S->dec_reset_pending : 0; rnd->row_reset[S->n_rows + k] = rf; a.row_reset[b * RD_DEC_ROWS + S->n_rows + k] = rf; }
+                for (int k = 0; k < 3; k++) { const int rf = (k == 0) ? S->dec_reset_pending : 0; rnd->row_reset[S->n_rows + k] = rf; a.row_reset[b * a.dec_rows + S->n_rows + k] = rf; }
                 S->dec_reset_pending = 0; S->n_rows += 3; S->pending_valid++; S->valid_inv++;
             }
             if (S->endofover) { S->has_eoo = 1; S->eoo_inv++; }
@@ -1209,6 +1215,27 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             S->n_calls = nc + 1; S->calls_inv++;
         }
         __syncthreads();
+        if (S->snap_now >= 0) {
+            // rollback point of a speculated UW check: the state this call would have left had the check FAILED, i.e.
+            // identical except next_state = search and nin = Nmf (radae_rxe.py:289-296)
+            const int k = S->snap_now;
+            rd_rx_stream *sp = a.snap + (size_t)b * RD_CHK_MAX + k;
+            for (int i = tid; i < RD_RXBUF; i += NT_RX) { sp->rx_buf[i][0] = sh->rxb[i].x; sp->rx_buf[i][1] = sh->rxb[i].y; }
+            for (int i = tid; i < RD_NMF; i += NT_RX) { sp->rowsum1[i] = sh->rowsum1[i]; sp->rowsum2[i] = sh->rowsum2[i]; }
+            for (int i = tid; i < 102; i += NT_RX) { sp->bpf_mem[i][0] = sh->bmem[i].x; sp->bpf_mem[i][1] = sh->bmem[i].y; }
+            if (tid == 0) {
+                sp->state = ST_SEARCH; sp->nin = RD_NMF; sp->tmax = S->tmax; sp->tmax_candidate = S->tmax_candidate; sp->valid_count = S->valid_count;
+                sp->uw_errors = 0; sp->synced_count = S->synced_count; sp->mf = S->mf; sp->f_ind_max = S->f_ind_max;
+                sp->dec_reset_pending = S->dec_reset_pending; sp->bpf_mem_len = S->bpf_mem_len; sp->has_eoo = S->has_eoo; sp->lcg = S->lcg; sp->dt_valid = 0;
+                sp->fmax = S->fmax; sp->foff_err = S->foff_err; sp->rx_phase[0] = S->rph_r; sp->rx_phase[1] = S->rph_i;
+                sp->Dthresh = S->Dthresh; sp->Dtmax12 = S->Dtmax12; sp->Dtmax12_eoo = S->Dtmax12_eoo; sp->snr_est = S->snr_est;
+                sp->bpf_phase[0] = S->bpf_phase.x; sp->bpf_phase[1] = S->bpf_phase.y; sp->consumed = st->consumed + S->consumed_round;
+                int *ca = rnd->chk_acc[k];
+                ca[0] = S->consumed_inv; ca[1] = S->calls_inv; ca[2] = S->valid_inv; ca[3] = S->eoo_inv; ca[4] = S->n_rows; ca[5] = S->n_calls; ca[6] = S->has_eoo; ca[7] = 0;
+                S->snap_now = -1;
+            }
+            __syncthreads();
+        }
         PH(10);
     }
 
@@ -1226,7 +1253,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         st->Dthresh = S->Dthresh; st->Dtmax12 = S->Dtmax12; st->Dtmax12_eoo = S->Dtmax12_eoo; st->snr_est = S->snr_est;
         st->bpf_phase[0] = S->bpf_phase.x; st->bpf_phase[1] = S->bpf_phase.y; st->consumed += S->consumed_round;
         rnd->n_calls = S->n_calls; rnd->n_rows = S->n_rows; rnd->uw_from_row = S->uw_from_row; rnd->consumed = S->consumed_round;
-        rnd->blocked = S->blocked; rnd->out_base = S->out_base;
+        rnd->blocked = 0; rnd->out_base = S->out_base; rnd->n_chk = S->n_chk;
         a.acc[b * 4 + 0] = S->consumed_inv; a.acc[b * 4 + 1] = S->calls_inv; a.acc[b * 4 + 2] = S->valid_inv; a.acc[b * 4 + 3] = S->eoo_inv;
         a.n_rows[b] = S->n_rows;
         a.status[b * 4 + 0] = S->nin; a.status[b * 4 + 1] = S->state == ST_SYNC; a.status[b * 4 + 2] = (int)S->snr_est; a.status[b * 4 + 3] = S->state;
@@ -1263,18 +1290,33 @@ extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, doubl
     return (int)hipGetLastError();
 }
 
-// decoder output rows -> feature frames + UW accounting (rade_api.c:488-513, radae_rxe.py:300-319)
+// decoder output rows -> feature frames + UW accounting (rade_api.c:488-513, radae_rxe.py:300-319), and the
+// verification of UW checks the sync kernel passed speculatively.  A window that really had > 7 aux-bit errors
+// rolls its stream back to the snapshot taken right after that check (state = search), discarding later calls.
 __global__ __launch_bounds__(256) void k_rx_post(rd_post_args a)
 {
     const int b = blockIdx.x, tid = threadIdx.x;
     rd_rx_round *rnd = a.round + b;
     rd_rx_stream *st = a.st + b;
-    const int n_rows = rnd->n_rows;
-    __shared__ int err[RD_DEC_ROWS];
+    int n_rows = rnd->n_rows;
+    __shared__ int err[RD_DEC_ROWS_MAX];
+    __shared__ int s_fail, s_rows;
     if (n_rows == 0) return;
-    const float *f84 = a.feat84 + (size_t)b * RD_DEC_ROWS * 84;
-    if (tid < n_rows) err[tid] = f84[tid * 84 + 20] > 0.0f ? 1 : 0;      // first aux symbol of each group of 4
+    const float *f84 = a.feat84 + (size_t)b * a.dec_rows * 84;
+    for (int r = tid; r < n_rows; r += blockDim.x) err[r] = f84[r * 84 + 20] > 0.0f ? 1 : 0;      // first aux symbol of each group of 4
     __syncthreads();
+    if (tid == 0) {
+        int fail = -1;
+        for (int k = 0; k < rnd->n_chk && fail < 0; k++) {
+            int e = rnd->chk_base[k];
+            for (int r = rnd->chk_from[k]; r < rnd->chk_row[k]; r++) e += err[r];
+            if (e > 7) fail = k;
+        }
+        s_fail = fail; s_rows = fail >= 0 ? rnd->chk_acc[fail][4] : n_rows;
+    }
+    __syncthreads();
+    const int fail = s_fail;
+    n_rows = s_rows;
     // scatter: valid frame v (3 rows) -> 12 feature frames x 36 floats, 20 used + 16 zeros
     float *out = a.features_out + (size_t)b * a.feat_stride + (size_t)rnd->out_base * RD_FEAT_MF;
     for (int i = tid; i < (n_rows / 3) * RD_FEAT_MF; i += blockDim.x) {
@@ -1282,17 +1324,37 @@ __global__ __launch_bounds__(256) void k_rx_post(rd_post_args a)
         const int row = fr >> 2, sub = fr & 3;
         out[i] = j < 20 ? f84[row * 84 + sub * 21 + j] : 0.0f;
     }
+    if (fail >= 0) {                                     // restore the rollback snapshot (all threads copy, 33 KB)
+        const rd_rx_stream *sp = a.snap + (size_t)b * RD_CHK_MAX + fail;
+        const int *src = (const int *)sp; int *dst = (int *)st;
+        for (int i = tid; i < (int)(sizeof(rd_rx_stream) / 4); i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     if (tid == 0) {
-        int add = 0;
-        for (int r = rnd->uw_from_row; r < n_rows; r++) add += err[r];
-        st->uw_errors += add;
+        const int n_calls = fail >= 0 ? rnd->chk_acc[fail][5] : rnd->n_calls;
+        if (fail >= 0) {
+            const int *ca = rnd->chk_acc[fail];
+            a.acc[b * 4 + 0] = ca[0]; a.acc[b * 4 + 1] = ca[1]; a.acc[b * 4 + 2] = ca[2]; a.acc[b * 4 + 3] = ca[3];
+            int add = 0;                                 // the check frame's own aux bits open the next window
+            for (int r = rnd->chk_row[fail]; r < n_rows; r++) add += err[r];
+            st->uw_errors = add;
+            a.n_rows[b] = n_rows;                        // the conv-history carry must use the last kept row
+            a.status[b * 4 + 0] = RD_NMF; a.status[b * 4 + 1] = 0; a.status[b * 4 + 2] = (int)st->snr_est; a.status[b * 4 + 3] = ST_SEARCH;
+            atomicAdd(&a.progress[2], 1);
+        } else {
+            int add = 0;
+            for (int r = rnd->uw_from_row; r < n_rows; r++) add += err[r];
+            st->uw_errors += add;
+        }
         if (a.trace) {
-            for (int c = 0; c < rnd->n_calls; c++) {
+            for (int c = 0; c < n_calls; c++) {
                 const int idx = rnd->call_trace_idx[c];
                 if (idx >= a.trace_cap) continue;
                 int e = 0;
                 for (int r = rnd->call_row_lo[c]; r < rnd->call_row_hi[c]; r++) e += err[r];
-                a.trace[(size_t)b * a.trace_cap + idx].uw_errors += e;
+                rd_rx_trace *tr = a.trace + (size_t)b * a.trace_cap + idx;
+                tr->uw_errors += e;
+                if (fail >= 0 && c == n_calls - 1) { tr->state_after = ST_SEARCH; tr->nin_after = RD_NMF; }   // the failed check's call
             }
         }
     }

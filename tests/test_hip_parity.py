@@ -126,6 +126,45 @@ def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden):
     eng.close()
 
 
+def test_speculated_uw_checks_roll_back(Engine, torch_dev, oracle, oracle_model, monkeypatch):
+    """UW checks are passed speculatively when their frames are not decoded yet and rolled back if they really
+    failed (radae_rxe.py:220-224).  A RADE_FOFF_TEST frequency error and low SNR make windows fail: the batch path
+    (whole utterance per launch) must equal decode-after-every-call and the oracle, bit for bit on the trace."""
+    import torch
+    from radae_amd.engine import sigma_from_EbNodB
+    n_mf = 40
+    streams = []
+    for seed, eb, fo in [(31, 20.0, 5.0), (32, -2.0, -20.0), (33, 1.0, 12.0)]:
+        feats, G, n_pre, noise = _make_stream(seed, n_mf, eb, fo, "mpp")
+        streams.append((feats, G, n_pre, noise, sigma_from_EbNodB(eb), fo))
+    res = {}
+    for mode in ("1", None):
+        if mode: monkeypatch.setenv("RADE_ROUND_CALLS", mode)
+        else: monkeypatch.delenv("RADE_ROUND_CALLS", raising=False)
+        out = []
+        for i, (feats, G, n_pre, noise, sigma, fo) in enumerate(streams):
+            eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=64, flags=4 if i == 0 else 0)   # stream 0: clean signal, 10 Hz off after sync entry
+            iq = eng.tx(torch.tensor(feats[None], device=torch_dev))
+            rx = eng.channel(iq, sigma, fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=torch.tensor(G[None], device=torch_dev),
+                             noise=torch.tensor(noise[None], device=torch_dev))
+            f, st, _ = eng.rx(rx)
+            out.append((rx.cpu().numpy()[0], f.cpu().numpy()[0, :st[0].n_valid], eng.rx_trace(0), (st[0].consumed, st[0].n_calls, st[0].n_valid, st[0].has_eoo, st[0].nin, st[0].state)))
+            eng.close()
+        res[mode] = out
+    n_fail = 0
+    for i, (a, bb) in enumerate(zip(res["1"], res[None])):
+        assert a[3] == bb[3]
+        for k in INT_KEYS:
+            assert np.array_equal(a[2][k], bb[2][k]), (i, k)
+        assert np.array_equal(a[1], bb[1])
+        d = oracle.run_rx_stream(oracle_model, a[0], foff_err=10.0 if i == 0 else 0.0)
+        for k in INT_KEYS:
+            assert np.array_equal(bb[2][k], d[k]), (i, k)
+        sa, sb = d["state_before"], d["state_after"]
+        n_fail += int(np.sum((sa == 2) & (sb == 0)))
+    assert n_fail >= 1            # the case really exercises sync losses
+
+
 def _make_stream(seed, n_mf, EbNodB, fo, chan):
     from radae_amd.channel_tools import multipath_g, synth_features
     rng = np.random.default_rng(seed)
