@@ -155,6 +155,7 @@ typedef struct {
     int max_calls;                                       /* call budget per stream per invocation */
     int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
     rd_rx_stream *snap;                                  /* [B][RD_CHK_MAX] rollback snapshots */
+    const float *fftG, *ffttw;                           /* rd_fft_tables_fill(): [RD_NFC][2048][2], [2048 + 64][2] */
     float *zrows;                                        /* [B][dec_rows][80] */
     int *n_rows; int *row_reset;                         /* flat [B], [B][dec_rows] copies for the decoder kernels */
     float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */

@@ -29,6 +29,7 @@ struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
     rd_rx_stream *rx_snap;
+    float *fftG, *ffttw;
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -147,8 +148,13 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     rd_tables *tab = malloc(sizeof *tab);
     rd_tables_fill(tab);
     h->d_tab = dev_upload(tab, sizeof *tab);
+    {
+        float *G = malloc(sizeof(float) * RD_NFC * 2048 * 2), *tw = malloc(sizeof(float) * (2048 + 64) * 2);
+        if (G && tw) { rd_fft_tables_fill(tab, G, tw); h->fftG = dev_upload(G, sizeof(float) * RD_NFC * 2048 * 2); h->ffttw = dev_upload(tw, sizeof(float) * (2048 + 64) * 2); }
+        free(G); free(tw);
+    }
     free(tab);
-    if (!h->d_tab) goto fail;
+    if (!h->d_tab || !h->fftG || !h->ffttw) goto fail;
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 7) & ~7; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
@@ -194,7 +200,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->dec2_hbuf = dev_zeros(sizeof(float) * B * T * 96);
     for (int l = 0; l < 5; l++) { h->dec2_h[l] = dev_zeros(sizeof(float) * B * 96); if (!h->dec2_h[l]) goto fail; }
     if (!h->dec2_x || !h->dec2_gi || !h->dec2_hbuf) goto fail;
-    h->dtcache = dev_zeros(sizeof(float) * B * RD_NMF * RD_NFC);
+    h->dtcache = dev_zeros(sizeof(float) * B * 2 * RD_NMF * RD_NFC);
     if (!h->enc_xin || !h->enc_x || !h->enc_gi || !h->enc_z || !h->eoo || !h->eoo_bits || !h->chan_scratch || !h->rx_st || !h->rx_round || !h->rx_avail ||
         !h->rx_acc || !h->rx_progress || !h->rx_nrows || !h->rx_rowreset || !h->rx_status || !h->zrows || !h->dec_x || !h->dec_gi || !h->dec_hbuf || !h->feat84 || !h->dtcache) {
         fprintf(stderr, "rade: device allocation failed\n"); goto fail;
@@ -239,7 +245,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_snap };
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_snap, h->fftG, h->ffttw };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -425,7 +431,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
-    sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.snap = h->rx_snap; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+    sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.snap = h->rx_snap; sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     rd_post_args pa;
     memset(&pa, 0, sizeof pa);

@@ -24,6 +24,7 @@ void rd_tables_fill(rd_tables *T);
 int rd_model_parse(const void *blob, size_t len, rd_model *m);
 void rd_model_free(rd_model *m);
 
+void rd_fft_tables_fill(const rd_tables *T, float *G, float *tw);
 #ifdef __cplusplus
 }
 #endif

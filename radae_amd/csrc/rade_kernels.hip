@@ -600,10 +600,10 @@ extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
 enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
 
 #ifdef RD_PHASE_TIMING   // developer aid: per-phase shader-clock totals of workgroup 0 (make EXTRA=-DRD_PHASE_TIMING)
-__device__ long long g_phase_cycles[16];
+__device__ long long g_phase_cycles[24];
 #define PH_T0() long long ph_t_ = clock64()
 #define PH(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); atomicAdd((unsigned long long *)&g_phase_cycles[i], (unsigned long long)(n_ - ph_t_)); ph_t_ = n_; } } while (0)
-extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 16); long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
+extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 24); long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
 #else
 #define PH_T0() do { } while (0)
 #define PH(i) do { } while (0)
@@ -611,12 +611,14 @@ extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out,
 
 
 #define NT_RX 512
+#define FFT_N 2048
+#define FFT_SCR (32 * 65)               // floats per wave of the FFT transpose scratch: [q][l], one-word pad (conflict-free both ways)
 
 struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
     uint32_t lcg;
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, blocked, pending_valid, out_base;
-    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, units, n_chk, snap_now;
+    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync, units, n_chk, snap_now;
     float snr_est, mag; float2 bpf_phase;
     double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
 };
@@ -625,16 +627,24 @@ struct RxShared {
     RxScalars S;
     float2 bmem[102];                     // BPF memory (dsp.py:55,96)
     double2 pd[RD_M], pendd[RD_M];        // pilot / end-of-over replicas as doubles (refine, check_pilots)
-    float2 wfwd[RD_M][RD_NC];             // forward DFT matrix (dsp.py:501)
     float2 rxb[RD_RXBUF];                 // rx_buf (radae_rxe.py:141)
     float2 xm[102 + RD_NINMAX + 2];       // BPF [mem | mixed-down new]; reused as rx1[1152] for the demod
-    float2 pw[RD_M][RD_NFC];              // acquisition.p_w
     float2 sym[6][RD_NC];
     float2 rp[2][RD_NC];
     float bpf_h[RD_NTAP + 3];
     union {
-        float absd[96][RD_NFC + 1];       // check_pilots scratch |Dt| rows
-        float2 dtr[2][80][16];            // refine(): complex64 Dt1 / Dt2 per (f, t)
+        struct {                          // synchronised state (S.lds_sync != 0)
+            float2 wfwd[RD_M][RD_NC];     // forward DFT matrix (dsp.py:501)
+            float2 pw[RD_M][RD_NFC];      // acquisition.p_w
+            union {
+                float absd[96][RD_NFC + 1];   // check_pilots scratch |Dt| rows
+                float2 dtr[2][80][16];        // refine(): complex64 Dt1 / Dt2 per (f, t); does not overlap the FFT area
+            };
+        };
+        struct {                          // search / candidate state: FFT pilot correlator
+            float2 fftX[FFT_N];           // spectrum of the rx_buf window being correlated
+            float fftscr[NT_RX / 64][FFT_SCR];
+        };
     };
     double2 rtw[80], rrot[80];            // refine(): e^{-jw_f} and e^{-jw_f Nmf} per candidate frequency
     float rowsum1[RD_NMF], rowsum2[RD_NMF]; // sum_f |Dt1[t,f]|, |Dt2[t,f]|
@@ -642,6 +652,147 @@ struct RxShared {
     double redd[(NT_RX / 64 + 1) * 10];   // block reductions (double): per-wave partials + totals
     float redf[16]; int redi[16]; int redj[16];   // arg-max reduction: slot 0 result, 1.. per-wave partials
 };
+
+// ---------------------------------------------------------------------------------------------------------
+// FFT pilot correlator (search / candidate state).  One wavefront transforms 2048 points held 32 per lane:
+//   pass 1: lane l owns x[l + 64 k2]; in-lane radix-2 DIF DFT over k2 -> A_l[q], times e^{-j2pi l q/2048}
+//   transpose through a per-wave LDS scratch so lane (q, h) owns A_l[q] for l in [32h, 32h+32)
+//   pass 2: one DIF radix-2 stage across the lane pair, then the in-lane 32-point DFT over l
+// Lane (q, h) ends with X[q + 32 (2 p + h)] in v[brev5(p)].  Twiddles of the in-lane DFTs are literals.
+// ---------------------------------------------------------------------------------------------------------
+__device__ static constexpr float C32[16] = { 1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f, 6.123233996e-17f, -1.950903220e-01f, -3.826834324e-01f, -5.555702330e-01f, -7.071067812e-01f, -8.314696123e-01f, -9.238795325e-01f, -9.807852804e-01f };
+__device__ static constexpr float S32[16] = { 0.000000000e+00f, 1.950903220e-01f, 3.826834324e-01f, 5.555702330e-01f, 7.071067812e-01f, 8.314696123e-01f, 9.238795325e-01f, 9.807852804e-01f, 1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f };
+__device__ static constexpr float C64[32] = { 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 6.123233996e-17f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f };
+__device__ static constexpr float S64[32] = { 0.000000000e+00f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f, 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f };
+__host__ __device__ constexpr int brev5(int x) { return ((x & 1) << 4) | ((x & 2) << 2) | (x & 4) | ((x & 8) >> 2) | ((x & 16) >> 4); }
+__device__ __forceinline__ float lane_swap1(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+
+__device__ __forceinline__ void dft32_inlane(float2 (&v)[32])
+{   // forward DFT, decimation in frequency: output X[q] is left in v[brev5(q)]
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int half = 16 >> s;
+#pragma unroll
+        for (int g = 0; g < (1 << s); g++) {
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                const int i = g * 2 * half + k, j = i + half, e = k << s;
+                const float2 x = v[i], y = v[j];
+                v[i] = make_float2(x.x + y.x, x.y + y.y);
+                const float dr = x.x - y.x, di = x.y - y.y;
+                if (e == 0) v[j] = make_float2(dr, di);
+                else if (e == 8) v[j] = make_float2(di, -dr);                       // times -j
+                else if (e == 4) v[j] = make_float2((dr + di) * C32[4], (di - dr) * C32[4]);
+                else if (e == 12) v[j] = make_float2((di - dr) * C32[4], -(dr + di) * C32[4]);
+                else v[j] = make_float2(dr * C32[e] + di * S32[e], di * C32[e] - dr * S32[e]);   // times e^{-j2pi e/32}
+            }
+        }
+    }
+}
+
+// v[k2] = x[lane + 64 k2] in, X[q + 32(2p + h)] (q = lane>>1, h = lane&1) in v[brev5(p)] out
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(1))) float glb_float;
+__device__ __forceinline__ void fft2048_wave(float2 (&v)[32], lds_float *scr, const glb_float *__restrict__ tw, int lane)
+{
+    dft32_inlane(v);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float2 w[8];                                    // issue the 8 loads together, then consume (the barriers pin that order)
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int q = 8 * c + u; w[u] = make_float2(tw[2 * (q * 64 + lane)], tw[2 * (q * 64 + lane) + 1]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int q = 8 * c + u; if (q) v[brev5(q)] = cmul(v[brev5(q)], w[u]); }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int q2 = lane >> 1, h = lane & 1;
+    float ur[32], ui[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) scr[q * 65 + lane] = v[brev5(q)].x;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int l = 0; l < 32; l++) ur[l] = scr[q2 * 65 + 32 * h + l];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 32; q++) scr[q * 65 + lane] = v[brev5(q)].y;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int l = 0; l < 32; l++) ui[l] = scr[q2 * 65 + 32 * h + l];
+    __builtin_amdgcn_wave_barrier();
+    // radix-2 DIF stage over l <-> l + 32 (the partner lane): even outputs on h = 0, odd outputs (twiddled) on h = 1
+    const float sg = h ? -1.0f : 1.0f;
+    const glb_float *w64 = tw + 2 * (2048 + h * 32);                                          // h = 0: ones, h = 1: e^{-j2pi l/64}
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float2 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] = make_float2(w64[2 * (8 * c + u)], w64[2 * (8 * c + u) + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int l = 8 * c + u;
+            const float sr = fmaf(ur[l], sg, lane_swap1(ur[l])), si = fmaf(ui[l], sg, lane_swap1(ui[l]));   // h = 0: u + o;  h = 1: o - u
+            v[l] = l ? cmul(make_float2(sr, si), w[u]) : make_float2(sr, si);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    dft32_inlane(v);
+}
+
+// |Dt| surfaces by FFT convolution (see the FFT correlator notes above); runs with its own register allocation.
+// pass 0: Dt1 (rx_buf[t + m]) -> buffer oldb, pass 1: Dt2 (rx_buf[Nmf + t + m]) -> buffer newb; cached skips pass 0.
+__device__ __forceinline__ void rx_detect_fft(RxShared *sh, const float *G_, const float *tw_, float *cache_, int cached, int oldb, int newb)
+{
+    const glb_float *G = (const glb_float *)G_, *tw = (const glb_float *)tw_; glb_float *cache = (glb_float *)cache_;   // address spaces are lost across the call
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q2 = lane >> 1, h = lane & 1;
+    lds_float *scr = (lds_float *)&sh->fftscr[wave][0];                      // LDS address space is lost across the call: restore it
+    lds_float *rxf = (lds_float *)&sh->rxb[0], *Xf = (lds_float *)&sh->fftX[0];
+#pragma unroll 1
+    for (int pass = cached ? 1 : 0; pass < 2; pass++) {
+        lds_float *x = rxf + 2 * pass * RD_NMF;
+        glb_float *dst = cache + (size_t)(pass ? newb : oldb) * RD_NFC * RD_NMF;
+        float2 v[32];
+        // fi = -1: forward transform of the window (every wave repeats it: identical values, no workgroup barrier);
+        // fi >= 0: inverse transform of X . G_f as the forward transform of the re/im-swapped product
+#pragma unroll 1
+        for (int fi = -1; fi < RD_NFC / (NT_RX / 64); fi++) {
+            const int f = wave * (RD_NFC / (NT_RX / 64)) + fi;
+            if (fi < 0) {
+#pragma unroll
+                for (int k2 = 0; k2 < 32; k2++) {                             // Nmf + M - 1 = 1119 samples, zero padded
+                    const int n = lane + 64 * k2;
+                    v[k2] = (k2 < 18 && n < RD_NMF + RD_M - 1) ? make_float2(x[2 * n], x[2 * n + 1]) : make_float2(0.0f, 0.0f);
+                }
+            } else {
+                const glb_float *Gf = G + (size_t)f * FFT_N * 2;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float2 g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int k = lane + 64 * (8 * c + u); g[u] = make_float2(Gf[2 * k], Gf[2 * k + 1]); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int k = lane + 64 * (8 * c + u); const float2 y = cmul(make_float2(Xf[2 * k], Xf[2 * k + 1]), g[u]); v[8 * c + u] = make_float2(y.y, y.x); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            fft2048_wave(v, scr, tw, lane);
+            if (fi < 0) {
+#pragma unroll
+                for (int p = 0; p < 32; p++) { const int k = q2 + 64 * p + 32 * h; Xf[2 * k] = v[brev5(p)].x; Xf[2 * k + 1] = v[brev5(p)].y; }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int p = 0; p < 15; p++) {                                // t = q2 + 32 (2p + h) < Nmf
+                    const float2 c = v[brev5(p)];
+                    dst[(size_t)f * RD_NMF + q2 + 64 * p + 32 * h] = __builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y));
+                }
+            }
+        }
+        __syncthreads();                                                      // fftX is rewritten by the next pass; |Dt| visible to the workgroup
+    }
+}
 
 // max reduction with lexicographic tie-break (smaller k0, then smaller k1 wins); result in sh->redf[0], redi[0], redj[0]
 __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
@@ -842,10 +993,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 
     // ---- load the stream's working set into LDS
     for (int i = tid; i < RD_RXBUF; i += NT_RX) sh->rxb[i] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]);
-    for (int i = tid; i < RD_M * RD_NFC; i += NT_RX) sh->pw[i / RD_NFC][i % RD_NFC] = make_float2(tab->p_w[i / RD_NFC][i % RD_NFC][0], tab->p_w[i / RD_NFC][i % RD_NFC][1]);
     for (int i = tid; i < RD_NTAP; i += NT_RX) sh->bpf_h[i] = tab->bpf_h[i];
     for (int i = tid; i < RD_M; i += NT_RX) { sh->pd[i] = make_double2(tab->p[i][0], tab->p[i][1]); sh->pendd[i] = make_double2(tab->pend[i][0], tab->pend[i][1]); }
-    for (int i = tid; i < RD_M * RD_NC; i += NT_RX) sh->wfwd[i / RD_NC][i % RD_NC] = make_float2(tab->Wfwd[i / RD_NC][i % RD_NC][0], tab->Wfwd[i / RD_NC][i % RD_NC][1]);
     for (int i = tid; i < RD_NMF; i += NT_RX) { sh->rowsum1[i] = st->rowsum1[i]; sh->rowsum2[i] = st->rowsum2[i]; }
     for (int i = tid; i < 102; i += NT_RX) sh->bmem[i] = make_float2(st->bpf_mem[i][0], st->bpf_mem[i][1]);
     if (tid == 0) {
@@ -857,13 +1006,16 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
         S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->blocked = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0; S->dt_valid = st->dt_valid; S->units = 0; S->n_chk = 0; S->snap_now = -1;
+        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->units = 0; S->n_chk = 0; S->snap_now = -1;
     }
     const int avail = a.avail[b];
     __syncthreads();
     PH_T0(); PH(0);
 
     for (int it = 0; it < a.round_calls; it++) {   // <= round_calls calls: sizes of the per-round hand-off arrays
+        // opaque per-iteration copy: keeps the compiler from hoisting every thread-index address computation of the
+        // loop body into registers that stay live across the whole call (they starve the FFT correlator of registers)
+        int tid = threadIdx.x; asm volatile("" : "+v"(tid));
         // ---- can this stream make another call right now?  (decided once, by thread 0)
         if (tid == 0) {
             int go = 1;
@@ -878,6 +1030,12 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         if (!S->go) break;
         const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
         const float2 bpf_phase = S->bpf_phase;
+        if (state == ST_SYNC && !S->lds_sync) {      // the demod / check_pilots tables share LDS with the FFT correlator
+            for (int i = tid; i < RD_M * RD_NFC; i += NT_RX) sh->pw[i / RD_NFC][i % RD_NFC] = make_float2(tab->p_w[i / RD_NFC][i % RD_NFC][0], tab->p_w[i / RD_NFC][i % RD_NFC][1]);
+            for (int i = tid; i < RD_M * RD_NC; i += NT_RX) sh->wfwd[i / RD_NC][i % RD_NC] = make_float2(tab->Wfwd[i / RD_NC][i % RD_NC][0], tab->Wfwd[i / RD_NC][i % RD_NC][1]);
+            __syncthreads();
+            if (tid == 0) S->lds_sync = 1;
+        }
 
         // ---- complex_bpf.bpf (dsp.py:63-102)
         const float2 *xin = rxin + S->consumed_inv;
@@ -932,56 +1090,32 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             // ---- acquisition.detect_pilots (dsp.py:178-231).  While searching nin == Nmf, so this call's Dt1 surface is
             // the previous call's Dt2 surface: |Dt2| is cached in HBM ([960][40] f32 per stream) and only the new
             // Dt2 is correlated (two adjacent t tiles per MFMA pairing).  First call after (re)entering search: both.
+            // Correlation along t runs as FFT convolution: 1 forward + 40 inverse 2048-point transforms per surface, one
+            // wavefront per transform (every wave repeats the forward one: same values, no workgroup barrier needed).
             float best = -1.0f; int bt = 0x7fffffff, bfi = 0;
-            {
-                const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, j = lane & 15;
-                float *cache = a.dtcache + (size_t)b * RD_NMF * RD_NFC;
-                const bool cached = S->dt_valid != 0;
-                if (cached) { for (int t = tid; t < RD_NMF; t += NT_RX) sh->rowsum1[t] = sh->rowsum2[t]; __syncthreads(); }
-                const int npair = cached ? RD_NMF / 32 : RD_NMF / 16;
-                for (int pr = wave; pr < npair; pr += NT_RX / 64) {
-                    const int tA = (cached ? pr * 32 : pr * 16) + j, tB = tA + 16;      // tB only used when cached
-                    float rsA1 = 0, rsA2 = 0, rsB2 = 0, lmaxA = -1.0f, lmaxB = -1.0f; int largA = 0, largB = 0;
-#pragma unroll 1
-                    for (int nt = 0; nt < 5; nt++) {
-                        const int f = 8 * nt + 2 * q;
-                        f32x4 c1, c2;
-                        if (cached) {
-                            const float2 oA = *(const float2 *)(cache + (size_t)tA * RD_NFC + f), oB = *(const float2 *)(cache + (size_t)tB * RD_NFC + f);
-                            corr_tile_mfma(sh, tA + RD_NMF, tB + RD_NMF, nt, c1, c2);
-                            const float nA0 = hypotf(c1[0], c1[1]), nA1 = hypotf(c1[2], c1[3]), nB0 = hypotf(c2[0], c2[1]), nB1 = hypotf(c2[2], c2[3]);
-                            *(float2 *)(cache + (size_t)tA * RD_NFC + f) = make_float2(nA0, nA1);
-                            *(float2 *)(cache + (size_t)tB * RD_NFC + f) = make_float2(nB0, nB1);
-                            rsA2 += nA0 + nA1; rsB2 += nB0 + nB1;
-                            float v = oA.x + nA0; if (v > lmaxA) { lmaxA = v; largA = f; }
-                            v = oA.y + nA1; if (v > lmaxA) { lmaxA = v; largA = f + 1; }
-                            v = oB.x + nB0; if (v > lmaxB) { lmaxB = v; largB = f; }
-                            v = oB.y + nB1; if (v > lmaxB) { lmaxB = v; largB = f + 1; }
-                        } else {
-                            corr_tile_mfma(sh, tA, tA + RD_NMF, nt, c1, c2);
-                            const float a10 = hypotf(c1[0], c1[1]), a11 = hypotf(c1[2], c1[3]), a20 = hypotf(c2[0], c2[1]), a21 = hypotf(c2[2], c2[3]);
-                            *(float2 *)(cache + (size_t)tA * RD_NFC + f) = make_float2(a20, a21);
-                            rsA1 += a10 + a11; rsA2 += a20 + a21;
-                            float v = a10 + a20; if (v > lmaxA) { lmaxA = v; largA = f; }
-                            v = a11 + a21; if (v > lmaxA) { lmaxA = v; largA = f + 1; }
-                        }
-                    }
-                    // combine the four lane groups (same t, different f) in a fixed order
-#pragma unroll
-                    for (int off = 16; off <= 32; off <<= 1) {
-                        rsA1 += __shfl_xor(rsA1, off); rsA2 += __shfl_xor(rsA2, off); rsB2 += __shfl_xor(rsB2, off);
-                        float ov = __shfl_xor(lmaxA, off); int oa = __shfl_xor(largA, off);
-                        if (ov > lmaxA || (ov == lmaxA && oa < largA)) { lmaxA = ov; largA = oa; }
-                        ov = __shfl_xor(lmaxB, off); oa = __shfl_xor(largB, off);
-                        if (ov > lmaxB || (ov == lmaxB && oa < largB)) { lmaxB = ov; largB = oa; }
-                    }
-                    if (lane < 16) {
-                        sh->rowsum2[tA] = rsA2;
-                        if (cached) sh->rowsum2[tB] = rsB2; else sh->rowsum1[tA] = rsA1;
-                        if (lmaxA > best) { best = lmaxA; bt = tA; bfi = largA; }   // tiles ascend per wave: first max kept
-                        if (cached && lmaxB > best) { best = lmaxB; bt = tB; bfi = largB; }
-                    }
+            const bool cached = S->dt_valid != 0;
+            const int oldb = cached ? S->dt_valid - 1 : 0, newb = 1 - oldb;
+            float *cache = a.dtcache + (size_t)b * 2 * RD_NFC * RD_NMF;      // [2][f][t] |Dt| surfaces
+            if (tid == 0) { S->lds_sync = 0; S->dt_new = newb; }
+            if (cached) for (int t = tid; t < RD_NMF; t += NT_RX) sh->rowsum1[t] = sh->rowsum2[t];
+            __syncthreads();
+            PH(16);
+            rx_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb);
+#ifdef RD_DETECT_TWICE
+            rx_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb);
+#endif
+            PH(17);
+            for (int t = tid; t < RD_NMF; t += NT_RX) {
+                const float *c1 = cache + (size_t)oldb * RD_NFC * RD_NMF + t, *c2 = cache + (size_t)newb * RD_NFC * RD_NMF + t;
+                float rs1 = 0.0f, rs2 = 0.0f, lmax = -1.0f; int larg = 0;
+#pragma unroll 8
+                for (int f = 0; f < RD_NFC; f++) {
+                    const float d1 = c1[f * RD_NMF], d2 = c2[f * RD_NMF];
+                    rs1 += d1; rs2 += d2;
+                    const float v12 = d1 + d2; if (v12 > lmax) { lmax = v12; larg = f; }
                 }
+                sh->rowsum2[t] = rs2; if (!cached) sh->rowsum1[t] = rs1;
+                if (lmax > best) { best = lmax; bt = t; bfi = larg; }        // t ascends per thread: first maximum kept
             }
             PH(2);
             block_argmax(sh, best, bt, bfi);
@@ -1193,7 +1327,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 else { S->valid_count--; if (S->valid_count == 0) next_state = ST_SEARCH; }
                 if (S->endofover || S->uw_fail) next_state = ST_SEARCH;
             }
-            S->dt_valid = (state != ST_SYNC && next_state != ST_SYNC) ? 1 : 0;   // next call's Dt1 == this call's Dt2
+            S->dt_valid = (state != ST_SYNC && next_state != ST_SYNC) ? S->dt_new + 1 : 0;   // next call's Dt1 == this call's Dt2 (buffer dt_new)
             S->state = next_state;
             if (next_state == ST_SEARCH) S->nin = RD_NMF;
             S->mf++;
