@@ -612,7 +612,8 @@ extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out,
 
 #define NT_RX 512
 #define FFT_N 2048
-#define FFT_SCR (32 * 65)               // floats per wave of the FFT transpose scratch: [q][l], one-word pad (conflict-free both ways)
+#define FFT_SCR (32 * 66)               // floats per wave of the FFT transpose scratch: [q][l + (l >> 5)], row stride 66: both
+                                        // halves of the wave hit 32 distinct banks on the write (fixed q) and on the read (fixed l)
 
 struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
@@ -692,6 +693,13 @@ __device__ __forceinline__ void dft32_inlane(float2 (&v)[32])
 
 // v[k2] = x[lane + 64 k2] in, X[q + 32(2p + h)] (q = lane>>1, h = lane&1) in v[brev5(p)] out
 typedef __attribute__((address_space(3))) float lds_float;
+#ifdef RD_FFT_PAD65
+#define FFT_WR(q, lane) ((q) * 65 + (lane))
+#define FFT_RD(q2, h, l) ((q2) * 65 + 32 * (h) + (l))
+#else
+#define FFT_WR(q, lane) ((q) * 66 + (lane) + ((lane) >> 5))
+#define FFT_RD(q2, h, l) ((q2) * 66 + 33 * (h) + (l))
+#endif
 typedef __attribute__((address_space(1))) float glb_float;
 __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], lds_float *scr, const glb_float *__restrict__ tw, int lane)
 {
@@ -709,16 +717,16 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], lds_float *scr, co
     const int q2 = lane >> 1, h = lane & 1;
     float ur[32], ui[32];
 #pragma unroll
-    for (int q = 0; q < 32; q++) scr[q * 65 + lane] = v[brev5(q)].x;
+    for (int q = 0; q < 32; q++) scr[FFT_WR(q, lane)] = v[brev5(q)].x;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int l = 0; l < 32; l++) ur[l] = scr[q2 * 65 + 32 * h + l];
+    for (int l = 0; l < 32; l++) ur[l] = scr[FFT_RD(q2, h, l)];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 32; q++) scr[q * 65 + lane] = v[brev5(q)].y;
+    for (int q = 0; q < 32; q++) scr[FFT_WR(q, lane)] = v[brev5(q)].y;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int l = 0; l < 32; l++) ui[l] = scr[q2 * 65 + 32 * h + l];
+    for (int l = 0; l < 32; l++) ui[l] = scr[FFT_RD(q2, h, l)];
     __builtin_amdgcn_wave_barrier();
     // radix-2 DIF stage over l <-> l + 32 (the partner lane): even outputs on h = 0, odd outputs (twiddled) on h = 1
     const float sg = h ? -1.0f : 1.0f;
@@ -742,22 +750,31 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], lds_float *scr, co
 
 // |Dt| surfaces by FFT convolution (see the FFT correlator notes above); runs with its own register allocation.
 // pass 0: Dt1 (rx_buf[t + m]) -> buffer oldb, pass 1: Dt2 (rx_buf[Nmf + t + m]) -> buffer newb; cached skips pass 0.
-__device__ __forceinline__ void rx_detect_fft(RxShared *sh, const float *G_, const float *tw_, float *cache_, int cached, int oldb, int newb)
+#ifndef RD_DETECT_INLINE
+#define RD_DETECT_INLINE __forceinline__
+#endif
+__device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, const float *tw_, float *cache_, int cached, int oldb, int newb,
+                                              float &best, int &bt, int &bfi)
 {
-    const glb_float *G = (const glb_float *)G_, *tw = (const glb_float *)tw_; glb_float *cache = (glb_float *)cache_;   // address spaces are lost across the call
+    const glb_float *G = (const glb_float *)G_, *tw = (const glb_float *)tw_; glb_float *cache = (glb_float *)cache_;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q2 = lane >> 1, h = lane & 1;
-    lds_float *scr = (lds_float *)&sh->fftscr[wave][0];                      // LDS address space is lost across the call: restore it
+    lds_float *scr = (lds_float *)&sh->fftscr[wave][0];
     lds_float *rxf = (lds_float *)&sh->rxb[0], *Xf = (lds_float *)&sh->fftX[0];
+    constexpr int NFW = RD_NFC / (NT_RX / 64);                                // frequencies per wave
 #pragma unroll 1
     for (int pass = cached ? 1 : 0; pass < 2; pass++) {
         lds_float *x = rxf + 2 * pass * RD_NMF;
         glb_float *dst = cache + (size_t)(pass ? newb : oldb) * RD_NFC * RD_NMF;
+        const glb_float *prev = cache + (size_t)oldb * RD_NFC * RD_NMF;       // |Dt1| while pass 1 produces |Dt2|
         float2 v[32];
+        float rs[15], mx[15]; unsigned long long argw = 0ull;                 // this wave's partial row sums / max_f(|Dt1|+|Dt2|) of its 15 t per lane
+#pragma unroll
+        for (int p = 0; p < 15; p++) { rs[p] = 0.0f; mx[p] = -1.0f; }
         // fi = -1: forward transform of the window (every wave repeats it: identical values, no workgroup barrier);
         // fi >= 0: inverse transform of X . G_f as the forward transform of the re/im-swapped product
 #pragma unroll 1
-        for (int fi = -1; fi < RD_NFC / (NT_RX / 64); fi++) {
-            const int f = wave * (RD_NFC / (NT_RX / 64)) + fi;
+        for (int fi = -1; fi < NFW; fi++) {
+            const int f = wave * NFW + fi;
             if (fi < 0) {
 #pragma unroll
                 for (int k2 = 0; k2 < 32; k2++) {                             // Nmf + M - 1 = 1119 samples, zero padded
@@ -777,6 +794,11 @@ __device__ __forceinline__ void rx_detect_fft(RxShared *sh, const float *G_, con
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            const int t0 = q2 + 32 * h;                                       // this lane's outputs: t = t0 + 64 p < Nmf
+            float d1[15];                                                     // |Dt1| of the same (f, t): fetched now, used after the transform
+#pragma unroll
+            for (int p = 0; p < 15; p++) d1[p] = (pass && fi >= 0) ? prev[(size_t)f * RD_NMF + t0 + 64 * p] : 0.0f;
+            __builtin_amdgcn_sched_barrier(0);
             fft2048_wave(v, scr, tw, lane);
             if (fi < 0) {
 #pragma unroll
@@ -784,13 +806,41 @@ __device__ __forceinline__ void rx_detect_fft(RxShared *sh, const float *G_, con
                 __builtin_amdgcn_wave_barrier();
             } else {
 #pragma unroll
-                for (int p = 0; p < 15; p++) {                                // t = q2 + 32 (2p + h) < Nmf
+                for (int p = 0; p < 15; p++) {
                     const float2 c = v[brev5(p)];
-                    dst[(size_t)f * RD_NMF + q2 + 64 * p + 32 * h] = __builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y));
+                    const float d = __builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y));
+                    dst[(size_t)f * RD_NMF + t0 + 64 * p] = d;
+                    rs[p] += d;
+                    if (pass) { const float s12 = d1[p] + d; if (s12 > mx[p]) { mx[p] = s12; argw = (argw & ~(15ull << (4 * p))) | ((unsigned long long)fi << (4 * p)); } }
                 }
             }
         }
-        __syncthreads();                                                      // fftX is rewritten by the next pass; |Dt| visible to the workgroup
+        // per-wave partials -> own scratch region (free now), combined by the whole workgroup in wave (= f) order
+        {
+            const int t0 = q2 + 32 * h;
+#pragma unroll
+            for (int p = 0; p < 15; p++) { scr[t0 + 64 * p] = rs[p]; scr[RD_NMF + t0 + 64 * p] = mx[p]; }
+            scr[2 * RD_NMF + 2 * lane] = __uint_as_float((unsigned)argw); scr[2 * RD_NMF + 2 * lane + 1] = __uint_as_float((unsigned)(argw >> 32));
+        }
+        __syncthreads();
+        for (int t = tid; t < RD_NMF; t += NT_RX) {
+            const int ln = 2 * (t & 31) + ((t >> 5) & 1), sh4 = 4 * (t >> 6);
+            float sum = 0.0f, lmax = -1.0f; int larg = 0;
+#pragma unroll
+            for (int w = 0; w < NT_RX / 64; w++) {
+                lds_float *sw = (lds_float *)&sh->fftscr[w][0];
+                sum += sw[t];
+                const float m = sw[RD_NMF + t];
+                if (m > lmax) {                                               // strict: the first maximum in f order is kept
+                    const unsigned lo = __float_as_uint(sw[2 * RD_NMF + 2 * ln]), hi = __float_as_uint(sw[2 * RD_NMF + 2 * ln + 1]);
+                    const unsigned long long aw = ((unsigned long long)hi << 32) | lo;
+                    lmax = m; larg = w * NFW + (int)((aw >> sh4) & 15);
+                }
+            }
+            if (pass) { sh->rowsum2[t] = sum; if (lmax > best) { best = lmax; bt = t; bfi = larg; } }   // t ascends per thread: first maximum kept
+            else sh->rowsum1[t] = sum;
+        }
+        __syncthreads();                                                      // scratch and fftX are rewritten by the next pass / the caller
     }
 }
 
@@ -1100,23 +1150,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             if (cached) for (int t = tid; t < RD_NMF; t += NT_RX) sh->rowsum1[t] = sh->rowsum2[t];
             __syncthreads();
             PH(16);
-            rx_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb);
-#ifdef RD_DETECT_TWICE
-            rx_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb);
-#endif
+            rx_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb, best, bt, bfi);
             PH(17);
-            for (int t = tid; t < RD_NMF; t += NT_RX) {
-                const float *c1 = cache + (size_t)oldb * RD_NFC * RD_NMF + t, *c2 = cache + (size_t)newb * RD_NFC * RD_NMF + t;
-                float rs1 = 0.0f, rs2 = 0.0f, lmax = -1.0f; int larg = 0;
-#pragma unroll 8
-                for (int f = 0; f < RD_NFC; f++) {
-                    const float d1 = c1[f * RD_NMF], d2 = c2[f * RD_NMF];
-                    rs1 += d1; rs2 += d2;
-                    const float v12 = d1 + d2; if (v12 > lmax) { lmax = v12; larg = f; }
-                }
-                sh->rowsum2[t] = rs2; if (!cached) sh->rowsum1[t] = rs1;
-                if (lmax > best) { best = lmax; bt = t; bfi = larg; }        // t ascends per thread: first maximum kept
-            }
             PH(2);
             block_argmax(sh, best, bt, bfi);
             const float Dmax = sh->redf[0]; const int tbest = sh->redi[0], fbest = sh->redj[0];

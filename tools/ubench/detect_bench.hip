@@ -9,7 +9,9 @@ __global__ __launch_bounds__(NT_RX) void k_detect_bench(const float *G, const fl
     for (int i = threadIdx.x; i < RD_RXBUF; i += NT_RX) sh->rxb[i] = make_float2(0.01f * (i % 37), 0.02f * (i % 11));
     __syncthreads();
     const long long t0 = clock64();
-    for (int it = 0; it < iters; it++) rx_detect_fft(sh, G, tw, cache + (size_t)blockIdx.x * 2 * RD_NFC * RD_NMF, cached, it & 1, 1 - (it & 1));
+    float best = -1.0f; int bt = 0, bfi = 0;
+    for (int it = 0; it < iters; it++) rx_detect_fft(sh, G, tw, cache + (size_t)blockIdx.x * 2 * RD_NFC * RD_NMF, cached, it & 1, 1 - (it & 1), best, bt, bfi);
+    if (best == 12345.0f) cyc[1] = bt + bfi;
     const long long t1 = clock64();
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
