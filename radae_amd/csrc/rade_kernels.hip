@@ -629,17 +629,18 @@ struct RxShared {
     float2 bmem[102];                     // BPF memory (dsp.py:55,96)
     double2 pd[RD_M], pendd[RD_M];        // pilot / end-of-over replicas as doubles (refine, check_pilots)
     float2 rxb[RD_RXBUF];                 // rx_buf (radae_rxe.py:141)
-    float2 xm[102 + RD_NINMAX + 2];       // BPF [mem | mixed-down new]; reused as rx1[1152] for the demod
+    __attribute__((aligned(16))) float2 xm[1408];   // BPF [mem | mixed-down new] (1224); refine(): rx window as doubles (11264 B); rx1[1152] for the demod
     float2 sym[6][RD_NC];
     float2 rp[2][RD_NC];
-    float bpf_h[RD_NTAP + 3];
+    __attribute__((aligned(16))) float bpf_h[RD_NTAP + 3];
     union {
         struct {                          // synchronised state (S.lds_sync != 0)
             float2 wfwd[RD_M][RD_NC];     // forward DFT matrix (dsp.py:501)
             float2 pw[RD_M][RD_NFC];      // acquisition.p_w
             union {
                 float absd[96][RD_NFC + 1];   // check_pilots scratch |Dt| rows
-                float2 dtr[2][80][16];        // refine(): complex64 Dt1 / Dt2 per (f, t); does not overlap the FFT area
+                float2 dtr[2 * 80 * 16];      // refine(): complex64 Dt1 / Dt2 at [(frame * nf + f) * 16 + t]; does not overlap the FFT area
+                struct { char rpart_pad[8192]; double rpart[6][64][4]; };   // refine(), in-sync grid (dtr uses 5 KB): second-half partial tiles
             };
         };
         struct {                          // search / candidate state: FFT pilot correlator
@@ -647,7 +648,7 @@ struct RxShared {
             float fftscr[NT_RX / 64][FFT_SCR];
         };
     };
-    double2 rtw[80], rrot[80];            // refine(): e^{-jw_f} and e^{-jw_f Nmf} per candidate frequency
+    double2 rtw[80], rrot[80], rt80[80];  // refine(): e^{-jw_f}, e^{-jw_f Nmf}, e^{-jw_f 80} per candidate frequency
     float rowsum1[RD_NMF], rowsum2[RD_NMF]; // sum_f |Dt1[t,f]|, |Dt2[t,f]|
     int rows48[48];
     double redd[(NT_RX / 64 + 1) * 10];   // block reductions (double): per-wave partials + totals
@@ -945,8 +946,55 @@ __device__ float sigma_r_from_rowsums(RxShared *sh)
 
 // refine(): fine timing/frequency search maximising |Dt1+Dt2| (dsp.py:233-270).  NumPy evaluates the dot products in
 // complex128 and stores them as complex64, so this runs on the f64 matrix cores (v_mfma_f64_16x16x4_f64):
-//   C[(f,c'), t] = sum_{(n,c)} Q[(f,c'),(n,c)] X[(n,c), t],   Q = realified e^{-jw_f n} conj(p[n]),  X = rx[t+n] (re | im)
-// one 16x16 tile per (8 frequencies, modem frame); the Q fragment is generated in registers by a rotation recurrence.
+//   C[(f,c'), t] = sum_{(n,c)} A[(f,c'),(n,c)] B[(n,c), t],  A = realified e^{-jw_f n},  B = conj(p[n]) rx[t+n] (re | im)
+// one 16x16 tile per (8 frequencies, modem frame).  Each lane's A entry is cos(w n) or +-sin(w n) for n = 2s + n0 and
+// follows the three-term recurrence x[s+1] = 2 cos(2w) x[s] - x[s-1]: one FMA per MFMA.  The window is converted to
+// double once ((xr, xi, xi, -xr) per sample so a lane reads the pair its component needs).
+__device__ __forceinline__ f64x4 refine_tile(const RxShared *sh, int mt, int frame, int s0, int ns, int nf, int nt, int lane)
+{
+    const int i = lane & 15, kk = lane >> 4, c = kk & 1, n0 = kk >> 1;
+    const int row = 16 * mt + i, fi = row >> 1, cp = row & 1;
+    const bool rv = fi < nf;
+    const double2 z1 = sh->rtw[rv ? fi : 0];                                  // e^{-jw}
+    double2 cur = s0 ? sh->rt80[rv ? fi : 0] : make_double2(1.0, 0.0);        // e^{-jw 2 s0} (s0 = 0 or 40)
+    if (n0) cur = make_double2(cur.x * z1.x - cur.y * z1.y, cur.x * z1.y + cur.y * z1.x);
+    const double c2r = z1.x * z1.x - z1.y * z1.y, c2i = 2.0 * z1.x * z1.y;   // e^{-2jw}
+    const double2 prv = make_double2(cur.x * c2r + cur.y * c2i, cur.y * c2r - cur.x * c2i);   // cur * e^{+2jw}
+    // realified rotation: (c',c) = (0,0) cos, (0,1) sin, (1,0) -sin, (1,1) cos;  cos = Re e^{-jwn}, sin = -Im e^{-jwn}
+    double xc = cp == c ? cur.x : (cp == 0 ? -cur.y : cur.y), xp = cp == c ? prv.x : (cp == 0 ? -prv.y : prv.y);
+    if (!rv) { xc = 0.0; xp = 0.0; }
+    const double k2 = 2.0 * c2r;
+    const double *xw = (const double *)&sh->xm[0] + 4 * (frame * 176 + (i < nt ? i : 0) + 2 * s0 + n0) + 2 * c;
+    const double2 *pp = &sh->pd[2 * s0 + n0];
+    f64x4 acc0 = { 0.0, 0.0, 0.0, 0.0 }, acc1 = acc0;
+    // software pipeline over batches of 4 samples: the next batch's LDS reads are in flight while this batch's products
+    // and matrix instructions issue (two waves per SIMD cannot hide the 40-cycle f64 latency by themselves)
+    double2 pn[4]; double a1[4], a2[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { pn[u] = pp[2 * u]; a1[u] = xw[8 * u]; a2[u] = xw[8 * u + 1]; }
+#pragma unroll 1
+    for (int s = 0; s < ns; s += 4) {
+        double b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) b[u] = pn[u].x * a1[u];
+#pragma unroll
+        for (int u = 0; u < 4; u++) b[u] = fma(pn[u].y, a2[u], b[u]);         // component c of conj(p[n]) rx[t+n]
+        __builtin_amdgcn_sched_barrier(0);
+        const int sn = s + 4 < ns ? s + 4 : s;                                // last batch re-reads itself: branch-free
+#pragma unroll
+        for (int u = 0; u < 4; u++) { pn[u] = pp[2 * (sn + u)]; a1[u] = xw[8 * (sn + u)]; a2[u] = xw[8 * (sn + u) + 1]; }
+        __builtin_amdgcn_sched_barrier(0);
+        const double x1 = fma(k2, xc, -xp), x2 = fma(k2, x1, -xc), x3 = fma(k2, x2, -x1);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xc, b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b[3], acc1, 0, 0, 0);
+        xp = x3; xc = fma(k2, x3, -x2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc0 + acc1;
+}
+
 __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -954,37 +1002,24 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
     const double delta = (fstart + fstep) - fstart;                       // np.arange fill rule
     const int ntasks = ((2 * nf + 15) >> 4) * 2;
     const int i = lane & 15, kk = lane >> 4;
-    const float *rxf = (const float *)&sh->rxb[0];
     PH_T0();
-    if (tid < nf) {                                                       // one sincos pair per candidate frequency
+    if (tid < nf) {                                                       // sincos per candidate frequency
         const double w = 2.0 * PI_D * (fstart + tid * delta) / 8000.0;
         double sn, cs; sincos(-w, &sn, &cs); sh->rtw[tid] = make_double2(cs, sn);
         sincos(-w * RD_NMF, &sn, &cs); sh->rrot[tid] = make_double2(cs, sn);
+        sincos(-w * 80.0, &sn, &cs); sh->rt80[tid] = make_double2(cs, sn);
+    }
+    if (tid >= 64 && tid < 64 + 2 * 176) {                                // the two windows as doubles: (xr, xi, xi, -xr)
+        const int j = tid - 64, frame = j / 176, k = j - frame * 176;
+        const float2 x = sh->rxb[min(t0 + frame * RD_NMF + k, RD_RXBUF - 1)];
+        double *d = (double *)&sh->xm[0] + 4 * j;
+        d[0] = (double)x.x; d[1] = (double)x.y; d[2] = (double)x.y; d[3] = -(double)x.x;
     }
     __syncthreads();
     PH(12);
-    for (int task = wave; task < ntasks; task += NT_RX / 64) {
-        const int mt = task >> 1, frame = task & 1;
-        const int row = 16 * mt + i, fi = row >> 1, cp = row & 1;
-        const bool rv = fi < nf;
-        const int c = kk & 1, n0 = kk >> 1;                               // this lane feeds k = (n = 2s + n0, c)
-        const double2 z1 = sh->rtw[rv ? fi : 0];                          // e^{-jw}
-        double zc = n0 ? z1.x : 1.0, zs = n0 ? z1.y : 0.0;                // z = e^{-jw n0}
-        const double rc = z1.x * z1.x - z1.y * z1.y, rs = 2.0 * z1.x * z1.y;   // e^{-2jw}: two samples per MFMA step
-        const float *xb = rxf + 2 * (t0 + (i < nt ? i : 0) + frame * RD_NMF + n0) + c;
-        f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll 4
-        for (int s = 0; s < 80; s++) {
-            const double2 pp = sh->pd[2 * s + n0];
-            const double qr = zc * pp.x + zs * pp.y, qi = zs * pp.x - zc * pp.y;      // e^{-jwn} conj(p[n])
-            double av = cp == 0 ? (c == 0 ? qr : -qi) : (c == 0 ? qi : qr);
-            av = rv ? av : 0.0;
-            const double bv = (double)xb[4 * s];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            const double nz = zc * rc - zs * rs; zs = zc * rs + zs * rc; zc = nz;
-        }
-        // C layout (f64 16x16x4): col = lane&15 (t), row = (lane>>4) + 4*reg.  Rows alternate re/im, so the lane 16
-        // positions away holds the other component of the same (f, t).
+    // C layout (f64 16x16x4): col = lane&15 (t), row = (lane>>4) + 4*reg.  Rows alternate re/im, so the lane 16
+    // positions away holds the other component of the same (f, t).
+    auto finish = [&](const f64x4 &acc, int mt, int frame) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const double mine = acc[r], other = __shfl_xor(mine, 16);
@@ -995,16 +1030,40 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
                     const double2 rt = sh->rrot[fo];
                     const double tr = re * rt.x - im * rt.y; im = re * rt.y + im * rt.x; re = tr;
                 }
-                if (fo < nf && i < nt) sh->dtr[frame][fo][i] = make_float2((float)re, (float)im);
+                if (fo < nf && i < nt) sh->dtr[(frame * nf + fo) * 16 + i] = make_float2((float)re, (float)im);
             }
         }
+    };
+    if (ntasks <= 6) {
+        // in-sync grid: 6 tiles x 2 halves of the sample range = 12 pieces; wave w takes piece w and (w < 4) piece w + 8,
+        // i.e. three pieces per SIMD.  Piece c < 6 = first half of tile c (kept in registers), c >= 6 = second half of
+        // tile c - 6 (handed over through LDS and added in a fixed order).
+        f64x4 mine = { 0.0, 0.0, 0.0, 0.0 };
+        if (wave < ntasks) mine = refine_tile(sh, wave >> 1, wave & 1, 0, 40, nf, nt, lane);
+        for (int c = wave + (wave < 6 ? 8 : 0); c < 12 && c >= 6; c += 8) {
+            const int task = c - 6;
+            if (task < ntasks) {
+                const f64x4 part = refine_tile(sh, task >> 1, task & 1, 40, 40, nf, nt, lane);
+#pragma unroll
+                for (int r = 0; r < 4; r++) sh->rpart[task][lane][r] = part[r];
+            }
+            if (wave >= 6) break;
+        }
+        __syncthreads();
+        if (wave < ntasks) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) mine[r] += sh->rpart[wave][lane][r];
+            finish(mine, wave >> 1, wave & 1);
+        }
+    } else {
+        for (int task = wave; task < ntasks; task += NT_RX / 64) finish(refine_tile(sh, task >> 1, task & 1, 0, 80, nf, nt, lane), task >> 1, task & 1);
     }
     __syncthreads();
     PH(13);
     float best = -1.0f; int bf = 0x7fffffff, bt = 0x7fffffff;
     for (int task = tid; task < nf * nt; task += NT_RX) {
         const int fi = task / nt, ti = task - fi * nt;
-        const float2 a = sh->dtr[0][fi][ti], b = sh->dtr[1][fi][ti];
+        const float2 a = sh->dtr[fi * 16 + ti], b = sh->dtr[(nf + fi) * 16 + ti];
         const float v = hypotf(a.x + b.x, a.y + b.y);                     // |Dt1 + Dt2| in complex64
         if (v > best || (v == best && (fi < bf || (fi == bf && ti < bt)))) { best = v; bf = fi; bt = ti; }
     }
@@ -1090,33 +1149,48 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // ---- complex_bpf.bpf (dsp.py:63-102)
         const float2 *xin = rxin + S->consumed_inv;
         for (int i = tid; i < ml; i += NT_RX) sh->xm[i] = sh->bmem[i];
-        float2 pvr[(RD_NINMAX + NT_RX - 1) / NT_RX];          // mixing phasors of this thread's samples (used twice)
-#pragma unroll
-        for (int q = 0; q < (RD_NINMAX + NT_RX - 1) / NT_RX; q++) {
-            const int i = tid + q * NT_RX;
-            pvr[q] = make_float2(0.0f, 0.0f);
-            if (i < nin) { pvr[q] = cmul(bpf_phase, ld2(tab->bpf_E, i)); sh->xm[ml + i] = cmul(xin[i], pvr[q]); }
-        }
+        for (int i = tid; i < nin; i += NT_RX) sh->xm[ml + i] = cmul(xin[i], cmul(bpf_phase, ld2(tab->bpf_E, i)));
         __syncthreads();
-        float2 filt[(RD_NINMAX + NT_RX - 1) / NT_RX];
+        PH(18);
+        // 101-tap FIR, three consecutive outputs per thread over a sliding register window (one LDS read per tap and
+        // thread instead of one per tap and output); taps accumulate in ascending order
+        float2 filt[3];
+        {
+            const int i0 = 3 * tid;
+            float ar[3] = { 0.0f, 0.0f, 0.0f }, ai[3] = { 0.0f, 0.0f, 0.0f };
+            if (i0 < nin) {
+#pragma unroll 2
+                for (int kb = 0; kb < 96; kb += 8) {
+                    float2 x[10]; float h[8];
 #pragma unroll
-        for (int q = 0; q < (RD_NINMAX + NT_RX - 1) / NT_RX; q++) {
-            const int i = tid + q * NT_RX;
-            float ar = 0.0f, ai = 0.0f;
-            if (i < nin) {
-                float pr[4] = { 0, 0, 0, 0 }, pi[4] = { 0, 0, 0, 0 };
-#pragma unroll 5
-                for (int k = 0; k < 100; k += 4) {
+                    for (int u = 0; u < 10; u++) x[u] = sh->xm[i0 + kb + u];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const float2 x = sh->xm[i + k + u]; const float h = sh->bpf_h[k + u]; pr[u] += x.x * h; pi[u] += x.y * h; }
+                    for (int u = 0; u < 8; u++) h[u] = sh->bpf_h[kb + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) { ar[j] = fmaf(x[u + j].x, h[u], ar[j]); ai[j] = fmaf(x[u + j].y, h[u], ai[j]); }
                 }
-                { const float2 x = sh->xm[i + 100]; const float h = sh->bpf_h[100]; pr[0] += x.x * h; pi[0] += x.y * h; }
-                ar = (pr[0] + pr[1]) + (pr[2] + pr[3]); ai = (pi[0] + pi[1]) + (pi[2] + pi[3]);
-                const float2 o = cmul(make_float2(ar, ai), cconj(pvr[q]));
-                ar = o.x; ai = o.y;
+                {
+                    float2 x[7]; float h[5];
+#pragma unroll
+                    for (int u = 0; u < 7; u++) x[u] = sh->xm[i0 + 96 + u];
+#pragma unroll
+                    for (int u = 0; u < 5; u++) h[u] = sh->bpf_h[96 + u];
+#pragma unroll
+                    for (int u = 0; u < 5; u++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) { ar[j] = fmaf(x[u + j].x, h[u], ar[j]); ai[j] = fmaf(x[u + j].y, h[u], ai[j]); }
+                }
             }
-            filt[q] = make_float2(ar, ai);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int i = i0 + j;
+                filt[j] = make_float2(0.0f, 0.0f);
+                if (i < nin) filt[j] = cmul(make_float2(ar[j], ai[j]), cconj(cmul(bpf_phase, ld2(tab->bpf_E, i))));   // mix back up
+            }
         }
+        PH(19);
         // new BPF memory = last 102 of [mem | new]; rx_buf shift (radae_rxe.py:196-197)
         float2 keep[(RD_RXBUF + NT_RX - 1) / NT_RX];
 #pragma unroll
@@ -1127,7 +1201,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 #pragma unroll
         for (int q = 0; q < (RD_RXBUF + NT_RX - 1) / NT_RX; q++) { const int i = tid + q * NT_RX; if (i + nin < RD_RXBUF) sh->rxb[i] = keep[q]; }
 #pragma unroll
-        for (int q = 0; q < (RD_NINMAX + NT_RX - 1) / NT_RX; q++) { const int i = tid + q * NT_RX; if (i < nin) sh->rxb[RD_RXBUF - nin + i] = filt[q]; }
+        for (int j = 0; j < 3; j++) { const int i = 3 * tid + j; if (i < nin) sh->rxb[RD_RXBUF - nin + i] = filt[j]; }
         if (tid < 102) sh->bmem[tid] = memv;
         if (tid == 0) {
             S->bpf_phase = cmul(bpf_phase, ld2(tab->bpf_E, nin - 1));
