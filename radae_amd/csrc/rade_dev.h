@@ -116,6 +116,24 @@ int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s);
 long rd_pack_weights(const float *W, int N, int K, float *out);
 long rd_packed_size(int N, int K);
 
+/* CoreDecoderStatefull.forward for the rows of one receiver round, one workgroup per stream (k_dec_stream): every
+ * layer of radae_base.py:388-430 back to back in one launch -- the streams are independent, so no grid-wide
+ * step separates the layers.  Same arithmetic (k interleave, reduction order) as the split-K GEMM + scan kernels. */
+typedef struct { const float *wp, *bias; int N, K; } rd_lin;
+typedef struct {
+    const float *z; long z_sb;                 /* [B][.][80] latent rows */
+    float *x; long x_sb;                       /* [B][1 + Tcap][736] DenseNet rows; x points at row 0 of stream 0, row -1 = conv history */
+    float *gi; long gi_sb;                     /* [B][.][288] */
+    float *hbuf; long hb_sb;                   /* [B][.][96] */
+    float *h[5];                               /* GRU states [B][96] */
+    float *out; long out_sb; int out_w;        /* [B][.][84] */
+    const int *n_rows; const int *reset; int reset_sb;
+    rd_lin dense1, gin[5], glu[5], conv[5], output;
+    const float *whh[5], *bhh[5];
+    int B;
+} rd_decs_args;
+int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s);
+
 /* GRU recurrence over T steps, one workgroup per stream.  gi[b][t][3H] = W_ih x + b_ih (from the GEMM).
  * h state [B][H] in/out.  Writes clamp(h_t) to out + b*out_sb + t*out_st. */
 typedef struct {
@@ -153,6 +171,7 @@ typedef struct {
     const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
     int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
     int max_calls;                                       /* call budget per stream per invocation */
+    int unit_budget, unit_cost[3];                       /* per-launch work budget; cost of a sync / cached search / uncached search call */
     int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
     rd_rx_stream *snap;                                  /* [B][RD_CHK_MAX] rollback snapshots */
     const float *fftG, *ffttw;                           /* rd_fft_tables_fill(): [RD_NFC][2048][2], [2048 + 64][2] */

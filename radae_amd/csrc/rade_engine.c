@@ -139,7 +139,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
     const size_t B = (size_t)h->B, T = (size_t)h->Tcap;
     /* up to a whole utterance per sync launch (RADE_ROUND_CALLS=1 decodes after every call: no speculated UW checks) */
-    h->R = getenv("RADE_ROUND_CALLS") ? atoi(getenv("RADE_ROUND_CALLS")) : 24;
+    h->R = getenv("RADE_ROUND_CALLS") ? atoi(getenv("RADE_ROUND_CALLS")) : 8;
     if (h->R < 1) h->R = 1;
     if (h->R > RD_RX_ROUND_MAX) h->R = RD_RX_ROUND_MAX;
     h->dec_rows = 3 * h->R;
@@ -396,6 +396,23 @@ static int decoder_layers(rade_batch *h, const float *z, int T, int Tio, int Tca
 
 static int decoder_round(rade_batch *h, int T, void *stream)
 {
+    if (!getenv("RADE_LAYERWISE_DECODER")) {          /* one launch: every layer for each stream's rows (k_dec_stream) */
+        rd_decs_args d;
+        memset(&d, 0, sizeof d);
+        const long DR = h->dec_rows;
+        d.z = h->zrows; d.z_sb = DR * RD_LATENT; d.x = h->dec_x + RD_DEC_W; d.x_sb = (1 + DR) * RD_DEC_W;
+        d.gi = h->dec_gi; d.gi_sb = DR * 288; d.hbuf = h->dec_hbuf; d.hb_sb = DR * 96;
+        d.out = h->feat84; d.out_sb = DR * h->feat_in; d.out_w = h->feat_in;
+        d.n_rows = h->rx_nrows; d.reset = h->rx_rowreset; d.reset_sb = h->dec_rows; d.B = h->B;
+#define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).N = (src).N; (dst).K = (src).K; } while (0)
+        LIN(d.dense1, h->dec_dense1); LIN(d.output, h->dec_output);
+        for (int l = 0; l < 5; l++) { LIN(d.gin[l], h->dec_gin[l]); LIN(d.glu[l], h->dec_glu[l]); LIN(d.conv[l], h->dec_conv[l]); d.whh[l] = h->dec_whh[l]; d.bhh[l] = h->dec_bhh[l]; d.h[l] = h->dec_h[l]; }
+#undef LIN
+        PROF_BEGIN(h, stream);
+        const int rc = rd_launch_dec_stream(&d, stream);
+        PROF_END(h, stream, RADE_PROF_GEMM, 0.0);
+        return rc;
+    }
     return decoder_layers(h, h->zrows, T, h->dec_rows, h->dec_rows, h->dec_x, h->dec_gi, h->dec_hbuf, h->dec_h, h->rx_nrows, h->rx_rowreset, h->feat84, stream);
 }
 
@@ -431,7 +448,12 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
-    sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.snap = h->rx_snap; sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+    sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows;
+    {   /* measured per-call cost ratio on MI355X (tools/phase_timing.py); RADE_UNIT_COSTS="sync,search,search2" overrides */
+        int c0 = 5, c1 = 8, c2 = 14;
+        if (getenv("RADE_UNIT_COSTS")) sscanf(getenv("RADE_UNIT_COSTS"), "%d,%d,%d", &c0, &c1, &c2);
+        sa.unit_cost[0] = c0; sa.unit_cost[1] = c1; sa.unit_cost[2] = c2; sa.unit_budget = c0 * h->R;
+    } sa.snap = h->rx_snap; sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     rd_post_args pa;
     memset(&pa, 0, sizeof pa);

@@ -308,6 +308,176 @@ extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
 }
 
 // =====================================================================================================
+// Per-stream fused decoder (receiver rounds): the whole DenseNet stack for one stream's rows in one workgroup of
+// eight wavefronts.  GEMMs split K over the waves exactly like k_gemm_splitk (k-blocks interleaved, partials reduced
+// in wave order), the recurrences run as in k_gru_scan<96>, so the results are bit-identical to the layer-wise path.
+// =====================================================================================================
+#define DS_NT 3
+struct DecShared {
+    float red[SK_WAVES][DS_NT][16][64];      // 96 KB split-K partials
+    __attribute__((aligned(16))) float hs[2][96];
+    int rst[RD_DEC_ROWS_MAX];
+};
+
+// Y[t, n] = act(sum_k [a0 | a1][t, k] W[n, k] + bias[n]) for t < Tb; a0 (K0 floats, may be 0) is the previous row's tap
+template <int NT>
+__device__ void ds_gemm(DecShared *sh, const float *a1, int a1_st, int K1, const float *a0, int a0_st, int K0, const int *rst,
+                        const rd_lin w, float *y, int y_st, int act, int Tb)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int ntt = (w.N + 31) >> 5;
+    const int nkb0 = K0 >> 3, nkb = nkb0 + (K1 >> 3);
+    const size_t wstep = (size_t)ntt * 256;
+    for (int r0 = 0; r0 < Tb; r0 += 32) {
+        const int t = min(r0 + (lane & 31), Tb - 1);
+        const float *p1 = a1 + (size_t)t * a1_st + 4 * half;
+        const float *p0 = nullptr;
+        if (K0) p0 = ((rst && rst[t]) ? g_zero_row : a0 + (size_t)t * a0_st) + 4 * half;
+        for (int nt0 = 0; nt0 < ntt; nt0 += NT) {
+            f32x16 acc[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+            const float *wbase = w.wp + ((size_t)nt0 * 64 + lane) * 4;
+#pragma unroll 2
+            for (int kb = wave; kb < nkb; kb += SK_WAVES) {
+                const float *p = kb < nkb0 ? p0 + kb * 8 : p1 + (kb - nkb0) * 8;
+                const f32x4 av = *(const f32x4 *)p;
+                f32x4 bv[NT];
+#pragma unroll
+                for (int i = 0; i < NT; i++) bv[i] = (nt0 + i < ntt) ? *(const f32x4 *)(wbase + kb * wstep + i * 256) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int i = 0; i < NT; i++)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[i][s], acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) sh->red[wave][i][j][lane] = acc[i][j];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int col = (nt0 + i) * 32 + (lane & 31);
+                if (nt0 + i >= ntt || col >= w.N) continue;
+                const float bias = w.bias ? w.bias[col] : 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const int j = wave * 2 + jj;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int ww = 0; ww < SK_WAVES; ww++) v += sh->red[ww][i][j][lane];
+                    const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                    if (tt >= Tb) continue;
+                    v += bias;
+                    if (act == 1) v = clamp1(tanhf(v));
+                    else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * sigmoid_f(v));
+                    y[(size_t)tt * y_st + col] = v;
+                }
+            }
+            __syncthreads();                     // partials are reused by the next tile group; y is read by the next layer
+        }
+    }
+}
+
+// GRU recurrence over Tb steps (k_gru_scan<96> inside a 512-thread workgroup: threads >= 384 only keep the barriers)
+__device__ void ds_scan(DecShared *sh, const float *gi_, int gi_st, const float *Whh, const float *bhh, float *hstate, float *out, int out_st, bool use_rst, int Tb)
+{
+    constexpr int H = 96, KP = H / 4;
+    const int tid = threadIdx.x;
+    const bool on = tid < 4 * H;
+    const int j = on ? tid >> 2 : 0, p = tid & 3;
+    float wr[KP], wz[KP], wn[KP];
+    {
+        const float *w0 = Whh + (size_t)j * H + p * KP;
+#pragma unroll
+        for (int k = 0; k < KP; k += 4) {
+            const f32x4 v0 = *(const f32x4 *)(w0 + k), v1 = *(const f32x4 *)(w0 + (size_t)H * H + k), v2 = *(const f32x4 *)(w0 + (size_t)2 * H * H + k);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { wr[k + u] = v0[u]; wz[k + u] = v1[u]; wn[k + u] = v2[u]; }
+        }
+    }
+    const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
+    float hj = hstate[j];
+    if (on && p == 0) sh->hs[0][j] = hj;
+    const float *gi = gi_ + (p < 3 ? p * H + j : j);
+    float g0 = 0.0f, g1 = 0.0f;
+    if (Tb > 0) g0 = gi[0];
+    if (Tb > 1) g1 = gi[gi_st];
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < Tb; t++) {
+        if (use_rst && sh->rst[t]) {                   // uniform over the workgroup
+            hj = 0.0f;
+            __syncthreads();
+            if (on && p == 0) sh->hs[cur][j] = 0.0f;
+            __syncthreads();
+        }
+        float g2 = 0.0f;
+        if (t + 2 < Tb) g2 = gi[(size_t)(t + 2) * gi_st];
+        float sr = 0.0f, sz = 0.0f, sn = 0.0f;
+        const float *hp = sh->hs[cur] + p * KP;
+#pragma unroll
+        for (int k = 0; k < KP; k += 4) {
+            const f32x4 hv = *(const f32x4 *)(hp + k);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { sr += wr[k + u] * hv[u]; sz += wz[k + u] * hv[u]; sn += wn[k + u] * hv[u]; }
+        }
+        sr += __shfl_xor(sr, 1); sz += __shfl_xor(sz, 1); sn += __shfl_xor(sn, 1);
+        sr += __shfl_xor(sr, 2); sz += __shfl_xor(sz, 2); sn += __shfl_xor(sn, 2);
+        const float gr = __shfl(g0, (tid & 60) + 0), gz = __shfl(g0, (tid & 60) + 1), gn = __shfl(g0, (tid & 60) + 2);
+        const float r = sigmoid_f((sr + br) + gr);
+        const float z = sigmoid_f((sz + bz) + gz);
+        const float n = tanhf(gn + (sn + bn) * r);
+        hj = (hj - n) * z + n;
+        if (on && p == 0) {
+            sh->hs[cur ^ 1][j] = hj;
+            out[(size_t)t * out_st + j] = clamp1(hj);
+        }
+        g0 = g1; g1 = g2;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (on && p == 0) hstate[j] = hj;
+}
+
+__global__ __launch_bounds__(64 * SK_WAVES) void k_dec_stream(rd_decs_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ds_raw[];
+    DecShared *sh = (DecShared *)ds_raw;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Tb = a.n_rows[b];
+    if (Tb <= 0) return;
+    const int W = RD_DEC_W;
+    const int *rstg = a.reset + (size_t)b * a.reset_sb;
+    for (int i = tid; i < Tb; i += blockDim.x) sh->rst[i] = rstg[i];
+    __syncthreads();
+    float *x = a.x + (size_t)b * a.x_sb;
+    float *gi = a.gi + (size_t)b * a.gi_sb, *hb = a.hbuf + (size_t)b * a.hb_sb;
+    ds_gemm<DS_NT>(sh, a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, nullptr, 0, 0, nullptr, a.dense1, x, W, 1, Tb);
+#pragma unroll 1
+    for (int l = 0; l < 5; l++) {
+        const int in = 96 + 128 * l, cin = in + 96;      // radae_base.py:378-386
+        ds_gemm<DS_NT>(sh, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb);
+        ds_scan(sh, gi, 288, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, hb, 96, true, Tb);
+        ds_gemm<DS_NT>(sh, hb, 96, 96, nullptr, 0, 0, nullptr, a.glu[l], x + in, W, 2, Tb);
+        ds_gemm<1>(sh, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
+    }
+    ds_gemm<DS_NT>(sh, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
+}
+
+extern "C" int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s)
+{
+    if (a->B <= 0) return 0;
+    static int attr_done = 0;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void *)k_dec_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DecShared)); attr_done = 1; }
+    hipLaunchKernelGGL(k_dec_stream, dim3(a->B), dim3(64 * SK_WAVES), sizeof(DecShared), (hipStream_t)s, *a);
+    return (int)hipGetLastError();
+}
+
+// =====================================================================================================
 // small data-movement kernels
 // =====================================================================================================
 __global__ void k_enc_pack(const float *features, float *xin, int B, int T)
@@ -897,12 +1067,14 @@ __device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int tA_lane, 
         const int sn = blk < 9 ? (blk + 1) * 8 : 0;            // last block re-reads block 0 (harmless) to stay branch-free
 #pragma unroll
         for (int u = 0; u < 8; u++) { na[u] = pa[(sn + u) * (4 * RD_NFC)]; nb1[u] = pbA[4 * (sn + u)]; nb2[u] = pbB[4 * (sn + u)]; }
+        __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of the matrix instructions
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const float a = ca[u] * sgn;
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb1[u], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb2[u], acc2, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; u++) { ca[u] = na[u]; cb1[u] = nb1[u]; cb2[u] = nb2[u]; }
     }
@@ -1131,6 +1303,10 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             if (S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls) go = 0;
             else if (S->consumed_inv + S->nin > avail) go = 0;
             else if (S->state == ST_SYNC && S->pending_valid > 0 && ((S->synced_count + 1) % 8) == 0 && S->n_chk >= RD_CHK_MAX) go = 0;   // no snapshot slot left
+            else {      // work units level a round's duration between searching (FFT correlator) and synchronised streams
+                const int cost = S->state == ST_SYNC ? a.unit_cost[0] : (S->dt_valid ? a.unit_cost[1] : a.unit_cost[2]);
+                if (S->units > 0 && S->units + cost > a.unit_budget) go = 0; else S->units += cost;
+            }
             S->go = go;
             S->state_before = S->state; S->nin_before = S->nin;
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
