@@ -34,7 +34,6 @@ extern "C" {
 #define RD_ENC_IN   88    /* 84 padded to a multiple of 8 */
 #define RD_RX_ROUND_MAX 128   /* capacity: do_radae_rx calls per stream per sync-kernel launch (engine picks R <= this) */
 #define RD_DEC_ROWS_MAX (3 * RD_RX_ROUND_MAX)
-#define RD_CHK_MAX 16          /* speculated UW checks per round (one per 8 synchronised frames) */
 
 /* constant tables, one copy in HBM (filled by rade_tables.c) */
 typedef struct {
@@ -68,7 +67,7 @@ typedef struct {
     float rowsum1[RD_NMF], rowsum2[RD_NMF];   /* sum_f |Dt1[t,f]|, |Dt2[t,f]|: all check_pilots ever reads back */
 } rd_rx_stream;
 
-/* per-stream, per-round hand-off from the sync kernel to the decoder kernels and the post kernel */
+/* per-stream, per-launch bookkeeping of the receiver kernel (row flags for its decoder stage, per-call trace indices) */
 typedef struct {
     int n_calls;                        /* calls made this round */
     int n_rows;                         /* decoder steps emitted (3 per valid call) */
@@ -78,13 +77,8 @@ typedef struct {
     int call_ret[RD_RX_ROUND_MAX];      /* bit0 valid bit1 eoo */
     int call_row_lo[RD_RX_ROUND_MAX], call_row_hi[RD_RX_ROUND_MAX]; /* trace patching of uw_errors */
     int call_trace_idx[RD_RX_ROUND_MAX];
-    /* UW checks passed speculatively (their frames were not decoded yet): verified by k_rx_post, which rolls the
-     * stream back to snapshot k when window k really had more than 7 aux-bit errors (radae_rxe.py:220-224) */
-    int n_chk, chk_call[RD_CHK_MAX], chk_from[RD_CHK_MAX], chk_row[RD_CHK_MAX], chk_base[RD_CHK_MAX];
-    int chk_acc[RD_CHK_MAX][8];         /* post-call consumed, calls, valid, eoo, n_rows, n_calls, has_eoo, uw_errors-of-check-frame placeholder */
-    int blocked;                        /* unused */
-    int out_base;                       /* valid frames this invocation before this round (features_out slot) */
-    int pad[2];
+    int out_base;                       /* valid frames of this invocation written to features_out so far */
+    int pad[3];
 } rd_rx_round;
 
 /* same layout as rade_rx_trace in include/rade_batch.h */
@@ -115,24 +109,6 @@ int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s);
 /* packs W[N][K] (row-major) into the fragment order the GEMM kernel streams; returns #floats (K,N padded) */
 long rd_pack_weights(const float *W, int N, int K, float *out);
 long rd_packed_size(int N, int K);
-
-/* CoreDecoderStatefull.forward for the rows of one receiver round, one workgroup per stream (k_dec_stream): every
- * layer of radae_base.py:388-430 back to back in one launch -- the streams are independent, so no grid-wide
- * step separates the layers.  Same arithmetic (k interleave, reduction order) as the split-K GEMM + scan kernels. */
-typedef struct { const float *wp, *bias; int N, K; } rd_lin;
-typedef struct {
-    const float *z; long z_sb;                 /* [B][.][80] latent rows */
-    float *x; long x_sb;                       /* [B][1 + Tcap][736] DenseNet rows; x points at row 0 of stream 0, row -1 = conv history */
-    float *gi; long gi_sb;                     /* [B][.][288] */
-    float *hbuf; long hb_sb;                   /* [B][.][96] */
-    float *h[5];                               /* GRU states [B][96] */
-    float *out; long out_sb; int out_w;        /* [B][.][84] */
-    const int *n_rows; const int *reset; int reset_sb;
-    rd_lin dense1, gin[5], glu[5], conv[5], output;
-    const float *whh[5], *bhh[5];
-    int B;
-} rd_decs_args;
-int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s);
 
 /* GRU recurrence over T steps, one workgroup per stream.  gi[b][t][3H] = W_ih x + b_ih (from the GEMM).
  * h state [B][H] in/out.  Writes clamp(h_t) to out + b*out_sb + t*out_st. */
@@ -166,6 +142,24 @@ typedef struct {
 } rd_chan_args;
 int rd_launch_channel(const rd_chan_args *a, rd_stream_t s);
 
+/* CoreDecoderStatefull.forward for the rows of one receiver round, one workgroup per stream (k_dec_stream): every
+ * layer of radae_base.py:388-430 back to back in one launch -- the streams are independent, so no grid-wide
+ * step separates the layers.  Same arithmetic (k interleave, reduction order) as the split-K GEMM + scan kernels. */
+typedef struct { const float *wp, *bias; int N, K; } rd_lin;
+typedef struct {
+    const float *z; long z_sb;                 /* [B][.][80] latent rows */
+    float *x; long x_sb;                       /* [B][1 + Tcap][736] DenseNet rows; x points at row 0 of stream 0, row -1 = conv history */
+    float *gi; long gi_sb;                     /* [B][.][288] */
+    float *hbuf; long hb_sb;                   /* [B][.][96] */
+    float *h[5];                               /* GRU states [B][96] */
+    float *out; long out_sb; int out_w;        /* [B][.][84] */
+    const int *n_rows; const int *reset; int reset_sb;
+    rd_lin dense1, gin[5], glu[5], conv[5], output;
+    const float *whh[5], *bhh[5];
+    int B;
+} rd_decs_args;
+int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s);
+
 typedef struct {
     const rd_tables *tab; rd_rx_stream *st; rd_rx_round *round;
     const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
@@ -173,28 +167,21 @@ typedef struct {
     int max_calls;                                       /* call budget per stream per invocation */
     int unit_budget, unit_cost[3];                       /* per-launch work budget; cost of a sync / cached search / uncached search call */
     int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
-    rd_rx_stream *snap;                                  /* [B][RD_CHK_MAX] rollback snapshots */
+    rd_decs_args dec;                                    /* the decoder runs inside the stream's workgroup (rx_decode_pending) */
+    float *features_out; long feat_stride;               /* [B][cap][432] */
     const float *fftG, *ffttw;                           /* rd_fft_tables_fill(): [RD_NFC][2048][2], [2048 + 64][2] */
     float *zrows;                                        /* [B][dec_rows][80] */
-    int *n_rows; int *row_reset;                         /* flat [B], [B][dec_rows] copies for the decoder kernels */
     float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */
     int *status;                                         /* [B][4]: nin, sync, snr_int, state */
     float *eoo_out;                                      /* [B][180] or NULL */
     rd_rx_trace *trace; float *trace_z; int trace_cap;   /* optional */
-    int *progress;                                       /* [4]: calls made this round, max rows, unused, unused */
+    int *progress;                                       /* [4]: calls made by this launch, unused x3 */
     int B;
 } rd_sync_args;
 int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
 
 int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
 
-typedef struct {
-    rd_rx_stream *st; rd_rx_round *round; const float *feat84;   /* [B][dec_rows][84] */
-    rd_rx_stream *snap; int *acc; int *n_rows; int *progress; int *status; int dec_rows;
-    float *features_out; long feat_stride; rd_rx_trace *trace; int trace_cap;
-    int B;
-} rd_post_args;
-int rd_launch_rx_post(const rd_post_args *a, rd_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,6 @@ typedef struct { float *wp, *bias; int N, K; } dev_lin;
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
-    rd_rx_stream *rx_snap;
     float *fftG, *ffttw;
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
@@ -139,10 +138,14 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
     const size_t B = (size_t)h->B, T = (size_t)h->Tcap;
     /* up to a whole utterance per sync launch (RADE_ROUND_CALLS=1 decodes after every call: no speculated UW checks) */
-    h->R = getenv("RADE_ROUND_CALLS") ? atoi(getenv("RADE_ROUND_CALLS")) : 8;
+    h->R = getenv("RADE_ROUND_CALLS") ? atoi(getenv("RADE_ROUND_CALLS")) : RD_RX_ROUND_MAX;
     if (h->R < 1) h->R = 1;
     if (h->R > RD_RX_ROUND_MAX) h->R = RD_RX_ROUND_MAX;
-    h->dec_rows = 3 * h->R;
+    /* rows a stream may hold before its decoder stage runs: 8 frames wait for a unique-word check, up to 7 more can be
+     * left over from before a loss of sync */
+    h->dec_rows = getenv("RADE_DEC_ROWS") ? atoi(getenv("RADE_DEC_ROWS")) : 48;
+    if (h->dec_rows < 3) h->dec_rows = 3;
+    if (h->dec_rows > RD_DEC_ROWS_MAX) h->dec_rows = RD_DEC_ROWS_MAX;
     const size_t DR = (size_t)h->dec_rows;
 
     rd_tables *tab = malloc(sizeof *tab);
@@ -193,8 +196,6 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->dec_gi = dev_zeros(sizeof(float) * B * DR * 288);
     h->dec_hbuf = dev_zeros(sizeof(float) * B * DR * 96);
     h->feat84 = dev_zeros(sizeof(float) * B * DR * 84);
-    h->rx_snap = dev_zeros(sizeof(rd_rx_stream) * B * RD_CHK_MAX);
-    if (!h->rx_snap) goto fail;
     h->dec2_x = dev_zeros(sizeof(float) * B * (1 + T) * RD_DEC_W);
     h->dec2_gi = dev_zeros(sizeof(float) * B * T * 288);
     h->dec2_hbuf = dev_zeros(sizeof(float) * B * T * 96);
@@ -245,7 +246,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_snap, h->fftG, h->ffttw };
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -394,26 +395,19 @@ static int decoder_layers(rade_batch *h, const float *z, int T, int Tio, int Tca
     return e;
 }
 
-static int decoder_round(rade_batch *h, int T, void *stream)
+/* pointers of the receiver's in-kernel decoder stage (rx_decode_pending -> ds_layers) */
+static void fill_dec_args(const rade_batch *h, rd_decs_args *d)
 {
-    if (!getenv("RADE_LAYERWISE_DECODER")) {          /* one launch: every layer for each stream's rows (k_dec_stream) */
-        rd_decs_args d;
-        memset(&d, 0, sizeof d);
-        const long DR = h->dec_rows;
-        d.z = h->zrows; d.z_sb = DR * RD_LATENT; d.x = h->dec_x + RD_DEC_W; d.x_sb = (1 + DR) * RD_DEC_W;
-        d.gi = h->dec_gi; d.gi_sb = DR * 288; d.hbuf = h->dec_hbuf; d.hb_sb = DR * 96;
-        d.out = h->feat84; d.out_sb = DR * h->feat_in; d.out_w = h->feat_in;
-        d.n_rows = h->rx_nrows; d.reset = h->rx_rowreset; d.reset_sb = h->dec_rows; d.B = h->B;
+    memset(d, 0, sizeof *d);
+    const long DR = h->dec_rows;
+    d->z = h->zrows; d->z_sb = DR * RD_LATENT; d->x = h->dec_x + RD_DEC_W; d->x_sb = (1 + DR) * RD_DEC_W;
+    d->gi = h->dec_gi; d->gi_sb = DR * 288; d->hbuf = h->dec_hbuf; d->hb_sb = DR * 96;
+    d->out = h->feat84; d->out_sb = DR * h->feat_in; d->out_w = h->feat_in;
+    d->n_rows = h->rx_nrows; d->reset = h->rx_rowreset; d->reset_sb = h->dec_rows; d->B = h->B;
 #define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).N = (src).N; (dst).K = (src).K; } while (0)
-        LIN(d.dense1, h->dec_dense1); LIN(d.output, h->dec_output);
-        for (int l = 0; l < 5; l++) { LIN(d.gin[l], h->dec_gin[l]); LIN(d.glu[l], h->dec_glu[l]); LIN(d.conv[l], h->dec_conv[l]); d.whh[l] = h->dec_whh[l]; d.bhh[l] = h->dec_bhh[l]; d.h[l] = h->dec_h[l]; }
+    LIN(d->dense1, h->dec_dense1); LIN(d->output, h->dec_output);
+    for (int l = 0; l < 5; l++) { LIN(d->gin[l], h->dec_gin[l]); LIN(d->glu[l], h->dec_glu[l]); LIN(d->conv[l], h->dec_conv[l]); d->whh[l] = h->dec_whh[l]; d->bhh[l] = h->dec_bhh[l]; d->h[l] = h->dec_h[l]; }
 #undef LIN
-        PROF_BEGIN(h, stream);
-        const int rc = rd_launch_dec_stream(&d, stream);
-        PROF_END(h, stream, RADE_PROF_GEMM, 0.0);
-        return rc;
-    }
-    return decoder_layers(h, h->zrows, T, h->dec_rows, h->dec_rows, h->dec_x, h->dec_gi, h->dec_hbuf, h->dec_h, h->rx_nrows, h->rx_rowreset, h->feat84, stream);
 }
 
 int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *features_out_dev, int reset_state, void *stream)
@@ -452,14 +446,13 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     {   /* measured per-call cost ratio on MI355X (tools/phase_timing.py); RADE_UNIT_COSTS="sync,search,search2" overrides */
         int c0 = 5, c1 = 8, c2 = 14;
         if (getenv("RADE_UNIT_COSTS")) sscanf(getenv("RADE_UNIT_COSTS"), "%d,%d,%d", &c0, &c1, &c2);
-        sa.unit_cost[0] = c0; sa.unit_cost[1] = c1; sa.unit_cost[2] = c2; sa.unit_budget = c0 * h->R;
-    } sa.snap = h->rx_snap; sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.zrows = h->zrows; sa.n_rows = h->rx_nrows; sa.row_reset = h->rx_rowreset; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+        sa.unit_cost[0] = c0; sa.unit_cost[1] = c1; sa.unit_cost[2] = c2; sa.unit_budget = getenv("RADE_UNIT_COSTS") ? c0 * h->R : 0x3fffffff;   /* no budget by default: one launch does it all */
+    }
+    sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
-    rd_post_args pa;
-    memset(&pa, 0, sizeof pa);
-    pa.st = h->rx_st; pa.round = h->rx_round; pa.feat84 = h->feat84; pa.features_out = features_out_dev; pa.feat_stride = feat_stride;
-    pa.trace = h->trace; pa.trace_cap = h->trace_cap; pa.B = B;
-    pa.snap = h->rx_snap; pa.acc = h->rx_acc; pa.n_rows = h->rx_nrows; pa.progress = h->rx_progress; pa.status = h->rx_status; pa.dec_rows = h->dec_rows;
+    fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
+    /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only
+     * continues when a stream ran into the per-launch call limit */
     for (;;) {
         CHK(hipMemsetAsync(h->rx_progress, 0, sizeof(int) * 4, st));
         PROF_BEGIN(h, st);
@@ -467,14 +460,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
         PROF_END(h, st, RADE_PROF_SYNC, 0.0);
         CHK(hipMemcpyAsync(hs, h->rx_progress, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
         CHK(hipStreamSynchronize(st));
-        if (hs[0] == 0) break;                  /* no stream could make a call: out of samples or budget */
-        if (hs[1] > 0) {
-            if (decoder_round(h, hs[1] < h->dec_rows ? hs[1] : h->dec_rows, st)) goto fail;
-            PROF_BEGIN(h, st);
-            if (rd_launch_rx_post(&pa, st)) goto fail;
-            PROF_END(h, st, RADE_PROF_POST, 0.0);
-            if (rd_launch_carry_rows(h->dec_x, B, h->dec_rows, RD_DEC_W, 1, 0, h->rx_nrows, st)) goto fail;
-        }
+        if (hs[0] == 0 || hs[1] == 0) break;    /* nothing done, or no stream stopped at the per-launch limit */
     }
     if (status_host) {
         int *acc = hs + 8, *sts = hs + 8 + 4 * B;

@@ -317,6 +317,7 @@ struct DecShared {
     float red[SK_WAVES][DS_NT][16][64];      // 96 KB split-K partials
     __attribute__((aligned(16))) float hs[2][96];
     int rst[RD_DEC_ROWS_MAX];
+    int err[RD_DEC_ROWS_MAX];                // receiver: aux-bit (UW) decisions of the decoded rows
 };
 
 // Y[t, n] = act(sum_k [a0 | a1][t, k] W[n, k] + bias[n]) for t < Tb; a0 (K0 floats, may be 0) is the previous row's tap
@@ -443,17 +444,10 @@ __device__ void ds_scan(DecShared *sh, const float *gi_, int gi_st, const float 
     if (on && p == 0) hstate[j] = hj;
 }
 
-__global__ __launch_bounds__(64 * SK_WAVES) void k_dec_stream(rd_decs_args a)
+// all decoder layers for rows [0, Tb) of stream b; sh->rst[] holds the per-row reset flags
+__device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ds_raw[];
-    DecShared *sh = (DecShared *)ds_raw;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int Tb = a.n_rows[b];
-    if (Tb <= 0) return;
     const int W = RD_DEC_W;
-    const int *rstg = a.reset + (size_t)b * a.reset_sb;
-    for (int i = tid; i < Tb; i += blockDim.x) sh->rst[i] = rstg[i];
-    __syncthreads();
     float *x = a.x + (size_t)b * a.x_sb;
     float *gi = a.gi + (size_t)b * a.gi_sb, *hb = a.hbuf + (size_t)b * a.hb_sb;
     ds_gemm<DS_NT>(sh, a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, nullptr, 0, 0, nullptr, a.dense1, x, W, 1, Tb);
@@ -466,6 +460,19 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_dec_stream(rd_decs_args a)
         ds_gemm<1>(sh, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
     }
     ds_gemm<DS_NT>(sh, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
+}
+
+__global__ __launch_bounds__(64 * SK_WAVES) void k_dec_stream(rd_decs_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ds_raw[];
+    DecShared *sh = (DecShared *)ds_raw;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int Tb = a.n_rows[b];
+    if (Tb <= 0) return;
+    const int *rstg = a.reset + (size_t)b * a.reset_sb;
+    for (int i = tid; i < Tb; i += blockDim.x) sh->rst[i] = rstg[i];
+    __syncthreads();
+    ds_layers(sh, a, b, Tb);
 }
 
 extern "C" int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s)
@@ -788,8 +795,8 @@ extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out,
 struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
     uint32_t lcg;
-    int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, blocked, pending_valid, out_base;
-    int go, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync, units, n_chk, snap_now;
+    int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
+    int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync, units;
     float snr_est, mag; float2 bpf_phase;
     double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
 };
@@ -1261,6 +1268,54 @@ __device__ __forceinline__ void rx_corr_term(const RxShared *sh, int t0, double 
 // and proved fragile under -O3.)
 static_assert(sizeof(RxShared) <= 160 * 1024, "k_rx_sync working set must fit the 160 KiB LDS of a CU");
 
+// Decoder + output stage for the rows a stream has pending, run by the stream's own workgroup: CoreDecoder over the
+// rows (ds_layers), rows -> 36-float feature frames (rade_api.c:488-513), aux-bit (UW) error accounting
+// (radae_rxe.py:300-319) and the per-call trace.  The decoder's LDS scratch overlays the demod / correlator tables,
+// which are reloaded on the next synchronised call.
+__device__ __forceinline__ void rx_decode_pending(RxShared *sh, const rd_sync_args &a, int b)
+{
+    static_assert(sizeof(DecShared) <= sizeof(sh->wfwd) + sizeof(sh->pw) + sizeof(sh->dtr), "decoder scratch must fit the table area");
+    RxScalars *S = &sh->S;
+    DecShared *ds = (DecShared *)&sh->wfwd[0][0];
+    rd_rx_round *rnd = a.round + b;
+    const int tid = threadIdx.x;
+    const int Tb = S->n_rows;
+    for (int i = tid; i < Tb; i += NT_RX) ds->rst[i] = rnd->row_reset[i];
+    if (tid == 0) S->lds_sync = 0;
+    __syncthreads();
+    ds_layers(ds, a.dec, b, Tb);
+    const float *f84 = a.dec.out + (size_t)b * a.dec.out_sb;
+    for (int r = tid; r < Tb; r += NT_RX) ds->err[r] = f84[r * 84 + 20] > 0.0f ? 1 : 0;      // first aux symbol of each group of 4
+    // valid frame v (3 rows) -> 12 feature frames x 36 floats, 20 used + 16 zeros
+    float *out = a.features_out + (size_t)b * a.feat_stride + (size_t)S->out_base * RD_FEAT_MF;
+    for (int i = tid; i < (Tb / 3) * RD_FEAT_MF; i += NT_RX) {
+        const int fr = i / 36, j = i - fr * 36;          // fr = 10 ms frame index within this batch
+        const int row = fr >> 2, sub = fr & 3;
+        out[i] = j < 20 ? f84[row * 84 + sub * 21 + j] : 0.0f;
+    }
+    {   // conv history of the next batch = the last row
+        float *x = a.dec.x + (size_t)b * a.dec.x_sb;
+        for (int i = tid; i < RD_DEC_W; i += NT_RX) x[i - RD_DEC_W] = x[(size_t)(Tb - 1) * RD_DEC_W + i];
+    }
+    __syncthreads();
+    if (a.trace) {
+        for (int c = S->batch_call0 + tid; c < S->n_calls; c += NT_RX) {
+            const int idx = rnd->call_trace_idx[c];
+            if (idx >= a.trace_cap) continue;
+            int e = 0;
+            for (int r = rnd->call_row_lo[c]; r < rnd->call_row_hi[c]; r++) e += ds->err[r];
+            a.trace[(size_t)b * a.trace_cap + idx].uw_errors += e;
+        }
+    }
+    if (tid == 0) {
+        int add = 0;
+        for (int r = S->uw_from_row; r < Tb; r++) add += ds->err[r];
+        S->uw_errors += add;
+        S->out_base += Tb / 3; S->n_rows = 0; S->uw_from_row = 0; S->pending_valid = 0; S->batch_call0 = S->n_calls; S->need_decode = 0;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1286,14 +1341,14 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->Dthresh = st->Dthresh; S->Dtmax12 = st->Dtmax12; S->Dtmax12_eoo = st->Dtmax12_eoo; S->snr_est = st->snr_est;
         S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
-        S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->blocked = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->units = 0; S->n_chk = 0; S->snap_now = -1;
+        S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
+        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->units = 0; S->need_decode = 0; S->batch_call0 = 0;
     }
     const int avail = a.avail[b];
     __syncthreads();
     PH_T0(); PH(0);
 
-    for (int it = 0; it < a.round_calls; it++) {   // <= round_calls calls: sizes of the per-round hand-off arrays
+    for (int it = 0; it <= a.round_calls; it++) {  // <= round_calls calls (sizes of the per-launch arrays); the extra pass decodes what is pending
         // opaque per-iteration copy: keeps the compiler from hoisting every thread-index address computation of the
         // loop body into registers that stay live across the whole call (they starve the FFT correlator of registers)
         int tid = threadIdx.x; asm volatile("" : "+v"(tid));
@@ -1302,16 +1357,20 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             int go = 1;
             if (S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls) go = 0;
             else if (S->consumed_inv + S->nin > avail) go = 0;
-            else if (S->state == ST_SYNC && S->pending_valid > 0 && ((S->synced_count + 1) % 8) == 0 && S->n_chk >= RD_CHK_MAX) go = 0;   // no snapshot slot left
             else {      // work units level a round's duration between searching (FFT correlator) and synchronised streams
                 const int cost = S->state == ST_SYNC ? a.unit_cost[0] : (S->dt_valid ? a.unit_cost[1] : a.unit_cost[2]);
                 if (S->units > 0 && S->units + cost > a.unit_budget) go = 0; else S->units += cost;
             }
+            // the decoder runs right here, in this workgroup, when its output is needed: before a unique-word check
+            // (radae_rxe.py:220-224 looks at the aux bits of the 8 frames before this one) or when the row buffer is full
+            // ... or when this launch ends for the stream (out of samples, call limit)
+            S->need_decode = S->n_rows > 0 && (!go || (S->state == ST_SYNC && ((S->synced_count + 1) % 8) == 0) || S->n_rows + 3 > a.dec_rows);
             S->go = go;
             S->state_before = S->state; S->nin_before = S->nin;
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
         }
         __syncthreads();
+        if (S->need_decode) rx_decode_pending(sh, a, b);
         if (!S->go) break;
         const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
         const float2 bpf_phase = S->bpf_phase;
@@ -1474,15 +1533,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 if (t2 < RD_M) { nn = RD_NMF - RD_M; t2 += RD_M; }
                 S->nin = nn; S->tmax = t2;
                 S->synced_count++;                                              // :220-224
-                if (S->synced_count % 8 == 0) {
-                    if (S->uw_errors > 7) S->uw_fail = 1;   // the decoded part of the window already decides
-                    else if (S->n_rows > S->uw_from_row) {  // part of this window is not decoded yet: pass speculatively, k_rx_post verifies
-                        const int k = S->n_chk++;
-                        rnd->chk_call[k] = S->n_calls; rnd->chk_from[k] = S->uw_from_row; rnd->chk_row[k] = S->n_rows; rnd->chk_base[k] = S->uw_errors;
-                        S->snap_now = k;
-                    }
-                    S->uw_errors = 0; S->uw_from_row = S->n_rows;
-                }
+                if (S->synced_count % 8 == 0) { if (S->uw_errors > 7) S->uw_fail = 1; S->uw_errors = 0; S->uw_from_row = S->n_rows; }
             }
             __syncthreads();
             PH(6);
@@ -1619,7 +1670,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const int ret = S->valid_output | (S->endofover << 1);
             const int call_idx = S->mf - 2;                   // 0-based index of this call since reset
             if (S->valid_output) {
-                for (int k = 0; k < 3; k++) { const int rf = (k == 0) ? S->dec_reset_pending : 0; rnd->row_reset[S->n_rows + k] = rf; a.row_reset[b * a.dec_rows + S->n_rows + k] = rf; }
+                for (int k = 0; k < 3; k++) { const int rf = (k == 0) ? S->dec_reset_pending : 0; rnd->row_reset[S->n_rows + k] = rf; }
                 S->dec_reset_pending = 0; S->n_rows += 3; S->pending_valid++; S->valid_inv++;
             }
             if (S->endofover) { S->has_eoo = 1; S->eoo_inv++; }
@@ -1634,27 +1685,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             S->n_calls = nc + 1; S->calls_inv++;
         }
         __syncthreads();
-        if (S->snap_now >= 0) {
-            // rollback point of a speculated UW check: the state this call would have left had the check FAILED, i.e.
-            // identical except next_state = search and nin = Nmf (radae_rxe.py:289-296)
-            const int k = S->snap_now;
-            rd_rx_stream *sp = a.snap + (size_t)b * RD_CHK_MAX + k;
-            for (int i = tid; i < RD_RXBUF; i += NT_RX) { sp->rx_buf[i][0] = sh->rxb[i].x; sp->rx_buf[i][1] = sh->rxb[i].y; }
-            for (int i = tid; i < RD_NMF; i += NT_RX) { sp->rowsum1[i] = sh->rowsum1[i]; sp->rowsum2[i] = sh->rowsum2[i]; }
-            for (int i = tid; i < 102; i += NT_RX) { sp->bpf_mem[i][0] = sh->bmem[i].x; sp->bpf_mem[i][1] = sh->bmem[i].y; }
-            if (tid == 0) {
-                sp->state = ST_SEARCH; sp->nin = RD_NMF; sp->tmax = S->tmax; sp->tmax_candidate = S->tmax_candidate; sp->valid_count = S->valid_count;
-                sp->uw_errors = 0; sp->synced_count = S->synced_count; sp->mf = S->mf; sp->f_ind_max = S->f_ind_max;
-                sp->dec_reset_pending = S->dec_reset_pending; sp->bpf_mem_len = S->bpf_mem_len; sp->has_eoo = S->has_eoo; sp->lcg = S->lcg; sp->dt_valid = 0;
-                sp->fmax = S->fmax; sp->foff_err = S->foff_err; sp->rx_phase[0] = S->rph_r; sp->rx_phase[1] = S->rph_i;
-                sp->Dthresh = S->Dthresh; sp->Dtmax12 = S->Dtmax12; sp->Dtmax12_eoo = S->Dtmax12_eoo; sp->snr_est = S->snr_est;
-                sp->bpf_phase[0] = S->bpf_phase.x; sp->bpf_phase[1] = S->bpf_phase.y; sp->consumed = st->consumed + S->consumed_round;
-                int *ca = rnd->chk_acc[k];
-                ca[0] = S->consumed_inv; ca[1] = S->calls_inv; ca[2] = S->valid_inv; ca[3] = S->eoo_inv; ca[4] = S->n_rows; ca[5] = S->n_calls; ca[6] = S->has_eoo; ca[7] = 0;
-                S->snap_now = -1;
-            }
-            __syncthreads();
-        }
         PH(10);
     }
 
@@ -1672,12 +1702,11 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         st->Dthresh = S->Dthresh; st->Dtmax12 = S->Dtmax12; st->Dtmax12_eoo = S->Dtmax12_eoo; st->snr_est = S->snr_est;
         st->bpf_phase[0] = S->bpf_phase.x; st->bpf_phase[1] = S->bpf_phase.y; st->consumed += S->consumed_round;
         rnd->n_calls = S->n_calls; rnd->n_rows = S->n_rows; rnd->uw_from_row = S->uw_from_row; rnd->consumed = S->consumed_round;
-        rnd->blocked = 0; rnd->out_base = S->out_base; rnd->n_chk = S->n_chk;
+        rnd->out_base = S->out_base;
         a.acc[b * 4 + 0] = S->consumed_inv; a.acc[b * 4 + 1] = S->calls_inv; a.acc[b * 4 + 2] = S->valid_inv; a.acc[b * 4 + 3] = S->eoo_inv;
-        a.n_rows[b] = S->n_rows;
         a.status[b * 4 + 0] = S->nin; a.status[b * 4 + 1] = S->state == ST_SYNC; a.status[b * 4 + 2] = (int)S->snr_est; a.status[b * 4 + 3] = S->state;
         if (S->n_calls) atomicAdd(&a.progress[0], S->n_calls);
-        if (S->n_rows) atomicMax(&a.progress[1], S->n_rows);
+        if (S->calls_inv < a.max_calls && S->consumed_inv + S->nin <= avail) atomicAdd(&a.progress[1], 1);   // stopped at the per-launch limit
     }
 }
 
@@ -1709,78 +1738,3 @@ extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, doubl
     return (int)hipGetLastError();
 }
 
-// decoder output rows -> feature frames + UW accounting (rade_api.c:488-513, radae_rxe.py:300-319), and the
-// verification of UW checks the sync kernel passed speculatively.  A window that really had > 7 aux-bit errors
-// rolls its stream back to the snapshot taken right after that check (state = search), discarding later calls.
-__global__ __launch_bounds__(256) void k_rx_post(rd_post_args a)
-{
-    const int b = blockIdx.x, tid = threadIdx.x;
-    rd_rx_round *rnd = a.round + b;
-    rd_rx_stream *st = a.st + b;
-    int n_rows = rnd->n_rows;
-    __shared__ int err[RD_DEC_ROWS_MAX];
-    __shared__ int s_fail, s_rows;
-    if (n_rows == 0) return;
-    const float *f84 = a.feat84 + (size_t)b * a.dec_rows * 84;
-    for (int r = tid; r < n_rows; r += blockDim.x) err[r] = f84[r * 84 + 20] > 0.0f ? 1 : 0;      // first aux symbol of each group of 4
-    __syncthreads();
-    if (tid == 0) {
-        int fail = -1;
-        for (int k = 0; k < rnd->n_chk && fail < 0; k++) {
-            int e = rnd->chk_base[k];
-            for (int r = rnd->chk_from[k]; r < rnd->chk_row[k]; r++) e += err[r];
-            if (e > 7) fail = k;
-        }
-        s_fail = fail; s_rows = fail >= 0 ? rnd->chk_acc[fail][4] : n_rows;
-    }
-    __syncthreads();
-    const int fail = s_fail;
-    n_rows = s_rows;
-    // scatter: valid frame v (3 rows) -> 12 feature frames x 36 floats, 20 used + 16 zeros
-    float *out = a.features_out + (size_t)b * a.feat_stride + (size_t)rnd->out_base * RD_FEAT_MF;
-    for (int i = tid; i < (n_rows / 3) * RD_FEAT_MF; i += blockDim.x) {
-        const int fr = i / 36, j = i - fr * 36;          // fr = 10 ms frame index within this round's output
-        const int row = fr >> 2, sub = fr & 3;
-        out[i] = j < 20 ? f84[row * 84 + sub * 21 + j] : 0.0f;
-    }
-    if (fail >= 0) {                                     // restore the rollback snapshot (all threads copy, 33 KB)
-        const rd_rx_stream *sp = a.snap + (size_t)b * RD_CHK_MAX + fail;
-        const int *src = (const int *)sp; int *dst = (int *)st;
-        for (int i = tid; i < (int)(sizeof(rd_rx_stream) / 4); i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const int n_calls = fail >= 0 ? rnd->chk_acc[fail][5] : rnd->n_calls;
-        if (fail >= 0) {
-            const int *ca = rnd->chk_acc[fail];
-            a.acc[b * 4 + 0] = ca[0]; a.acc[b * 4 + 1] = ca[1]; a.acc[b * 4 + 2] = ca[2]; a.acc[b * 4 + 3] = ca[3];
-            int add = 0;                                 // the check frame's own aux bits open the next window
-            for (int r = rnd->chk_row[fail]; r < n_rows; r++) add += err[r];
-            st->uw_errors = add;
-            a.n_rows[b] = n_rows;                        // the conv-history carry must use the last kept row
-            a.status[b * 4 + 0] = RD_NMF; a.status[b * 4 + 1] = 0; a.status[b * 4 + 2] = (int)st->snr_est; a.status[b * 4 + 3] = ST_SEARCH;
-            atomicAdd(&a.progress[2], 1);
-        } else {
-            int add = 0;
-            for (int r = rnd->uw_from_row; r < n_rows; r++) add += err[r];
-            st->uw_errors += add;
-        }
-        if (a.trace) {
-            for (int c = 0; c < n_calls; c++) {
-                const int idx = rnd->call_trace_idx[c];
-                if (idx >= a.trace_cap) continue;
-                int e = 0;
-                for (int r = rnd->call_row_lo[c]; r < rnd->call_row_hi[c]; r++) e += err[r];
-                rd_rx_trace *tr = a.trace + (size_t)b * a.trace_cap + idx;
-                tr->uw_errors += e;
-                if (fail >= 0 && c == n_calls - 1) { tr->state_after = ST_SEARCH; tr->nin_after = RD_NMF; }   // the failed check's call
-            }
-        }
-    }
-}
-extern "C" int rd_launch_rx_post(const rd_post_args *a, rd_stream_t s)
-{
-    if (a->B <= 0) return 0;
-    hipLaunchKernelGGL(k_rx_post, dim3(a->B), dim3(256), 0, (hipStream_t)s, *a);
-    return (int)hipGetLastError();
-}
