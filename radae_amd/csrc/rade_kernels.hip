@@ -35,8 +35,25 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// thread index through an opaque asm: inside the receiver's per-call loop this keeps the compiler from hoisting every
+// thread-derived address computation of every phase out of the loop (hundreds of registers live across all phases)
+__device__ __forceinline__ int rx_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 __device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
+// gate activations of the GRU recurrences on the hardware exp2 / rcp units (about 1 ulp each): the recurrence is a
+// serial chain, so the libm-grade expf / tanhf / IEEE division sequences would dominate every time step
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
 __device__ __forceinline__ float2 ld2(const float (*p)[2], int i) { return make_float2(p[i][0], p[i][1]); }
+
+#ifdef RD_PHASE_TIMING   // developer aid: per-phase shader-clock totals of workgroup 0 (make EXTRA=-DRD_PHASE_TIMING)
+__device__ long long g_phase_cycles[24];
+#define PH_T0() long long ph_t_ = clock64()
+#define PH(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); atomicAdd((unsigned long long *)&g_phase_cycles[i], (unsigned long long)(n_ - ph_t_)); ph_t_ = n_; } } while (0)
+extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 24); long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
+#else
+#define PH_T0() do { } while (0)
+#define PH(i) do { } while (0)
+#endif
 
 __device__ float g_zero_row[2048];   // tap-0 source of a conv row whose decoder state was just reset
 
@@ -282,9 +299,9 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
         sr += __shfl_xor(sr, 1); sz += __shfl_xor(sz, 1); sn += __shfl_xor(sn, 1);
         sr += __shfl_xor(sr, 2); sz += __shfl_xor(sz, 2); sn += __shfl_xor(sn, 2);
         const float gr = __shfl(g0, (tid & 60) + 0), gz = __shfl(g0, (tid & 60) + 1), gn = __shfl(g0, (tid & 60) + 2);
-        const float r = sigmoid_f((sr + br) + gr);
-        const float z = sigmoid_f((sz + bz) + gz);
-        const float n = tanhf(gn + (sn + bn) * r);
+        const float r = gate_sigmoid((sr + br) + gr);
+        const float z = gate_sigmoid((sz + bz) + gz);
+        const float n = gate_tanh(gn + (sn + bn) * r);
         hj = (hj - n) * z + n;
         if (p == 0) {
             hs[cur ^ 1][j] = hj;
@@ -322,10 +339,10 @@ struct DecShared {
 
 // Y[t, n] = act(sum_k [a0 | a1][t, k] W[n, k] + bias[n]) for t < Tb; a0 (K0 floats, may be 0) is the previous row's tap
 template <int NT>
-__device__ void ds_gemm(DecShared *sh, const float *a1, int a1_st, int K1, const float *a0, int a0_st, int K0, const int *rst,
+__device__ void ds_gemm(DecShared *sh, int tid, const float *a1, int a1_st, int K1, const float *a0, int a0_st, int K0, const int *rst,
                         const rd_lin w, float *y, int y_st, int act, int Tb)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;   // (an opaque index here crashes clang 22's instcombine)
     const int ntt = (w.N + 31) >> 5;
     const int nkb0 = K0 >> 3, nkb = nkb0 + (K1 >> 3);
     const size_t wstep = (size_t)ntt * 256;
@@ -384,10 +401,10 @@ __device__ void ds_gemm(DecShared *sh, const float *a1, int a1_st, int K1, const
 }
 
 // GRU recurrence over Tb steps (k_gru_scan<96> inside a 512-thread workgroup: threads >= 384 only keep the barriers)
-__device__ void ds_scan(DecShared *sh, const float *gi_, int gi_st, const float *Whh, const float *bhh, float *hstate, float *out, int out_st, bool use_rst, int Tb)
+__device__ void ds_scan(DecShared *sh, int tid, const float *gi_, int gi_st, const float *Whh, const float *bhh, float *hstate, float *out, int out_st, bool use_rst, int Tb)
 {
     constexpr int H = 96, KP = H / 4;
-    const int tid = threadIdx.x;
+    tid = rx_tid();
     const bool on = tid < 4 * H;
     const int j = on ? tid >> 2 : 0, p = tid & 3;
     float wr[KP], wz[KP], wn[KP];
@@ -429,9 +446,9 @@ __device__ void ds_scan(DecShared *sh, const float *gi_, int gi_st, const float 
         sr += __shfl_xor(sr, 1); sz += __shfl_xor(sz, 1); sn += __shfl_xor(sn, 1);
         sr += __shfl_xor(sr, 2); sz += __shfl_xor(sz, 2); sn += __shfl_xor(sn, 2);
         const float gr = __shfl(g0, (tid & 60) + 0), gz = __shfl(g0, (tid & 60) + 1), gn = __shfl(g0, (tid & 60) + 2);
-        const float r = sigmoid_f((sr + br) + gr);
-        const float z = sigmoid_f((sz + bz) + gz);
-        const float n = tanhf(gn + (sn + bn) * r);
+        const float r = gate_sigmoid((sr + br) + gr);
+        const float z = gate_sigmoid((sz + bz) + gz);
+        const float n = gate_tanh(gn + (sn + bn) * r);
         hj = (hj - n) * z + n;
         if (on && p == 0) {
             sh->hs[cur ^ 1][j] = hj;
@@ -445,21 +462,25 @@ __device__ void ds_scan(DecShared *sh, const float *gi_, int gi_st, const float 
 }
 
 // all decoder layers for rows [0, Tb) of stream b; sh->rst[] holds the per-row reset flags
-__device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb)
+__device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb, int tid)
 {
     const int W = RD_DEC_W;
+    PH_T0();
     float *x = a.x + (size_t)b * a.x_sb;
     float *gi = a.gi + (size_t)b * a.gi_sb, *hb = a.hbuf + (size_t)b * a.hb_sb;
-    ds_gemm<DS_NT>(sh, a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, nullptr, 0, 0, nullptr, a.dense1, x, W, 1, Tb);
+    ds_gemm<DS_NT>(sh, tid, a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, nullptr, 0, 0, nullptr, a.dense1, x, W, 1, Tb);
 #pragma unroll 1
     for (int l = 0; l < 5; l++) {
         const int in = 96 + 128 * l, cin = in + 96;      // radae_base.py:378-386
-        ds_gemm<DS_NT>(sh, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb);
-        ds_scan(sh, gi, 288, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, hb, 96, true, Tb);
-        ds_gemm<DS_NT>(sh, hb, 96, 96, nullptr, 0, 0, nullptr, a.glu[l], x + in, W, 2, Tb);
-        ds_gemm<1>(sh, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
+        ds_gemm<DS_NT>(sh, tid, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb);
+        PH(21);
+        ds_scan(sh, tid, gi, 288, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, hb, 96, true, Tb);
+        PH(23);
+        ds_gemm<DS_NT>(sh, tid, hb, 96, 96, nullptr, 0, 0, nullptr, a.glu[l], x + in, W, 2, Tb);
+        ds_gemm<1>(sh, tid, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
     }
-    ds_gemm<DS_NT>(sh, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
+    ds_gemm<DS_NT>(sh, tid, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
+    PH(21);
 }
 
 __global__ __launch_bounds__(64 * SK_WAVES) void k_dec_stream(rd_decs_args a)
@@ -472,7 +493,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void k_dec_stream(rd_decs_args a)
     const int *rstg = a.reset + (size_t)b * a.reset_sb;
     for (int i = tid; i < Tb; i += blockDim.x) sh->rst[i] = rstg[i];
     __syncthreads();
-    ds_layers(sh, a, b, Tb);
+    ds_layers(sh, a, b, Tb, tid);
 }
 
 extern "C" int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s)
@@ -776,15 +797,6 @@ extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
 // =====================================================================================================
 enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
 
-#ifdef RD_PHASE_TIMING   // developer aid: per-phase shader-clock totals of workgroup 0 (make EXTRA=-DRD_PHASE_TIMING)
-__device__ long long g_phase_cycles[24];
-#define PH_T0() long long ph_t_ = clock64()
-#define PH(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); atomicAdd((unsigned long long *)&g_phase_cycles[i], (unsigned long long)(n_ - ph_t_)); ph_t_ = n_; } } while (0)
-extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 24); long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
-#else
-#define PH_T0() do { } while (0)
-#define PH(i) do { } while (0)
-#endif
 
 
 #define NT_RX 512
@@ -935,7 +947,7 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
                                               float &best, int &bt, int &bfi)
 {
     const glb_float *G = (const glb_float *)G_, *tw = (const glb_float *)tw_; glb_float *cache = (glb_float *)cache_;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q2 = lane >> 1, h = lane & 1;
+    const int tid = rx_tid(), wave = tid >> 6, lane = tid & 63, q2 = lane >> 1, h = lane & 1;
     lds_float *scr = (lds_float *)&sh->fftscr[wave][0];
     lds_float *rxf = (lds_float *)&sh->rxb[0], *Xf = (lds_float *)&sh->fftX[0];
     constexpr int NFW = RD_NFC / (NT_RX / 64);                                // frequencies per wave
@@ -1025,7 +1037,7 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
 // max reduction with lexicographic tie-break (smaller k0, then smaller k1 wins); result in sh->redf[0], redi[0], redj[0]
 __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float ov = __shfl_xor(v, off); const int o0 = __shfl_xor(k0, off), o1 = __shfl_xor(k1, off);
@@ -1055,7 +1067,7 @@ __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
 // with C rows n = 16nt + 4(l>>4) + r, i.e. (re,im) of f = 8nt + 2(l>>4) and f+1, for its column t.
 __device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int tA_lane, int tB_lane, int nt, f32x4 &acc1, f32x4 &acc2)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = rx_tid() & 63;
     const int i = lane & 15, kl = lane >> 4;
     const float *pwf = (const float *)&sh->pw[0][0];
     const float *rxf = (const float *)&sh->rxb[0];
@@ -1091,7 +1103,7 @@ __device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int tA_lane, 
 template <int NV>
 __device__ void block_sum_multi(RxShared *sh, double (&v)[NV])
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int k = 0; k < NV; k++)
 #pragma unroll
@@ -1118,7 +1130,7 @@ __device__ __forceinline__ float sigma_r_from_sums(double t1, double t2)
 __device__ float sigma_r_from_rowsums(RxShared *sh)
 {
     double v[2] = { 0.0, 0.0 };
-    for (int t = threadIdx.x; t < RD_NMF; t += NT_RX) { v[0] += (double)sh->rowsum1[t]; v[1] += (double)sh->rowsum2[t]; }
+    for (int t = rx_tid(); t < RD_NMF; t += NT_RX) { v[0] += (double)sh->rowsum1[t]; v[1] += (double)sh->rowsum2[t]; }
     block_sum_multi<2>(sh, v);
     return sigma_r_from_sums(v[0], v[1]);
 }
@@ -1176,7 +1188,7 @@ __device__ __forceinline__ f64x4 refine_tile(const RxShared *sh, int mt, int fra
 
 __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
     const int nf = (int)ceil((fstop - fstart) / fstep);                 // np.arange length
     const double delta = (fstart + fstep) - fstart;                       // np.arange fill rule
     const int ntasks = ((2 * nf + 15) >> 4) * 2;
@@ -1256,7 +1268,7 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
 // one term of dot(conj(w_vec*rx[t0..]), ref) in complex128 (dsp.py:307-313); thread n < 160 owns sample n
 __device__ __forceinline__ void rx_corr_term(const RxShared *sh, int t0, double s, double c, const double2 *ref, double &ar, double &ai)
 {
-    const int tid = threadIdx.x;
+    const int tid = rx_tid();
     const float2 x = sh->rxb[t0 + tid];
     const double qr = c * x.x - s * x.y, qi = -(c * x.y + s * x.x);    // conj(w_vec*rx)
     const double2 r = ref[tid];
@@ -1278,12 +1290,12 @@ __device__ __forceinline__ void rx_decode_pending(RxShared *sh, const rd_sync_ar
     RxScalars *S = &sh->S;
     DecShared *ds = (DecShared *)&sh->wfwd[0][0];
     rd_rx_round *rnd = a.round + b;
-    const int tid = threadIdx.x;
+    const int tid = rx_tid();
     const int Tb = S->n_rows;
     for (int i = tid; i < Tb; i += NT_RX) ds->rst[i] = rnd->row_reset[i];
     if (tid == 0) S->lds_sync = 0;
     __syncthreads();
-    ds_layers(ds, a.dec, b, Tb);
+    ds_layers(ds, a.dec, b, Tb, tid);
     const float *f84 = a.dec.out + (size_t)b * a.dec.out_sb;
     for (int r = tid; r < Tb; r += NT_RX) ds->err[r] = f84[r * 84 + 20] > 0.0f ? 1 : 0;      // first aux symbol of each group of 4
     // valid frame v (3 rows) -> 12 feature frames x 36 floats, 20 used + 16 zeros
@@ -1370,7 +1382,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
         }
         __syncthreads();
-        if (S->need_decode) rx_decode_pending(sh, a, b);
+        if (S->need_decode) { PH(22); rx_decode_pending(sh, a, b); PH(20); }
         if (!S->go) break;
         const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
         const float2 bpf_phase = S->bpf_phase;
