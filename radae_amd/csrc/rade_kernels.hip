@@ -1086,14 +1086,12 @@ __device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int tA_lane, 
         const int sn = blk < 9 ? (blk + 1) * 8 : 0;            // last block re-reads block 0 (harmless) to stay branch-free
 #pragma unroll
         for (int u = 0; u < 8; u++) { na[u] = pa[(sn + u) * (4 * RD_NFC)]; nb1[u] = pbA[4 * (sn + u)]; nb2[u] = pbB[4 * (sn + u)]; }
-        __builtin_amdgcn_sched_barrier(0);                     // keep the prefetch ahead of the matrix instructions
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const float a = ca[u] * sgn;
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb1[u], acc1, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb2[u], acc2, 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; u++) { ca[u] = na[u]; cb1[u] = nb1[u]; cb2[u] = nb2[u]; }
     }
@@ -1279,6 +1277,9 @@ __device__ __forceinline__ void rx_corr_term(const RxShared *sh, int t0, double 
 // barrier.  (Keeping ~40 loop-carried "uniform" scalars in every thread's registers cost 256 VGPRs
 // and proved fragile under -O3.)
 static_assert(sizeof(RxShared) <= 160 * 1024, "k_rx_sync working set must fit the 160 KiB LDS of a CU");
+
+__device__ static constexpr uint32_t LCG_A[48] = { 1664525u, 389569705u, 2940799637u, 158984081u, 2862450781u, 3211393721u, 1851289957u, 3934847009u, 2184914861u, 246739401u, 1948736821u, 2941245873u, 4195587069u, 4088025561u, 980655621u, 2001863745u, 657792333u, 65284841u, 1282409429u, 3808694225u, 2968195997u, 2417331449u, 2878627493u, 307989601u, 504219373u, 1897564169u, 2574089845u, 3294562801u, 3478292285u, 2651335705u, 2523738949u, 666245249u, 4137395341u, 2604435753u, 1706708245u, 3963176977u, 3678957277u, 3530469177u, 3858799589u, 629287073u, 3146069549u, 3820924489u, 2403397557u, 2390444593u, 2593868413u, 4291139161u, 1705056389u, 3186638017u };
+__device__ static constexpr uint32_t LCG_C[48] = { 1013904223u, 1196435762u, 3519870697u, 2868466484u, 1649599747u, 2670642822u, 1476291629u, 2748932008u, 2180890343u, 2498801434u, 3421909937u, 3167820124u, 2636375307u, 3801544430u, 28987765u, 2210837584u, 3039689583u, 1338634754u, 1649346937u, 2768872580u, 2254235155u, 2326606934u, 1719328701u, 1061592568u, 53332215u, 1140036074u, 4224358465u, 2629538988u, 1946028059u, 573775550u, 1473591045u, 95141024u, 1592739711u, 1618554578u, 4257218569u, 2685635028u, 2617994019u, 740185638u, 4194465613u, 2426187848u, 967350023u, 366635194u, 2557108433u, 3503432700u, 353185579u, 706247310u, 408928405u, 1855199472u };
 
 // Decoder + output stage for the rows a stream has pending, run by the stream's own workgroup: CoreDecoder over the
 // rows (ds_layers), rows -> 36-float feature frames (rade_api.c:488-513), aux-bit (UW) error accounting
@@ -1497,7 +1498,16 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             PH(4);
             // check_pilots (dsp.py:273-320): refresh 48 pseudo-random rows
-            if (tid == 0) { uint32_t x = S->lcg; for (int i = 0; i < 48; i++) { x = x * 1664525u + 1013904223u; sh->rows48[i] = (int)((x >> 8) % RD_NMF); } S->lcg = x; }
+            // x_{i+1} = 1664525 x_i + 1013904223 (mod 2^32), 48 draws: thread i jumps straight to draw i (x_i = A^i x_0 + C_i)
+            {
+                const uint32_t x0 = S->lcg;
+                __syncthreads();
+                if (tid < 48) {
+                    const uint32_t x = LCG_A[tid] * x0 + LCG_C[tid];
+                    sh->rows48[tid] = (int)((x >> 8) % RD_NMF);
+                    if (tid == 47) S->lcg = x;
+                }
+            }
             __syncthreads();
             {
                 const int wave = tid >> 6, lane = tid & 63, q = lane >> 4;
