@@ -145,7 +145,7 @@ int rd_launch_channel(const rd_chan_args *a, rd_stream_t s);
 /* CoreDecoderStatefull.forward for the rows of one receiver round, one workgroup per stream (k_dec_stream): every
  * layer of radae_base.py:388-430 back to back in one launch -- the streams are independent, so no grid-wide
  * step separates the layers.  Same arithmetic (k interleave, reduction order) as the split-K GEMM + scan kernels. */
-typedef struct { const float *wp, *bias; int N, K; } rd_lin;
+typedef struct { const float *wp, *bias; const unsigned short *wp16; int N, K; } rd_lin;   /* wp16: rd_pack_weights_f16x2 */
 typedef struct {
     const float *z; long z_sb;                 /* [B][.][80] latent rows */
     float *x; long x_sb;                       /* [B][1 + Tcap][736] DenseNet rows; x points at row 0 of stream 0, row -1 = conv history */

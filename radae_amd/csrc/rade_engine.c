@@ -23,7 +23,7 @@
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rade: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); goto fail; } } while (0)
 
-typedef struct { float *wp, *bias; int N, K; } dev_lin;
+typedef struct { float *wp, *bias; unsigned short *wp16; int N, K; } dev_lin;
 
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
@@ -85,7 +85,14 @@ static int upload_lin(dev_lin *d, const float *w, const float *b, int N, int K, 
     rd_pack_weights(wsrc, N, Kpad, packed);
     d->wp = dev_upload(packed, sizeof(float) * n);
     d->bias = b ? dev_upload(b, sizeof(float) * N) : NULL;
-    d->N = N; d->K = Kpad;
+    d->N = N; d->K = Kpad; d->wp16 = NULL;
+    if (Kpad % 16 == 0) {                  /* two-plane f16 copy for the receiver's in-kernel decoder (f16 matrix cores) */
+        const long n16 = rd_packed16_size(N, Kpad);
+        unsigned short *p16 = malloc(sizeof(unsigned short) * n16);
+        rd_pack_weights_f16x2(wsrc, N, Kpad, p16);
+        d->wp16 = dev_upload(p16, sizeof(unsigned short) * n16);
+        free(p16);
+    }
     free(packed); free(tmp);
     return (d->wp && (!b || d->bias)) ? 0 : -1;
 }
@@ -241,7 +248,7 @@ rade_batch *rade_batch_open(const char *blob_path, const rade_batch_config *cfg)
     return h;
 }
 
-static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFree(d->bias); }
+static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFree(d->bias); if (d->wp16) hipFree(d->wp16); }
 void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
@@ -404,7 +411,7 @@ static void fill_dec_args(const rade_batch *h, rd_decs_args *d)
     d->gi = h->dec_gi; d->gi_sb = DR * 288; d->hbuf = h->dec_hbuf; d->hb_sb = DR * 96;
     d->out = h->feat84; d->out_sb = DR * h->feat_in; d->out_w = h->feat_in;
     d->n_rows = h->rx_nrows; d->reset = h->rx_rowreset; d->reset_sb = h->dec_rows; d->B = h->B;
-#define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).N = (src).N; (dst).K = (src).K; } while (0)
+#define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).wp16 = (src).wp16; (dst).N = (src).N; (dst).K = (src).K; } while (0)
     LIN(d->dense1, h->dec_dense1); LIN(d->output, h->dec_output);
     for (int l = 0; l < 5; l++) { LIN(d->gin[l], h->dec_gin[l]); LIN(d->glu[l], h->dec_glu[l]); LIN(d->conv[l], h->dec_conv[l]); d->whh[l] = h->dec_whh[l]; d->bhh[l] = h->dec_bhh[l]; d->h[l] = h->dec_h[l]; }
 #undef LIN

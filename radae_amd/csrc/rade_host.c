@@ -267,6 +267,59 @@ long rd_pack_weights(const float *W, int N, int K, float *out)
     return rd_packed_size(N, K);
 }
 
+/* float -> IEEE binary16 (round to nearest even, subnormals kept) and back: the two-plane split of the decoder weights */
+static unsigned short f32_to_f16(float f)
+{
+    unsigned int x; memcpy(&x, &f, 4);
+    const unsigned int sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);                 /* rounds to >= 65520: infinity */
+    if (x < 0x38800000u) {                                                         /* below 2^-14: subnormal half */
+        if (x < 0x33000000u) return (unsigned short)sign;                          /* < 2^-25 */
+        const int e = (int)(x >> 23);                                              /* biased float exponent, 102..112 */
+        unsigned int m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;                                                 /* 14..24 */
+        const unsigned int halfm = m >> shift, rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1);
+        unsigned int r = halfm + ((rem > mid || (rem == mid && (halfm & 1u))) ? 1u : 0u);
+        return (unsigned short)(sign | r);
+    }
+    unsigned int r = ((x - 0x38000000u) >> 13);
+    const unsigned int rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+    return (unsigned short)(sign | r);
+}
+static float f16_to_f32(unsigned short h)
+{
+    const unsigned int sign = (unsigned int)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    unsigned int x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { float f = (float)m * 5.9604644775390625e-08f; memcpy(&x, &f, 4); x |= sign; }      /* m * 2^-24 */
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4); return f;
+}
+
+/* W[N][K] (K a multiple of 16) -> B operands of v_mfma_f32_32x32x16_f16 in two planes, w = hi + lo to 22 bits:
+ * out[kb][nt][plane][lane][j] = plane(W[32 nt + lane%32][16 kb + 8 (lane/32) + j]) */
+long rd_packed16_size(int N, int K) { return (long)(K / 16) * ((N + 31) / 32) * 2 * 64 * 8; }
+long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out)
+{
+    const int nkb = K / 16, ntt = (N + 31) / 32;
+    for (int kb = 0; kb < nkb; kb++)
+        for (int nt = 0; nt < ntt; nt++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int nn = nt * 32 + (lane & 31), k = kb * 16 + 8 * (lane >> 5) + j;
+                    const float w = nn < N ? W[(size_t)nn * K + k] : 0.0f;
+                    const unsigned short hi = f32_to_f16(w), lo = f32_to_f16(w - f16_to_f32(hi));
+                    unsigned short *o = out + ((((size_t)kb * ntt + nt) * 2) * 64 + lane) * 8 + j;
+                    o[0] = hi; o[64 * 8] = lo;
+                }
+    return rd_packed16_size(N, K);
+}
+
 /* Tables of the FFT pilot correlator (k_rx_sync, search state).  Dt[t,f] = sum_m conj(rx[t+m]) p_w[m,f]
  * (dsp.py:207-208) is a correlation along t, so |Dt[.,f]| = |IDFT_2048(DFT_2048(rx) . G_f)| with
  * G_f[k] = (1/2048) sum_m conj(p_w[m,f]) e^{+j 2 pi k m/2048}, evaluated here in double from the float32 p_w the

@@ -25,6 +25,8 @@ int rd_model_parse(const void *blob, size_t len, rd_model *m);
 void rd_model_free(rd_model *m);
 
 void rd_fft_tables_fill(const rd_tables *T, float *G, float *tw);
+long rd_packed16_size(int N, int K);
+long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out);
 #ifdef __cplusplus
 }
 #endif

@@ -358,18 +358,37 @@ __device__ void ds_gemm(DecShared *sh, int tid, const float *a1, int a1_st, int 
 #pragma unroll
                 for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
             const float *wbase = w.wp + ((size_t)nt0 * 64 + lane) * 4;
-#pragma unroll 2
-            for (int kb = wave; kb < nkb; kb += SK_WAVES) {
-                const float *p = kb < nkb0 ? p0 + kb * 8 : p1 + (kb - nkb0) * 8;
-                const f32x4 av = *(const f32x4 *)p;
-                f32x4 bv[NT];
+            // two waves per SIMD cannot hide the L2 latency of the fragment loads: a ring of DEPTH k-blocks is kept in
+            // flight ahead of the matrix instructions (order pinned by the scheduling barriers)
+            constexpr int DEPTH = NT == 1 ? 3 : 1, RING = DEPTH + 1;
+            f32x4 ab[RING], bb[RING][NT];
+            auto fetch = [&](int slot, int kb) {
+                const bool ok = kb < nkb;
+                const int kc = ok ? kb : wave;                     // out-of-range prefetches re-read a valid block (branch-free)
+                ab[slot] = *(const f32x4 *)(kc < nkb0 ? p0 + kc * 8 : p1 + (kc - nkb0) * 8);
 #pragma unroll
-                for (int i = 0; i < NT; i++) bv[i] = (nt0 + i < ntt) ? *(const f32x4 *)(wbase + kb * wstep + i * 256) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                for (int i = 0; i < NT; i++) bb[slot][i] = (nt0 + i < ntt) ? *(const f32x4 *)(wbase + kc * wstep + i * 256) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            };
+            if (wave < nkb) {
 #pragma unroll
-                for (int s = 0; s < 4; s++)
+                for (int d = 0; d < DEPTH; d++) fetch(d, wave + d * SK_WAVES);
+#pragma unroll 1
+                for (int kb = wave; kb < nkb; kb += RING * SK_WAVES) {
 #pragma unroll
-                    for (int i = 0; i < NT; i++)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[i][s], acc[i], 0, 0, 0);
+                    for (int u = 0; u < RING; u++) {
+                        const int kc = kb + u * SK_WAVES;
+                        if (kc < nkb) {                            // uniform per wave
+                            fetch((u + DEPTH) % RING, kc + DEPTH * SK_WAVES);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int s = 0; s < 4; s++)
+#pragma unroll
+                                for (int i = 0; i < NT; i++)
+                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[u][s], bb[u][i][s], acc[i], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < NT; i++)
@@ -396,6 +415,95 @@ __device__ void ds_gemm(DecShared *sh, int tid, const float *a1, int a1_st, int 
                 }
             }
             __syncthreads();                     // partials are reused by the next tile group; y is read by the next layer
+        }
+    }
+}
+
+// Same GEMM on the f16 matrix cores with both operands split in two binary16 planes (v = hi + lo, 22 bits):
+// acc += A_hi B_hi + A_hi B_lo + A_lo B_hi per 16-deep k-block (the dropped lo*lo term is 2^-22 relative; products
+// are exact, accumulation is f32 as before).  v_mfma_f32_32x32x16_f16 moves 16 k per 8 passes where the f32
+// instruction moves 2 per 16, so the three products cost a fifth of the f32 time.  The activations are split on the
+// fly (VALU, overlapped with the matrix pipe); the weights come pre-split from rd_pack_weights_f16x2.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NT>
+__device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, int K1, const float *a0, int a0_st, int K0, const int *rst,
+                          const rd_lin w, float *y, int y_st, int act, int Tb)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int ntt = (w.N + 31) >> 5;
+    const int nkb0 = K0 >> 4, nkb = nkb0 + (K1 >> 4);
+    const size_t wstep = (size_t)ntt * 2 * 64 * 8;                 // halfs per k-block
+    for (int r0 = 0; r0 < Tb; r0 += 32) {
+        const int t = min(r0 + (lane & 31), Tb - 1);
+        const float *p1 = a1 + (size_t)t * a1_st + 8 * half;
+        const float *p0 = nullptr;
+        if (K0) p0 = ((rst && rst[t]) ? g_zero_row : a0 + (size_t)t * a0_st) + 8 * half;
+        for (int nt0 = 0; nt0 < ntt; nt0 += NT) {
+            f32x16 acc[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+            const unsigned short *wbase = w.wp16 + ((size_t)nt0 * 2 * 64 + lane) * 8;
+            f32x4 a_lo4 = { 0.0f, 0.0f, 0.0f, 0.0f }, a_hi4 = a_lo4;   // this block's 8 activations (f32)
+            f16x8 bh[NT], bl[NT];
+            auto fetch = [&](int kb) {
+                const float *p = kb < nkb0 ? p0 + kb * 16 : p1 + (kb - nkb0) * 16;
+                a_lo4 = *(const f32x4 *)p; a_hi4 = *(const f32x4 *)(p + 4);
+#pragma unroll
+                for (int i = 0; i < NT; i++) {
+                    if (nt0 + i < ntt) { bh[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8); bl[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8 + 64 * 8); }
+                    else { bh[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; bl[i] = bh[i]; }
+                }
+            };
+            if (wave < nkb) fetch(wave);
+#pragma unroll 1
+            for (int kb = wave; kb < nkb; kb += SK_WAVES) {
+                f16x8 ah, al;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float x = j < 4 ? a_lo4[j] : a_hi4[j - 4];
+                    const _Float16 hi = (_Float16)x;
+                    ah[j] = hi; al[j] = (_Float16)(x - (float)hi);
+                }
+                f16x8 ch[NT], cl[NT];
+#pragma unroll
+                for (int i = 0; i < NT; i++) { ch[i] = bh[i]; cl[i] = bl[i]; }
+                if (kb + SK_WAVES < nkb) fetch(kb + SK_WAVES);                 // next block's loads fly during the matrix instructions
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NT; i++) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ch[i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cl[i], acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ch[i], acc[i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) sh->red[wave][i][j][lane] = acc[i][j];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int col = (nt0 + i) * 32 + (lane & 31);
+                if (nt0 + i >= ntt || col >= w.N) continue;
+                const float bias = w.bias ? w.bias[col] : 0.0f;
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const int j = wave * 2 + jj;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int ww = 0; ww < SK_WAVES; ww++) v += sh->red[ww][i][j][lane];
+                    const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                    if (tt >= Tb) continue;
+                    v += bias;
+                    if (act == 1) v = clamp1(tanhf(v));
+                    else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * sigmoid_f(v));
+                    y[(size_t)tt * y_st + col] = v;
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -468,18 +576,18 @@ __device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb, i
     PH_T0();
     float *x = a.x + (size_t)b * a.x_sb;
     float *gi = a.gi + (size_t)b * a.gi_sb, *hb = a.hbuf + (size_t)b * a.hb_sb;
-    ds_gemm<DS_NT>(sh, tid, a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, nullptr, 0, 0, nullptr, a.dense1, x, W, 1, Tb);
+    ds_gemm16<DS_NT>(sh, tid, a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, nullptr, 0, 0, nullptr, a.dense1, x, W, 1, Tb);
 #pragma unroll 1
     for (int l = 0; l < 5; l++) {
         const int in = 96 + 128 * l, cin = in + 96;      // radae_base.py:378-386
-        ds_gemm<DS_NT>(sh, tid, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb);
+        ds_gemm16<DS_NT>(sh, tid, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb);
         PH(21);
         ds_scan(sh, tid, gi, 288, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, hb, 96, true, Tb);
         PH(23);
-        ds_gemm<DS_NT>(sh, tid, hb, 96, 96, nullptr, 0, 0, nullptr, a.glu[l], x + in, W, 2, Tb);
-        ds_gemm<1>(sh, tid, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
+        ds_gemm16<DS_NT>(sh, tid, hb, 96, 96, nullptr, 0, 0, nullptr, a.glu[l], x + in, W, 2, Tb);
+        ds_gemm16<1>(sh, tid, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
     }
-    ds_gemm<DS_NT>(sh, tid, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
+    ds_gemm16<DS_NT>(sh, tid, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
     PH(21);
 }
 
@@ -1572,12 +1680,20 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             if (tid == 0) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
             PH(7);
             // receiver_one (dsp.py:487-526): window [16:176] of each 192-sample symbol, 160->30 DFT
-            if (tid < 6 * RD_NC) {
-                const int s = tid / RD_NC, c = tid - s * RD_NC;
-                const float2 *x = rx1 + s * RD_SYM + RD_NCP - 16;
-                float2 acc = make_float2(0.0f, 0.0f);
-                for (int n = 0; n < RD_M; n++) acc = cadd(acc, cmul(x[n], sh->wfwd[n][c]));
-                sh->sym[s][c] = acc;
+            // two lanes per (symbol, carrier), 80 samples each in four independent chains; the halves meet through a lane swap
+            if (tid < 2 * 6 * RD_NC) {
+                const int o = tid >> 1, hf = tid & 1, s = o / RD_NC, c = o - s * RD_NC;
+                const float2 *x = rx1 + s * RD_SYM + RD_NCP - 16 + 80 * hf;
+                float2 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc[u] = make_float2(0.0f, 0.0f);
+#pragma unroll 5
+                for (int n = 0; n < 80; n += 4)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc[u] = cadd(acc[u], cmul(x[n + u], sh->wfwd[80 * hf + n + u][c]));
+                float2 t = cadd(cadd(acc[0], acc[1]), cadd(acc[2], acc[3]));
+                t.x += __shfl_xor(t.x, 1); t.y += __shfl_xor(t.y, 1);
+                if (hf == 0) sh->sym[s][c] = t;
             }
             __syncthreads();
             PH(8);

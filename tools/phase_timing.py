@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from radae_amd.engine import BatchEngine, load_library, sigma_from_EbNodB
 from radae_amd.channel_tools import synth_features, multipath_g
-B, T = 256, 1008; n_mf = T // 12
+B, T = int(os.environ.get("PT_STREAMS", "256")), 1008; n_mf = T // 12
 eng = BatchEngine(B, max_tx_mf=n_mf, rx_trace_calls=128)
 dev = torch.device('cuda')
 feats = torch.tensor(np.stack([synth_features(1000 + b, T) for b in range(B)]), device=dev)
