@@ -31,7 +31,7 @@ extern "C" {
 #define RD_NEOOBITS 180
 #define RD_ENC_W    864   /* encoder concat width */
 #define RD_DEC_W    736
-#define RD_ENC_IN   88    /* 84 padded to a multiple of 8 */
+#define RD_ENC_IN   96    /* 84 padded to a multiple of 16 (k-block of the f16 matrix instructions) */
 #define RD_RX_ROUND_MAX 128   /* capacity: do_radae_rx calls per stream per sync-kernel launch (engine picks R <= this) */
 #define RD_DEC_ROWS_MAX (3 * RD_RX_ROUND_MAX)
 
@@ -102,6 +102,7 @@ typedef struct {
     const int *reset; int reset_sb;    /* optional [B][reset_sb] (reset_sb >= T) */
     const int *n_rows;                 /* optional [B]: rows t >= n_rows[b] are skipped */
     const float *Wp; const float *bias;
+    const unsigned short *Wp16;        /* optional rd_pack_weights_f16x2 copy: used for large row counts when K0, K1 are multiples of 16 */
     float *y; long y_sb, y_st; int N;  /* N valid outputs (<= 32*NT) */
     int B, T, act;
 } rd_gemm_args;

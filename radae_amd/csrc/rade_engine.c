@@ -167,7 +167,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     if (!h->d_tab || !h->fftG || !h->ffttw) goto fail;
 
     int err = 0;
-    h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 7) & ~7; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
+    h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
     err |= upload_lin(&h->enc_dense1, m.enc_dense1.w, m.enc_dense1.b, 64, h->feat_in, h->enc_kpad);
     err |= upload_lin(&h->enc_zdense, m.enc_zdense.w, m.enc_zdense.b, 80, 864, 864);
     err |= upload_lin(&h->dec_dense1, m.dec_dense1.w, m.dec_dense1.b, 96, 80, 80);
@@ -294,7 +294,7 @@ static int gemm(rade_batch *hh, const dev_lin *w, const float *a1, long a1_sb, l
     rd_gemm_args g;
     memset(&g, 0, sizeof g);
     g.a1 = a1; g.a1_sb = a1_sb; g.a1_st = a1_st; g.K1 = K1; g.a0 = a0; g.a0_sb = a0_sb; g.a0_st = a0_st; g.K0 = K0;
-    g.reset = reset; g.reset_sb = hh->dec_rows; g.n_rows = n_rows; g.Wp = w->wp; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
+    g.reset = reset; g.reset_sb = hh->dec_rows; g.n_rows = n_rows; g.Wp = w->wp; g.Wp16 = w->wp16; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
     if (K0 + K1 != w->K) { fprintf(stderr, "rade: internal GEMM shape error (%d+%d != %d)\n", K0, K1, w->K); return -1; }
     PROF_BEGIN(hh, stream);
     const int rc = rd_launch_gemm(&g, stream);
