@@ -170,6 +170,7 @@ typedef struct {
     int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
     rd_decs_args dec;                                    /* the decoder runs inside the stream's workgroup (rx_decode_pending) */
     float *features_out; long feat_stride;               /* [B][cap][432] */
+    const unsigned short *corr16;                        /* rd_corr16_table_fill(): [5][10][2][64][8] binary16 */
     const float *fftG, *ffttw;                           /* rd_fft_tables_fill(): [RD_NFC][2048][2], [2048 + 64][2] */
     float *zrows;                                        /* [B][dec_rows][80] */
     float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */

@@ -28,7 +28,7 @@ typedef struct { float *wp, *bias; unsigned short *wp16; int N, K; } dev_lin;
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
-    float *fftG, *ffttw;
+    float *fftG, *ffttw; unsigned short *corr16;
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -162,9 +162,11 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         float *G = malloc(sizeof(float) * RD_NFC * 2048 * 2), *tw = malloc(sizeof(float) * (2048 + 64) * 2);
         if (G && tw) { rd_fft_tables_fill(tab, G, tw); h->fftG = dev_upload(G, sizeof(float) * RD_NFC * 2048 * 2); h->ffttw = dev_upload(tw, sizeof(float) * (2048 + 64) * 2); }
         free(G); free(tw);
+        unsigned short *c16 = malloc(sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8);
+        if (c16) { rd_corr16_table_fill(tab, c16); h->corr16 = dev_upload(c16, sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8); free(c16); }
     }
     free(tab);
-    if (!h->d_tab || !h->fftG || !h->ffttw) goto fail;
+    if (!h->d_tab || !h->fftG || !h->ffttw || !h->corr16) goto fail;
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
@@ -253,7 +255,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw };
+                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -455,7 +457,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
         if (getenv("RADE_UNIT_COSTS")) sscanf(getenv("RADE_UNIT_COSTS"), "%d,%d,%d", &c0, &c1, &c2);
         sa.unit_cost[0] = c0; sa.unit_cost[1] = c1; sa.unit_cost[2] = c2; sa.unit_budget = getenv("RADE_UNIT_COSTS") ? c0 * h->R : 0x3fffffff;   /* no budget by default: one launch does it all */
     }
-    sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+    sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only

@@ -320,6 +320,25 @@ long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out)
     return rd_packed16_size(N, K);
 }
 
+/* check_pilots rows on the f16 matrix cores: the realified pilot table Pm[n = 2f + c', k = 2m + c] = {pr, pi; pi, -pr}[c'][c]
+ * of p_w[m][f] (dsp.py:207-208 as a real GEMM), split in two binary16 planes and laid out as the A operands of
+ * v_mfma_f32_16x16x32_f16: out[nt][s][plane][lane][j] = plane(Pm[16 nt + lane%16][32 s + 8 (lane/16) + j]) */
+void rd_corr16_table_fill(const rd_tables *T, unsigned short *out /* [5][10][2][64][8] */)
+{
+    for (int nt = 0; nt < 5; nt++)
+        for (int s = 0; s < 10; s++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int n = 16 * nt + (lane & 15), f = n >> 1, cp = n & 1;
+                    const int k = 32 * s + 8 * (lane >> 4) + j, m = k >> 1, c = k & 1;
+                    const float pr = T->p_w[m][f][0], pi = T->p_w[m][f][1];
+                    const float v = cp == 0 ? (c == 0 ? pr : pi) : (c == 0 ? pi : -pr);
+                    const unsigned short hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                    unsigned short *o = out + ((((size_t)nt * 10 + s) * 2) * 64 + lane) * 8 + j;
+                    o[0] = hi; o[64 * 8] = lo;
+                }
+}
+
 /* Tables of the FFT pilot correlator (k_rx_sync, search state).  Dt[t,f] = sum_m conj(rx[t+m]) p_w[m,f]
  * (dsp.py:207-208) is a correlation along t, so |Dt[.,f]| = |IDFT_2048(DFT_2048(rx) . G_f)| with
  * G_f[k] = (1/2048) sum_m conj(p_w[m,f]) e^{+j 2 pi k m/2048}, evaluated here in double from the float32 p_w the

@@ -26,6 +26,7 @@ void rd_model_free(rd_model *m);
 
 void rd_fft_tables_fill(const rd_tables *T, float *G, float *tw);
 long rd_packed16_size(int N, int K);
+void rd_corr16_table_fill(const rd_tables *T, unsigned short *out);
 long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out);
 #ifdef __cplusplus
 }

@@ -1015,13 +1015,13 @@ struct RxShared {
     union {
         struct {                          // synchronised state (S.lds_sync != 0)
             float2 wfwd[RD_M][RD_NC];     // forward DFT matrix (dsp.py:501)
-            float2 pw[RD_M][RD_NFC];      // acquisition.p_w
             union {
                 float absd[96][RD_NFC + 1];   // check_pilots scratch |Dt| rows
                 float2 dtr[2 * 80 * 16];      // refine(): complex64 Dt1 / Dt2 at [(frame * nf + f) * 16 + t]; does not overlap the FFT area
                 struct { char rpart_pad[8192]; double rpart[6][64][4]; };   // refine(), in-sync grid (dtr uses 5 KB): second-half partial tiles
             };
         };
+        unsigned char dec_raw[sizeof(DecShared)];   // decoder stage scratch (rx_decode_pending)
         struct {                          // search / candidate state: FFT pilot correlator
             float2 fftX[FFT_N];           // spectrum of the rx_buf window being correlated
             float fftscr[NT_RX / 64][FFT_SCR];
@@ -1247,46 +1247,6 @@ __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
     __syncthreads();
 }
 
-// Pilot correlation on the matrix cores.  Dt[t,f] = sum_m conj(rx[t+m]) p_w[m,f] (dsp.py:207-208) is the real
-// GEMM  C[n,t] = sum_k Pm[n,k] X[k,t]  with k = 2m+c (re/im of rx), n = 2f+c' (re/im of Dt),
-//   X[k,t]  = rxf[2t + k]            (the interleaved float view of rx_buf: a Hankel matrix, never materialised)
-//   Pm[n,k] = {pr, pi; pi, -pr}[c'][c] of p_w[m,f]
-// One v_mfma_f32_16x16x4_f32 tile = 16 n x 16 t, K = 320 in 80 steps; two column sets (tA, tB) share the Pm
-// fragment (two independent accumulator chains keep the matrix pipe issuing back to back).  Every Dt value is
-// produced by the same k-ordered chain whichever pairing computed it, so results do not depend on the pairing.  Lane l feeds Pm[n = 16nt + (l&15)][k = 4s + (l>>4)] and X[k = 4s + (l>>4)][t = tl], and ends up
-// with C rows n = 16nt + 4(l>>4) + r, i.e. (re,im) of f = 8nt + 2(l>>4) and f+1, for its column t.
-__device__ __forceinline__ void corr_tile_mfma(const RxShared *sh, int tA_lane, int tB_lane, int nt, f32x4 &acc1, f32x4 &acc2)
-{
-    const int lane = rx_tid() & 63;
-    const int i = lane & 15, kl = lane >> 4;
-    const float *pwf = (const float *)&sh->pw[0][0];
-    const float *rxf = (const float *)&sh->rxb[0];
-    const int comp = (i ^ kl) & 1;                         // which component of p_w this lane reads
-    const float sgn = (i & kl & 1) ? -1.0f : 1.0f;         // Pm = -pr when c = c' = 1
-    const float *pa = pwf + ((kl >> 1) * RD_NFC + 8 * nt + (i >> 1)) * 2 + comp;   // + s * (2*RD_NFC*2)
-    const float *pbA = rxf + 2 * tA_lane + kl, *pbB = rxf + 2 * tB_lane + kl;         // + 4*s
-    acc1 = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc2 = acc1;
-    // 10 blocks of 8 k-steps; the next block's operands are fetched from LDS while this block's 16 MFMAs issue
-    float ca[8], cb1[8], cb2[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { ca[u] = pa[u * (4 * RD_NFC)]; cb1[u] = pbA[4 * u]; cb2[u] = pbB[4 * u]; }
-#pragma unroll 1
-    for (int blk = 0; blk < 10; blk++) {
-        float na[8], nb1[8], nb2[8];
-        const int sn = blk < 9 ? (blk + 1) * 8 : 0;            // last block re-reads block 0 (harmless) to stay branch-free
-#pragma unroll
-        for (int u = 0; u < 8; u++) { na[u] = pa[(sn + u) * (4 * RD_NFC)]; nb1[u] = pbA[4 * (sn + u)]; nb2[u] = pbB[4 * (sn + u)]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const float a = ca[u] * sgn;
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb1[u], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cb2[u], acc2, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) { ca[u] = na[u]; cb1[u] = nb1[u]; cb2[u] = nb2[u]; }
-    }
-}
-
 // sum NV doubles per thread over the workgroup: wave shuffles, then one LDS pass; result in sh->redd[0..NV)
 template <int NV>
 __device__ void block_sum_multi(RxShared *sh, double (&v)[NV])
@@ -1477,9 +1437,8 @@ __device__ static constexpr uint32_t LCG_C[48] = { 1013904223u, 1196435762u, 351
 // which are reloaded on the next synchronised call.
 __device__ __forceinline__ void rx_decode_pending(RxShared *sh, const rd_sync_args &a, int b)
 {
-    static_assert(sizeof(DecShared) <= sizeof(sh->wfwd) + sizeof(sh->pw) + sizeof(sh->dtr), "decoder scratch must fit the table area");
     RxScalars *S = &sh->S;
-    DecShared *ds = (DecShared *)&sh->wfwd[0][0];
+    DecShared *ds = (DecShared *)&sh->dec_raw[0];
     rd_rx_round *rnd = a.round + b;
     const int tid = rx_tid();
     const int Tb = S->n_rows;
@@ -1578,7 +1537,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
         const float2 bpf_phase = S->bpf_phase;
         if (state == ST_SYNC && !S->lds_sync) {      // the demod / check_pilots tables share LDS with the FFT correlator
-            for (int i = tid; i < RD_M * RD_NFC; i += NT_RX) sh->pw[i / RD_NFC][i % RD_NFC] = make_float2(tab->p_w[i / RD_NFC][i % RD_NFC][0], tab->p_w[i / RD_NFC][i % RD_NFC][1]);
             for (int i = tid; i < RD_M * RD_NC; i += NT_RX) sh->wfwd[i / RD_NC][i % RD_NC] = make_float2(tab->Wfwd[i / RD_NC][i % RD_NC][0], tab->Wfwd[i / RD_NC][i % RD_NC][1]);
             __syncthreads();
             if (tid == 0) S->lds_sync = 1;
@@ -1699,16 +1657,61 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 }
             }
             __syncthreads();
+            // 96 rows (48 draws x {Dt1, Dt2}) x 40 frequencies on the f16 matrix cores, operands split in two binary16
+            // planes: six tasks = 3 row tiles x {f-tiles 0-2, f-tiles 3-4}; the rx window of a row tile is converted
+            // once per k-step and reused by the task's f-tiles; the pilot planes stream from L2 (a.corr16)
             {
-                const int wave = tid >> 6, lane = tid & 63, q = lane >> 4;
-                for (int task = wave; task < 15; task += NT_RX / 64) {
-                    const int tile = task / 5, nt = task - tile * 5;
-                    const int row = tile * 16 + (lane & 15);
-                    f32x4 c1, c2;
-                    corr_tile_mfma(sh, sh->rows48[row], sh->rows48[row] + RD_NMF, nt, c1, c2);
-                    const int f = 8 * nt + 2 * q;
-                    sh->absd[2 * row][f] = hypotf(c1[0], c1[1]); sh->absd[2 * row][f + 1] = hypotf(c1[2], c1[3]);
-                    sh->absd[2 * row + 1][f] = hypotf(c2[0], c2[1]); sh->absd[2 * row + 1][f + 1] = hypotf(c2[2], c2[3]);
+                const int wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+                if (wave < 6) {
+                    const int rt = wave >> 1, nt_base = (wave & 1) ? 3 : 0, ntn = (wave & 1) ? 2 : 3;
+                    const int row = rt * 16 + i;
+                    const float *rxf = (const float *)&sh->rxb[0];
+                    const float *xa = rxf + 2 * sh->rows48[row] + 8 * g, *xb = xa + 2 * RD_NMF;
+                    const unsigned short *pt = a.corr16 + ((size_t)nt_base * 10 * 2 * 64 + lane) * 8;
+                    f32x4 accA[3], accB[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) { accA[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; accB[q] = accA[q]; }
+                    f16x8 ph[3], pl[3];
+                    auto fetch = [&](int sidx) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) if (q < ntn) {
+                            ph[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2) * 64 * 8);
+                            pl[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2 + 1) * 64 * 8);
+                        }
+                    };
+                    fetch(0);
+#pragma unroll 1
+                    for (int sidx = 0; sidx < 10; sidx++) {
+                        f16x8 ah, al, bh, bl, ch[3], cl[3];
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) {
+                            const float2 va = *(const float2 *)(xa + 32 * sidx + j), vb = *(const float2 *)(xb + 32 * sidx + j);
+                            const _Float16 a0 = (_Float16)va.x, a1 = (_Float16)va.y, b0 = (_Float16)vb.x, b1 = (_Float16)vb.y;
+                            ah[j] = a0; ah[j + 1] = a1; al[j] = (_Float16)(va.x - (float)a0); al[j + 1] = (_Float16)(va.y - (float)a1);
+                            bh[j] = b0; bh[j + 1] = b1; bl[j] = (_Float16)(vb.x - (float)b0); bl[j + 1] = (_Float16)(vb.y - (float)b1);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 3; q++) { ch[q] = ph[q]; cl[q] = pl[q]; }
+                        if (sidx + 1 < 10) fetch(sidx + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 3; q++) if (q < ntn) {
+                            accA[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q], ah, accA[q], 0, 0, 0);
+                            accB[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q], bh, accB[q], 0, 0, 0);
+                            accA[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], al, accA[q], 0, 0, 0);
+                            accB[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], bl, accB[q], 0, 0, 0);
+                            accA[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], ah, accA[q], 0, 0, 0);
+                            accB[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], bh, accB[q], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // C layout: column = lane & 15 (row draw), rows 4 (lane >> 4) + r = (re, im) of f = 8 nt + 2 g and f + 1
+#pragma unroll
+                    for (int q = 0; q < 3; q++) if (q < ntn) {
+                        const int f = 8 * (nt_base + q) + 2 * g;
+                        sh->absd[2 * row][f] = hypotf(accA[q][0], accA[q][1]); sh->absd[2 * row][f + 1] = hypotf(accA[q][2], accA[q][3]);
+                        sh->absd[2 * row + 1][f] = hypotf(accB[q][0], accB[q][1]); sh->absd[2 * row + 1][f + 1] = hypotf(accB[q][2], accB[q][3]);
+                    }
                 }
             }
             __syncthreads();
