@@ -143,9 +143,8 @@ typedef struct {
 } rd_chan_args;
 int rd_launch_channel(const rd_chan_args *a, rd_stream_t s);
 
-/* CoreDecoderStatefull.forward for the rows of one receiver round, one workgroup per stream (k_dec_stream): every
- * layer of radae_base.py:388-430 back to back in one launch -- the streams are independent, so no grid-wide
- * step separates the layers.  Same arithmetic (k interleave, reduction order) as the split-K GEMM + scan kernels. */
+/* CoreDecoderStatefull.forward (radae_base.py:388-430) for the pending rows of one stream, run inside the receiver
+ * kernel by the stream's own workgroup (rx_decode_pending -> ds_layers): buffers and weights of that stage. */
 typedef struct { const float *wp, *bias; const unsigned short *wp16; int N, K; } rd_lin;   /* wp16: rd_pack_weights_f16x2 */
 typedef struct {
     const float *z; long z_sb;                 /* [B][.][80] latent rows */
@@ -154,19 +153,16 @@ typedef struct {
     float *hbuf; long hb_sb;                   /* [B][.][96] */
     float *h[5];                               /* GRU states [B][96] */
     float *out; long out_sb; int out_w;        /* [B][.][84] */
-    const int *n_rows; const int *reset; int reset_sb;
     rd_lin dense1, gin[5], glu[5], conv[5], output;
     const float *whh[5], *bhh[5];
     int B;
 } rd_decs_args;
-int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s);
 
 typedef struct {
     const rd_tables *tab; rd_rx_stream *st; rd_rx_round *round;
     const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
     int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
     int max_calls;                                       /* call budget per stream per invocation */
-    int unit_budget, unit_cost[3];                       /* per-launch work budget; cost of a sync / cached search / uncached search call */
     int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
     rd_decs_args dec;                                    /* the decoder runs inside the stream's workgroup (rx_decode_pending) */
     float *features_out; long feat_stride;               /* [B][cap][432] */

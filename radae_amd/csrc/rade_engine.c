@@ -5,9 +5,9 @@
  * Execution model: the encoder / decoder are evaluated layer by layer over
  * ALL streams and ALL time steps of a chunk: the feed-forward part of every layer is one skinny-N
  * f32-MFMA GEMM with M = B*T rows, and only the 64/96-wide GRU recurrences run as serial scans.
- * The receiver runs one persistent workgroup per stream; because the sync state machine consumes the
- * decoder's aux bits (UW errors, radae_rxe.py:220-224, :306-312) the receive side proceeds in rounds
- * of at most RD_RX_ROUND modem frames: sync kernel -> decoder layers -> post kernel.
+ * The receiver runs one workgroup per stream for a whole rade_batch_rx call; the sync state machine consumes the
+ * decoder's aux bits (UW errors, radae_rxe.py:220-224, :306-312), so the decoder runs inside that workgroup
+ * right before every unique-word decision (k_rx_sync -> rx_decode_pending).
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -40,7 +40,7 @@ struct rade_batch {
     void *chan_scratch;
     /* receive side */
     rd_rx_stream *rx_st; rd_rx_round *rx_round;
-    int *rx_avail, *rx_acc, *rx_progress, *rx_nrows, *rx_rowreset, *rx_status;
+    int *rx_avail, *rx_acc, *rx_progress, *rx_status;
     float *zrows, *dec_x, *dec_gi, *dec_hbuf, *dec_h[5], *feat84, *dtcache;
     rd_rx_trace *trace; float *trace_z;
     int *h_small;                    /* pinned host scratch */
@@ -103,7 +103,6 @@ static void rx_reset_on(rade_batch *h, void *stream)
     rd_launch_rx_reset(h->rx_st, h->d_lcg_seeds, (h->flags & RADE_FOFF_TEST) ? 10.0 : 0.0 /* rade_api.c:263-264 */, h->B, st);
     for (int l = 0; l < 5; l++) hipMemsetAsync(h->dec_h[l], 0, sizeof(float) * h->B * 96, st);
     hipMemsetAsync(h->dec_x, 0, sizeof(float) * (size_t)h->B * (1 + h->dec_rows) * RD_DEC_W, st);
-    hipMemsetAsync(h->rx_rowreset, 0, sizeof(int) * h->B * h->dec_rows, st);
     if (h->trace) { hipMemsetAsync(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap, st); hipMemsetAsync(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF, st); }
 }
 static void tx_reset_on(rade_batch *h, void *stream)
@@ -144,7 +143,8 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->B = cfg->n_streams; h->max_tx_mf = cfg->max_tx_mf; h->device = cfg->device; h->flags = cfg->flags;
     h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
     const size_t B = (size_t)h->B, T = (size_t)h->Tcap;
-    /* up to a whole utterance per sync launch (RADE_ROUND_CALLS=1 decodes after every call: no speculated UW checks) */
+    /* do_radae_rx calls per stream and launch (the per-launch bookkeeping arrays hold RD_RX_ROUND_MAX); RADE_ROUND_CALLS
+     * lowers it for tests: the call loop then takes several launches with identical results */
     h->R = getenv("RADE_ROUND_CALLS") ? atoi(getenv("RADE_ROUND_CALLS")) : RD_RX_ROUND_MAX;
     if (h->R < 1) h->R = 1;
     if (h->R > RD_RX_ROUND_MAX) h->R = RD_RX_ROUND_MAX;
@@ -199,7 +199,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->rx_st = dev_zeros(sizeof(rd_rx_stream) * B);
     h->rx_round = dev_zeros(sizeof(rd_rx_round) * B);
     h->rx_avail = dev_zeros(sizeof(int) * B); h->rx_acc = dev_zeros(sizeof(int) * B * 4); h->rx_progress = dev_zeros(sizeof(int) * 4);
-    h->rx_nrows = dev_zeros(sizeof(int) * B); h->rx_rowreset = dev_zeros(sizeof(int) * B * DR); h->rx_status = dev_zeros(sizeof(int) * B * 4);
+    h->rx_status = dev_zeros(sizeof(int) * B * 4);
     h->zrows = dev_zeros(sizeof(float) * B * DR * RD_LATENT);
     h->dec_x = dev_zeros(sizeof(float) * B * (1 + DR) * RD_DEC_W);
     h->dec_gi = dev_zeros(sizeof(float) * B * DR * 288);
@@ -212,7 +212,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     if (!h->dec2_x || !h->dec2_gi || !h->dec2_hbuf) goto fail;
     h->dtcache = dev_zeros(sizeof(float) * B * 2 * RD_NMF * RD_NFC);
     if (!h->enc_xin || !h->enc_x || !h->enc_gi || !h->enc_z || !h->eoo || !h->eoo_bits || !h->chan_scratch || !h->rx_st || !h->rx_round || !h->rx_avail ||
-        !h->rx_acc || !h->rx_progress || !h->rx_nrows || !h->rx_rowreset || !h->rx_status || !h->zrows || !h->dec_x || !h->dec_gi || !h->dec_hbuf || !h->feat84 || !h->dtcache) {
+        !h->rx_acc || !h->rx_progress || !h->rx_status || !h->zrows || !h->dec_x || !h->dec_gi || !h->dec_hbuf || !h->feat84 || !h->dtcache) {
         fprintf(stderr, "rade: device allocation failed\n"); goto fail;
     }
     if (h->trace_cap > 0) {
@@ -255,7 +255,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_nrows, h->rx_rowreset, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16 };
+                     h->rx_progress, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -412,7 +412,7 @@ static void fill_dec_args(const rade_batch *h, rd_decs_args *d)
     d->z = h->zrows; d->z_sb = DR * RD_LATENT; d->x = h->dec_x + RD_DEC_W; d->x_sb = (1 + DR) * RD_DEC_W;
     d->gi = h->dec_gi; d->gi_sb = DR * 288; d->hbuf = h->dec_hbuf; d->hb_sb = DR * 96;
     d->out = h->feat84; d->out_sb = DR * h->feat_in; d->out_w = h->feat_in;
-    d->n_rows = h->rx_nrows; d->reset = h->rx_rowreset; d->reset_sb = h->dec_rows; d->B = h->B;
+    d->B = h->B;
 #define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).wp16 = (src).wp16; (dst).N = (src).N; (dst).K = (src).K; } while (0)
     LIN(d->dense1, h->dec_dense1); LIN(d->output, h->dec_output);
     for (int l = 0; l < 5; l++) { LIN(d->gin[l], h->dec_gin[l]); LIN(d->glu[l], h->dec_glu[l]); LIN(d->conv[l], h->dec_conv[l]); d->whh[l] = h->dec_whh[l]; d->bhh[l] = h->dec_bhh[l]; d->h[l] = h->dec_h[l]; }
@@ -452,11 +452,6 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows;
-    {   /* measured per-call cost ratio on MI355X (tools/phase_timing.py); RADE_UNIT_COSTS="sync,search,search2" overrides */
-        int c0 = 5, c1 = 8, c2 = 14;
-        if (getenv("RADE_UNIT_COSTS")) sscanf(getenv("RADE_UNIT_COSTS"), "%d,%d,%d", &c0, &c1, &c2);
-        sa.unit_cost[0] = c0; sa.unit_cost[1] = c1; sa.unit_cost[2] = c2; sa.unit_budget = getenv("RADE_UNIT_COSTS") ? c0 * h->R : 0x3fffffff;   /* no budget by default: one launch does it all */
-    }
     sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;

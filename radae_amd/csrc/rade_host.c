@@ -301,8 +301,9 @@ static float f16_to_f32(unsigned short h)
     float f; memcpy(&f, &x, 4); return f;
 }
 
-/* W[N][K] (K a multiple of 16) -> B operands of v_mfma_f32_32x32x16_f16 in two planes, w = hi + lo to 22 bits:
- * out[kb][nt][plane][lane][j] = plane(W[32 nt + lane%32][16 kb + 8 (lane/32) + j]) */
+/* W[N][K] (K a multiple of 16) -> B operands of v_mfma_f32_32x32x16_f16 in two planes, 2^10 w = hi + lo to 22 bits
+ * (the power-of-two scale keeps the low plane out of binary16's subnormal range; the GEMM epilogue undoes it):
+ * out[kb][nt][plane][lane][j] = plane(1024 W[32 nt + lane%32][16 kb + 8 (lane/32) + j]) */
 long rd_packed16_size(int N, int K) { return (long)(K / 16) * ((N + 31) / 32) * 2 * 64 * 8; }
 long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out)
 {
@@ -312,7 +313,7 @@ long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out)
             for (int lane = 0; lane < 64; lane++)
                 for (int j = 0; j < 8; j++) {
                     const int nn = nt * 32 + (lane & 31), k = kb * 16 + 8 * (lane >> 5) + j;
-                    const float w = nn < N ? W[(size_t)nn * K + k] : 0.0f;
+                    const float w = nn < N ? 1024.0f * W[(size_t)nn * K + k] : 0.0f;
                     const unsigned short hi = f32_to_f16(w), lo = f32_to_f16(w - f16_to_f32(hi));
                     unsigned short *o = out + ((((size_t)kb * ntt + nt) * 2) * 64 + lane) * 8 + j;
                     o[0] = hi; o[64 * 8] = lo;
@@ -322,7 +323,7 @@ long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out)
 
 /* check_pilots rows on the f16 matrix cores: the realified pilot table Pm[n = 2f + c', k = 2m + c] = {pr, pi; pi, -pr}[c'][c]
  * of p_w[m][f] (dsp.py:207-208 as a real GEMM), split in two binary16 planes and laid out as the A operands of
- * v_mfma_f32_16x16x32_f16: out[nt][s][plane][lane][j] = plane(Pm[16 nt + lane%16][32 s + 8 (lane/16) + j]) */
+ * v_mfma_f32_16x16x32_f16: out[nt][s][plane][lane][j] = plane(2^12 Pm[16 nt + lane%16][32 s + 8 (lane/16) + j]) */
 void rd_corr16_table_fill(const rd_tables *T, unsigned short *out /* [5][10][2][64][8] */)
 {
     for (int nt = 0; nt < 5; nt++)
@@ -332,7 +333,7 @@ void rd_corr16_table_fill(const rd_tables *T, unsigned short *out /* [5][10][2][
                     const int n = 16 * nt + (lane & 15), f = n >> 1, cp = n & 1;
                     const int k = 32 * s + 8 * (lane >> 4) + j, m = k >> 1, c = k & 1;
                     const float pr = T->p_w[m][f][0], pi = T->p_w[m][f][1];
-                    const float v = cp == 0 ? (c == 0 ? pr : pi) : (c == 0 ? pi : -pr);
+                    const float v = 4096.0f * (cp == 0 ? (c == 0 ? pr : pi) : (c == 0 ? pi : -pr));     /* 2^12: low plane stays normal */
                     const unsigned short hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
                     unsigned short *o = out + ((((size_t)nt * 10 + s) * 2) * 64 + lane) * 8 + j;
                     o[0] = hi; o[64 * 8] = lo;

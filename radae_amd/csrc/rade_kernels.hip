@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
         f16x8 ah, al, ch[NT], cl[NT];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const float x = a4[j >> 2][j & 3];
+            const float x = 256.0f * a4[j >> 2][j & 3];         // 2^8 (activations) x 2^10 (packed W): low planes stay normal binary16
             const _Float16 hi = (_Float16)x;
             ah[j] = hi; al[j] = (_Float16)(x - (float)hi);
         }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
             if (rr >= rows) continue;
             const int bb = rr / a.T, tt = rr - bb * a.T;
             if (a.n_rows && tt >= a.n_rows[bb]) continue;
-            float v = acc[i][j] + bias;
+            float v = acc[i][j] * 0x1p-18f + bias;
             if (a.act == 1) v = clamp1(tanhf(v));
             else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * sigmoid_f(v));
             a.y[bb * a.y_sb + tt * a.y_st + col] = v;
@@ -408,9 +408,9 @@ extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
 }
 
 // =====================================================================================================
-// Per-stream fused decoder (receiver rounds): the whole DenseNet stack for one stream's rows in one workgroup of
-// eight wavefronts.  GEMMs split K over the waves exactly like k_gemm_splitk (k-blocks interleaved, partials reduced
-// in wave order), the recurrences run as in k_gru_scan<96>, so the results are bit-identical to the layer-wise path.
+// Per-stream decoder stage of the receiver kernel: the whole DenseNet stack for one stream's pending rows, run by the
+// stream's own workgroup of eight wavefronts.  GEMMs split K over the waves (k-blocks interleaved, partials reduced
+// in wave order through LDS), the recurrences run as in k_gru_scan<96>.
 // =====================================================================================================
 #define DS_NT 3
 struct DecShared {
@@ -420,89 +420,8 @@ struct DecShared {
     int err[RD_DEC_ROWS_MAX];                // receiver: aux-bit (UW) decisions of the decoded rows
 };
 
-// Y[t, n] = act(sum_k [a0 | a1][t, k] W[n, k] + bias[n]) for t < Tb; a0 (K0 floats, may be 0) is the previous row's tap
-template <int NT>
-__device__ void ds_gemm(DecShared *sh, int tid, const float *a1, int a1_st, int K1, const float *a0, int a0_st, int K0, const int *rst,
-                        const rd_lin w, float *y, int y_st, int act, int Tb)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;   // (an opaque index here crashes clang 22's instcombine)
-    const int ntt = (w.N + 31) >> 5;
-    const int nkb0 = K0 >> 3, nkb = nkb0 + (K1 >> 3);
-    const size_t wstep = (size_t)ntt * 256;
-    for (int r0 = 0; r0 < Tb; r0 += 32) {
-        const int t = min(r0 + (lane & 31), Tb - 1);
-        const float *p1 = a1 + (size_t)t * a1_st + 4 * half;
-        const float *p0 = nullptr;
-        if (K0) p0 = ((rst && rst[t]) ? g_zero_row : a0 + (size_t)t * a0_st) + 4 * half;
-        for (int nt0 = 0; nt0 < ntt; nt0 += NT) {
-            f32x16 acc[NT];
-#pragma unroll
-            for (int i = 0; i < NT; i++)
-#pragma unroll
-                for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
-            const float *wbase = w.wp + ((size_t)nt0 * 64 + lane) * 4;
-            // two waves per SIMD cannot hide the L2 latency of the fragment loads: a ring of DEPTH k-blocks is kept in
-            // flight ahead of the matrix instructions (order pinned by the scheduling barriers)
-            constexpr int DEPTH = NT == 1 ? 3 : 1, RING = DEPTH + 1;
-            f32x4 ab[RING], bb[RING][NT];
-            auto fetch = [&](int slot, int kb) {
-                const bool ok = kb < nkb;
-                const int kc = ok ? kb : wave;                     // out-of-range prefetches re-read a valid block (branch-free)
-                ab[slot] = *(const f32x4 *)(kc < nkb0 ? p0 + kc * 8 : p1 + (kc - nkb0) * 8);
-#pragma unroll
-                for (int i = 0; i < NT; i++) bb[slot][i] = (nt0 + i < ntt) ? *(const f32x4 *)(wbase + kc * wstep + i * 256) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            };
-            if (wave < nkb) {
-#pragma unroll
-                for (int d = 0; d < DEPTH; d++) fetch(d, wave + d * SK_WAVES);
-#pragma unroll 1
-                for (int kb = wave; kb < nkb; kb += RING * SK_WAVES) {
-#pragma unroll
-                    for (int u = 0; u < RING; u++) {
-                        const int kc = kb + u * SK_WAVES;
-                        if (kc < nkb) {                            // uniform per wave
-                            fetch((u + DEPTH) % RING, kc + DEPTH * SK_WAVES);
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int s = 0; s < 4; s++)
-#pragma unroll
-                                for (int i = 0; i < NT; i++)
-                                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[u][s], bb[u][i][s], acc[i], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NT; i++)
-#pragma unroll
-                for (int j = 0; j < 16; j++) sh->red[wave][i][j][lane] = acc[i][j];
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < NT; i++) {
-                const int col = (nt0 + i) * 32 + (lane & 31);
-                if (nt0 + i >= ntt || col >= w.N) continue;
-                const float bias = w.bias ? w.bias[col] : 0.0f;
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++) {
-                    const int j = wave * 2 + jj;
-                    float v = 0.0f;
-#pragma unroll
-                    for (int ww = 0; ww < SK_WAVES; ww++) v += sh->red[ww][i][j][lane];
-                    const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
-                    if (tt >= Tb) continue;
-                    v += bias;
-                    if (act == 1) v = clamp1(tanhf(v));
-                    else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * sigmoid_f(v));
-                    y[(size_t)tt * y_st + col] = v;
-                }
-            }
-            __syncthreads();                     // partials are reused by the next tile group; y is read by the next layer
-        }
-    }
-}
-
-// Same GEMM on the f16 matrix cores with both operands split in two binary16 planes (v = hi + lo, 22 bits):
+// Y[t, n] = act(sum_k [a0 | a1][t, k] W[n, k] + bias[n]) for t < Tb; a0 (K0 floats, may be 0) is the previous row's tap.
+// f16 matrix cores with both operands split in two binary16 planes (v = hi + lo, 22 bits):
 // acc += A_hi B_hi + A_hi B_lo + A_lo B_hi per 16-deep k-block (the dropped lo*lo term is 2^-22 relative; products
 // are exact, accumulation is f32 as before).  v_mfma_f32_32x32x16_f16 moves 16 k per 8 passes where the f32
 // instruction moves 2 per 16, so the three products cost a fifth of the f32 time.  The activations are split on the
@@ -544,7 +463,7 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
                 f16x8 ah, al;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float x = j < 4 ? a_lo4[j] : a_hi4[j - 4];
+                    const float x = 256.0f * (j < 4 ? a_lo4[j] : a_hi4[j - 4]);   // 2^8 x 2^10 (packed W), undone in the epilogue
                     const _Float16 hi = (_Float16)x;
                     ah[j] = hi; al[j] = (_Float16)(x - (float)hi);
                 }
@@ -579,7 +498,7 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
                     for (int ww = 0; ww < SK_WAVES; ww++) v += sh->red[ww][i][j][lane];
                     const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
                     if (tt >= Tb) continue;
-                    v += bias;
+                    v = v * 0x1p-18f + bias;
                     if (act == 1) v = clamp1(tanhf(v));
                     else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * sigmoid_f(v));
                     y[(size_t)tt * y_st + col] = v;
@@ -671,28 +590,6 @@ __device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb, i
     }
     ds_gemm16<DS_NT>(sh, tid, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
     PH(21);
-}
-
-__global__ __launch_bounds__(64 * SK_WAVES) void k_dec_stream(rd_decs_args a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char ds_raw[];
-    DecShared *sh = (DecShared *)ds_raw;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int Tb = a.n_rows[b];
-    if (Tb <= 0) return;
-    const int *rstg = a.reset + (size_t)b * a.reset_sb;
-    for (int i = tid; i < Tb; i += blockDim.x) sh->rst[i] = rstg[i];
-    __syncthreads();
-    ds_layers(sh, a, b, Tb, tid);
-}
-
-extern "C" int rd_launch_dec_stream(const rd_decs_args *a, rd_stream_t s)
-{
-    if (a->B <= 0) return 0;
-    static int attr_done = 0;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void *)k_dec_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DecShared)); attr_done = 1; }
-    hipLaunchKernelGGL(k_dec_stream, dim3(a->B), dim3(64 * SK_WAVES), sizeof(DecShared), (hipStream_t)s, *a);
-    return (int)hipGetLastError();
 }
 
 // =====================================================================================================
@@ -998,7 +895,7 @@ struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
     uint32_t lcg;
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
-    int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync, units;
+    int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
     float snr_est, mag; float2 bpf_phase;
     double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
 };
@@ -1504,7 +1401,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
         S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->units = 0; S->need_decode = 0; S->batch_call0 = 0;
+        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0;
     }
     const int avail = a.avail[b];
     __syncthreads();
@@ -1519,10 +1416,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             int go = 1;
             if (S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls) go = 0;
             else if (S->consumed_inv + S->nin > avail) go = 0;
-            else {      // work units level a round's duration between searching (FFT correlator) and synchronised streams
-                const int cost = S->state == ST_SYNC ? a.unit_cost[0] : (S->dt_valid ? a.unit_cost[1] : a.unit_cost[2]);
-                if (S->units > 0 && S->units + cost > a.unit_budget) go = 0; else S->units += cost;
-            }
             // the decoder runs right here, in this workgroup, when its output is needed: before a unique-word check
             // (radae_rxe.py:220-224 looks at the aux bits of the 8 frames before this one) or when the row buffer is full
             // ... or when this launch ends for the stream (out of samples, call limit)
@@ -1685,7 +1578,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                         f16x8 ah, al, bh, bl, ch[3], cl[3];
 #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
-                            const float2 va = *(const float2 *)(xa + 32 * sidx + j), vb = *(const float2 *)(xb + 32 * sidx + j);
+                            float2 va = *(const float2 *)(xa + 32 * sidx + j), vb = *(const float2 *)(xb + 32 * sidx + j);
+                            va.x *= 256.0f; va.y *= 256.0f; vb.x *= 256.0f; vb.y *= 256.0f;       // 2^8 (samples) x 2^12 (pilot planes)
                             const _Float16 a0 = (_Float16)va.x, a1 = (_Float16)va.y, b0 = (_Float16)vb.x, b1 = (_Float16)vb.y;
                             ah[j] = a0; ah[j + 1] = a1; al[j] = (_Float16)(va.x - (float)a0); al[j + 1] = (_Float16)(va.y - (float)a1);
                             bh[j] = b0; bh[j + 1] = b1; bl[j] = (_Float16)(vb.x - (float)b0); bl[j + 1] = (_Float16)(vb.y - (float)b1);
@@ -1709,8 +1603,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 #pragma unroll
                     for (int q = 0; q < 3; q++) if (q < ntn) {
                         const int f = 8 * (nt_base + q) + 2 * g;
-                        sh->absd[2 * row][f] = hypotf(accA[q][0], accA[q][1]); sh->absd[2 * row][f + 1] = hypotf(accA[q][2], accA[q][3]);
-                        sh->absd[2 * row + 1][f] = hypotf(accB[q][0], accB[q][1]); sh->absd[2 * row + 1][f + 1] = hypotf(accB[q][2], accB[q][3]);
+                        sh->absd[2 * row][f] = 0x1p-20f * hypotf(accA[q][0], accA[q][1]); sh->absd[2 * row][f + 1] = 0x1p-20f * hypotf(accA[q][2], accA[q][3]);
+                        sh->absd[2 * row + 1][f] = 0x1p-20f * hypotf(accB[q][0], accB[q][1]); sh->absd[2 * row + 1][f + 1] = 0x1p-20f * hypotf(accB[q][2], accB[q][3]);
                     }
                 }
             }
