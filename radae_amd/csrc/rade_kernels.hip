@@ -34,6 +34,28 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// e^{-j angle(c)} = conj(c)/|c| (np.exp(-1j*np.angle(c)) without atan2 / sincos); angle(0) = 0
+__device__ __forceinline__ float2 unit_conj(float2 c)
+{
+#ifdef RD_NO_UNITCONJ
+    { const float ang = atan2f(c.y, c.x); float sn, cs; sincosf(-ang, &sn, &cs); return make_float2(cs, sn); }
+#endif
+    const float n2 = c.x * c.x + c.y * c.y;
+    if (n2 == 0.0f) return make_float2(1.0f, 0.0f);
+    const float inv = 1.0f / sqrtf(n2);
+    return make_float2(c.x * inv, -c.y * inv);
+}
+// (cos, sin) of a double angle: reduced to [-pi, pi] in double, evaluated in float (the results are used as float32)
+__device__ __forceinline__ float2 cis_reduced(double ang)
+{
+#ifdef RD_NO_CIS
+    double sd, cd; sincos(ang, &sd, &cd); return make_float2((float)cd, (float)sd);
+#else
+    const double r = ang - 6.283185307179586476925 * rint(ang * 0.15915494309189533577);
+    float sn, cs; sincosf((float)r, &sn, &cs);
+    return make_float2(cs, sn);
+#endif
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 // thread index through an opaque asm: inside the receiver's per-call loop this keeps the compiler from hoisting every
 // thread-derived address computation of every phase out of the loop (hundreds of registers live across all phases)
@@ -1622,7 +1644,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             double red[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
             for (int t = tid; t < RD_NMF; t += NT_RX) { red[0] += (double)sh->rowsum1[t]; red[1] += (double)sh->rowsum2[t]; }
             if (tid < RD_M) {
-                double sn, cs; sincos(-w * tid, &sn, &cs);
+                const float2 cf = cis_reduced(-w * tid);
+                const double sn = cf.y, cs = cf.x;
                 rx_corr_term(sh, tm, sn, cs, sh->pd, red[2], red[3]);
                 rx_corr_term(sh, tm + RD_NMF, sn, cs, sh->pd, red[4], red[5]);
                 rx_corr_term(sh, tm + RD_M + RD_NCP, sn, cs, sh->pendd, red[6], red[7]);
@@ -1651,7 +1674,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             // frequency correction (:227-233): rx_phase advances e^{-jw} per sample in complex128
             float2 *rx1 = sh->xm;
             for (int n = tid; n < RD_NEOO; n += NT_RX) {
-                double s, c; sincos(-w * (double)(n + 1), &s, &c);
+                const float2 cs = cis_reduced(-w * (double)(n + 1));
+                const double c = cs.x, s = cs.y;
                 const float pr = (float)(rph_r * c - rph_i * s), pi = (float)(rph_r * s + rph_i * c);
                 rx1[n] = cmul(sh->rxb[tmax - RD_NCP + n], make_float2(pr, pi));
             }
@@ -1701,9 +1725,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     float s1 = 0.0f, s2 = 0.0f, pm = 0.0f;
                     if (tid < RD_NC) {
                         const float2 r0 = sh->rp[0][tid], r1 = sh->rp[1][tid], pc = sh->sym[0][tid];
-                        const float ph = atan2f(r0.y, r0.x);
-                        float sn, cs; sincosf(-ph, &sn, &cs);
-                        const float2 rc = cmul(pc, make_float2(cs, sn));
+                        const float2 rc = cmul(pc, unit_conj(r0));
                         const float ap = hypotf(pc.x, pc.y); s1 = ap * ap; s2 = fabsf(rc.y) * fabsf(rc.y);
                         const float a0 = hypotf(r0.x, r0.y), a1 = hypotf(r1.x, r1.y); pm = a0 * a0 + a1 * a1;
                     }
@@ -1730,9 +1752,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     const float2 r0 = sh->rp[0][c], r1 = sh->rp[1][c];
                     const float2 slope = make_float2((r1.x - r0.x) / 5.0f, (r1.y - r0.y) / 5.0f);
                     const float2 ch = make_float2(slope.x * (float)k + r0.x, slope.y * (float)k + r0.y);
-                    const float ang = atan2f(ch.y, ch.x);
-                    float sn, cs; sincosf(-ang, &sn, &cs);
-                    const float2 v = cmul(sh->sym[k][c], make_float2(cs, sn));
+                    const float2 v = cmul(sh->sym[k][c], unit_conj(ch));
                     const float zr = v.x / mag, zi = v.y / mag;
                     zrow[2 * tid] = zr; zrow[2 * tid + 1] = zi;
                     if (a.trace_z && call_idx0 < a.trace_cap) { float *tz = a.trace_z + ((size_t)b * a.trace_cap + call_idx0) * RD_ZMF; tz[2 * tid] = zr; tz[2 * tid + 1] = zi; }
@@ -1744,9 +1764,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     const float pp = tab->P[c], pe = tab->Pend[c];
                     const float2 s = make_float2(sh->sym[0][c].x / pp + sh->sym[1][c].x / pe + sh->sym[5][c].x / pe,
                                                  sh->sym[0][c].y / pp + sh->sym[1][c].y / pe + sh->sym[5][c].y / pe);
-                    const float ang = atan2f(s.y, s.x);
-                    float sn, cs; sincosf(-ang, &sn, &cs);
-                    const float2 v = cmul(sh->sym[k][c], make_float2(cs, sn));
+                    const float2 v = cmul(sh->sym[k][c], unit_conj(s));
                     if (eoo_dst) { eoo_dst[2 * tid] = v.x; eoo_dst[2 * tid + 1] = v.y; }
                     if (a.trace_z && call_idx0 < a.trace_cap) { float *tz = a.trace_z + ((size_t)b * a.trace_cap + call_idx0) * RD_ZMF; tz[2 * tid] = v.x; tz[2 * tid + 1] = v.y; }
                 }

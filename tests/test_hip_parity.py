@@ -264,6 +264,29 @@ def test_streams_are_independent_and_ragged(Engine, torch_dev, golden):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["mpp", "foff"])
+def test_many_identical_streams_agree(Engine, torch_dev, golden, name):
+    """Race / slot-dependence guard: 96 copies of one golden stream (more workgroups than fit one XCD) must come out
+    bit-identical in every slot, twice in a row, and equal to the golden trace."""
+    import torch
+    g = golden("rxtrace_" + name)
+    B = 96
+    buf = torch.tensor(np.stack([g["rx_in"]] * B), device=torch_dev)
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64, flags=4 if name == "foff" else 0)
+    for rep in range(2):
+        eng.rx_reset()
+        f, st, _ = eng.rx(buf)
+        f = f.cpu().numpy()
+        for b in range(1, B):
+            assert st[b].n_calls == st[0].n_calls and st[b].n_valid == st[0].n_valid, (rep, b)
+            assert np.array_equal(f[b], f[0]), (rep, b)
+        for b in (0, B // 2, B - 1):
+            t = eng.rx_trace(b)
+            for k in INT_KEYS:
+                assert np.array_equal(t[k], g[k]), (rep, b, k)
+    eng.close()
+
+
 def test_single_stream_c_abi(golden):
     """rade_api.h entry points (what radae_tx.c / radae_rx.c / freedv-gui call), via radae_amd.api."""
     from radae_amd import api
