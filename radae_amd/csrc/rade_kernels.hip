@@ -678,10 +678,10 @@ extern "C" int rd_launch_carry_rows(float *x, int B, int Tcap, int W, int nhist,
 // tanh(|x|) * exp(j*angle(x))   (radae.py:218, dsp.py:377)
 __device__ __forceinline__ float2 pa_limit(float2 x)
 {
-    const float mag = hypotf(x.x, x.y), ang = atan2f(x.y, x.x);
-    const float t = tanhf(mag);
-    float sn, cs; sincosf(ang, &sn, &cs);
-    return make_float2(t * cs, t * sn);
+    const float mag = hypotf(x.x, x.y);
+    if (mag == 0.0f) return make_float2(0.0f, 0.0f);
+    const float g = tanhf(mag) / mag;                     // tanh(|x|) e^{j angle(x)} = x tanh(|x|)/|x|
+    return make_float2(x.x * g, x.y * g);
 }
 
 // one workgroup per (modem frame, stream): 5 symbols x 160 samples, 30-term IDFT per sample
@@ -695,11 +695,18 @@ __global__ __launch_bounds__(192) void k_ofdm_mod(const rd_tables *tab, const fl
     __syncthreads();
     float2 *out = tx + (size_t)b * tx_stride + (size_t)mf * RD_NMF;
     if (tid < RD_M) {
-        for (int s = 0; s <= RD_NS; s++) {
-            float2 acc = make_float2(0.0f, 0.0f);
+        float2 acc[RD_NS + 1];
+#pragma unroll
+        for (int s = 0; s <= RD_NS; s++) acc[s] = make_float2(0.0f, 0.0f);
 #pragma unroll 6
-            for (int c = 0; c < RD_NC; c++) acc = cadd(acc, cmul(sym[s][c], ld2(tab->Winv[c], tid)));
-            const float2 v = pa_limit(acc);
+        for (int c = 0; c < RD_NC; c++) {                 // one Winv load feeds the five symbols of the frame
+            const float2 w = ld2(tab->Winv[c], tid);
+#pragma unroll
+            for (int s = 0; s <= RD_NS; s++) acc[s] = cadd(acc[s], cmul(sym[s][c], w));
+        }
+#pragma unroll
+        for (int s = 0; s <= RD_NS; s++) {
+            const float2 v = pa_limit(acc[s]);
             out[s * RD_SYM + RD_NCP + tid] = v;
             if (tid >= RD_M - RD_NCP) out[s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
         }
