@@ -134,7 +134,7 @@ def main():
         # HBM bytes per launch come from the separate rocprofv3 --pmc passes of this same command (profiles/r01_pmc_summary.json)
         traffic, mfma_busy = None, None
         try:
-            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))["kernels"][{"rx_sync": "k_rx_sync", "gemm": "void k_gemm16<3>", "gru_scan": "void k_gru_scan<64>"}.get(dom, dom)]
+            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))["kernels"][{"rx_sync": "k_rx_sync", "gemm": "void k_gemm16<3, 2>", "gru_scan": "void k_gru_scan<64>"}.get(dom, dom)]
             traffic = pm["fetch_bytes_per_dispatch"] + pm["write_bytes_per_dispatch"]; mfma_busy = pm["mfma_busy_pct"]
         except Exception:
             pass

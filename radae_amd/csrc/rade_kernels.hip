@@ -164,78 +164,94 @@ __global__ __launch_bounds__(64) void k_gemm(rd_gemm_args a)
 // The same GEMM on the f16 matrix cores, operands split in two binary16 planes (see ds_gemm16 below for the
 // arithmetic): activations are split on the fly, W comes from rd_pack_weights_f16x2.  K segments are multiples of 16.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int NT>
+template <int NT, int RT>
 __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
-{
+{   // one wavefront = RT row tiles of 32 rows x NT column tiles: every W fragment is applied to RT row tiles, so the L2 traffic
+    // for the weights (the whole matrix per workgroup) drops RT-fold
     const int lane = threadIdx.x;
     const int rows = a.B * a.T;
-    const int r0 = blockIdx.x * 32;
+    const int r0 = blockIdx.x * 32 * RT;
     const int ntt = (a.N + 31) >> 5;
     const int nt0 = blockIdx.y * NT;
-    int r = r0 + (lane & 31);
-    if (r >= rows) r = rows - 1;
-    const int b = r / a.T, t = r - b * a.T;
     const int half = lane >> 5;
-    const float *p1 = a.a1 + b * a.a1_sb + t * a.a1_st + 8 * half;
-    const float *p0 = nullptr;
-    if (a.K0) {
-        const bool rst = a.reset && a.reset[b * a.reset_sb + t];
-        p0 = (rst ? g_zero_row : a.a0 + b * a.a0_sb + t * a.a0_st) + 8 * half;
+    const float *p1[RT], *p0[RT];
+#pragma unroll
+    for (int q = 0; q < RT; q++) {
+        int r = r0 + 32 * q + (lane & 31);
+        if (r >= rows) r = rows - 1;
+        const int b = r / a.T, t = r - b * a.T;
+        p1[q] = a.a1 + b * a.a1_sb + t * a.a1_st + 8 * half;
+        p0[q] = nullptr;
+        if (a.K0) {
+            const bool rst = a.reset && a.reset[b * a.reset_sb + t];
+            p0[q] = (rst ? g_zero_row : a.a0 + b * a.a0_sb + t * a.a0_st) + 8 * half;
+        }
     }
-    f32x16 acc[NT];
+    f32x16 acc[RT][NT];
 #pragma unroll
-    for (int i = 0; i < NT; i++)
+    for (int q = 0; q < RT; q++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[q][i][j] = 0.0f;
     const int nkb0 = a.K0 >> 4, nkb = nkb0 + (a.K1 >> 4);
     const unsigned short *wbase = a.Wp16 + ((size_t)nt0 * 2 * 64 + lane) * 8;
     const size_t wstep = (size_t)ntt * 2 * 64 * 8;
-    f32x4 a4[2]; f16x8 bh[NT], bl[NT];
+    f32x4 a4[RT][2]; f16x8 bh[NT], bl[NT];
     auto fetch = [&](int kb) {
-        const float *p = kb < nkb0 ? p0 + kb * 16 : p1 + (kb - nkb0) * 16;
-        a4[0] = *(const f32x4 *)p; a4[1] = *(const f32x4 *)(p + 4);
+#pragma unroll
+        for (int q = 0; q < RT; q++) {
+            const float *p = kb < nkb0 ? p0[q] + kb * 16 : p1[q] + (kb - nkb0) * 16;
+            a4[q][0] = *(const f32x4 *)p; a4[q][1] = *(const f32x4 *)(p + 4);
+        }
 #pragma unroll
         for (int i = 0; i < NT; i++) { bh[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8); bl[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8 + 64 * 8); }
     };
     fetch(0);
 #pragma unroll 1
     for (int kb = 0; kb < nkb; kb++) {
-        f16x8 ah, al, ch[NT], cl[NT];
+        f16x8 ah[RT], al[RT], ch[NT], cl[NT];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float x = 256.0f * a4[j >> 2][j & 3];         // 2^8 (activations) x 2^10 (packed W): low planes stay normal binary16
-            const _Float16 hi = (_Float16)x;
-            ah[j] = hi; al[j] = (_Float16)(x - (float)hi);
-        }
+        for (int q = 0; q < RT; q++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float x = 256.0f * a4[q][j >> 2][j & 3];     // 2^8 (activations) x 2^10 (packed W): low planes stay normal binary16
+                const _Float16 hi = (_Float16)x;
+                ah[q][j] = hi; al[q][j] = (_Float16)(x - (float)hi);
+            }
 #pragma unroll
         for (int i = 0; i < NT; i++) { ch[i] = bh[i]; cl[i] = bl[i]; }
         if (kb + 1 < nkb) fetch(kb + 1);                    // next k-block's loads fly during the matrix instructions
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ch[i], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cl[i], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ch[i], acc[i], 0, 0, 0);
-        }
+        for (int q = 0; q < RT; q++)
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q], ch[i], acc[q][i], 0, 0, 0);
+                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], cl[i], acc[q][i], 0, 0, 0);
+                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], ch[i], acc[q][i], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < NT; i++) {
-        const int col = (nt0 + i) * 32 + (lane & 31);
-        if (col >= a.N) continue;
-        const float bias = a.bias ? a.bias[col] : 0.0f;
+    for (int q = 0; q < RT; q++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int rr = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
-            if (rr >= rows) continue;
-            const int bb = rr / a.T, tt = rr - bb * a.T;
-            if (a.n_rows && tt >= a.n_rows[bb]) continue;
-            float v = acc[i][j] * 0x1p-18f + bias;
-            if (a.act == 1) v = clamp1(tanhf(v));
-            else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * sigmoid_f(v));
-            a.y[bb * a.y_sb + tt * a.y_st + col] = v;
+        for (int i = 0; i < NT; i++) {
+            const int col = (nt0 + i) * 32 + (lane & 31);
+            if (col >= a.N) continue;
+            const float bias = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int rr = r0 + 32 * q + (j & 3) + 8 * (j >> 2) + 4 * half;
+                if (rr >= rows) continue;
+                const int bb = rr / a.T, tt = rr - bb * a.T;
+                if (a.n_rows && tt >= a.n_rows[bb]) continue;
+                float v = acc[q][i][j] * 0x1p-18f + bias;
+                if (a.act == 1) v = clamp1(tanhf(v));
+                else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * sigmoid_f(v));
+                a.y[bb * a.y_sb + tt * a.y_st + col] = v;
+            }
         }
-    }
 }
 
 // Small-M variant (decoder rounds, single-stream API): the K loop is the latency, so 8 wavefronts of one
@@ -339,9 +355,10 @@ extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
     }
     dim3 block(64);
     if (a->Wp16 && (a->K0 & 15) == 0 && (a->K1 & 15) == 0) {          // f16 matrix cores, two-plane operands
-        if (ntt % 3 == 0) { dim3 grid(gx, ntt / 3); hipLaunchKernelGGL(k_gemm16<3>, grid, block, 0, st, *a); }
-        else if (ntt % 2 == 0) { dim3 grid(gx, ntt / 2); hipLaunchKernelGGL(k_gemm16<2>, grid, block, 0, st, *a); }
-        else { dim3 grid(gx, ntt); hipLaunchKernelGGL(k_gemm16<1>, grid, block, 0, st, *a); }
+        const int gx2 = (rows + 63) / 64;
+        if (ntt % 3 == 0) { dim3 grid(gx2, ntt / 3); hipLaunchKernelGGL((k_gemm16<3, 2>), grid, block, 0, st, *a); }
+        else if (ntt % 2 == 0) { dim3 grid(gx2, ntt / 2); hipLaunchKernelGGL((k_gemm16<2, 2>), grid, block, 0, st, *a); }
+        else { dim3 grid(gx2, ntt); hipLaunchKernelGGL((k_gemm16<1, 2>), grid, block, 0, st, *a); }
         return (int)hipGetLastError();
     }
     if (ntt % 3 == 0) { dim3 grid(gx, ntt / 3); hipLaunchKernelGGL(k_gemm<3>, grid, block, 0, st, *a); }
