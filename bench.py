@@ -108,7 +108,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "model19_check3 streaming radae_txe -> OFDM + MPP multipath/AWGN 3 dB/-11 Hz -> radae_rxe (configs[2])",
-                   "streams_per_gpu": B, "frames_per_stream": T, "global_streams": B * world, "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only"},
+                   "streams_per_gpu": B, "frames_per_stream": T, "global_streams": B * world, "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only",
+                   "arithmetic": "f32 DSP, f64 refine, matrix products on split-binary16 (2 x 11 bit) MFMA with f32 accumulation"},
     }
     if rank == 0:
         # sanity of what was timed: decoded frames and the loss.py-style aligned loss of stream 0
