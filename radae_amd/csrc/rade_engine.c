@@ -462,21 +462,23 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
         PROF_BEGIN(h, st);
         if (rd_launch_rx_sync(&sa, st)) goto fail;
         PROF_END(h, st, RADE_PROF_SYNC, 0.0);
+        /* progress word and (normally final) per-stream results come back in one round trip */
         CHK(hipMemcpyAsync(hs, h->rx_progress, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
+        if (status_host) {
+            CHK(hipMemcpyAsync(hs + 8, h->rx_acc, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
+            CHK(hipMemcpyAsync(hs + 8 + 4 * B, h->rx_status, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
+        }
         CHK(hipStreamSynchronize(st));
         if (hs[0] == 0 || hs[1] == 0) break;    /* nothing done, or no stream stopped at the per-launch limit */
     }
     if (status_host) {
-        int *acc = hs + 8, *sts = hs + 8 + 4 * B;
-        CHK(hipMemcpyAsync(acc, h->rx_acc, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
-        CHK(hipMemcpyAsync(sts, h->rx_status, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
-        CHK(hipStreamSynchronize(st));
+        const int *acc = hs + 8, *sts = hs + 8 + 4 * B;
         for (int b = 0; b < B; b++) {
             rade_rx_status *s = status_host + b;
             s->consumed = acc[4 * b]; s->n_calls = acc[4 * b + 1]; s->n_valid = acc[4 * b + 2]; s->has_eoo = acc[4 * b + 3] > 0;
             s->nin = sts[4 * b]; s->sync = sts[4 * b + 1]; s->snr_dB = sts[4 * b + 2]; s->state = sts[4 * b + 3];
         }
-    } else CHK(hipStreamSynchronize(st));
+    }
     return 0;
 fail:
     return -1;
