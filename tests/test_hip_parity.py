@@ -365,6 +365,63 @@ def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model):
     eng.close()
 
 
+@pytest.mark.parametrize("kind", ["noise", "sine"])
+def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind):
+    """The reference's acq_noise / acq_sine ctests (CMakeLists.txt:191-208): real-valued noise, or a 1 kHz sine in noise,
+    converted with Q = 0 (int16tof32.py --zeropad), must never synchronise.  12 s per stream, 8 streams with different
+    seeds; stream 0 is also checked call by call against the oracle."""
+    import torch
+    B, n = 8, 96000
+    rng = np.random.default_rng(77 if kind == "noise" else 78)
+    x = 0.1 * rng.standard_normal((B, n))
+    if kind == "sine":
+        x += 0.25 * np.cos(2 * np.pi * 1000.0 / 8000.0 * np.arange(n))[None]
+    rx = x.astype(np.float32).astype(np.complex64)                     # Q == 0
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=128)
+    f, st, _ = eng.rx(torch.tensor(rx, device=torch_dev))
+    for b in range(B):
+        assert st[b].n_calls == n // 960 and st[b].n_valid == 0 and st[b].sync == 0, (kind, b)
+        assert not np.any(eng.rx_trace(b)["state_after"] == 2), (kind, b)
+    t = eng.rx_trace(0)
+    d = oracle.run_rx_stream(oracle_model, rx[0])
+    for k in INT_KEYS:
+        assert np.array_equal(t[k], d[k]), (kind, k)
+    assert np.abs(t["Dtmax12"] - d["Dtmax12"]).max() < 3e-5 * max(1.0, np.abs(d["Dtmax12"]).max())
+    eng.close()
+
+
+def test_acquisition_statistics_mpp(Engine, torch_dev):
+    """rx.py --acq_test in batch form (rx.py:163-195, ctest acq_mpp): 64 utterances at 0 dB Eb/No on the MPP channel with
+    a +10 Hz offset.  Every stream must find sync, in less than 1.5 s of signal on average, with the entry timing inside
+    the 2.5 ms window and the coarse frequency within 5 Hz of the truth for at least 80 % of the streams."""
+    import torch
+    from radae_amd.engine import sigma_from_EbNodB
+    from radae_amd.channel_tools import multipath_g, synth_features
+    B, n_mf, n_pre, fo = 64, 40, 4000, 10.0
+    feats = np.stack([synth_features(300 + b, 12 * n_mf) for b in range(B)])
+    G = np.stack([multipath_g("mpp", 8000, n_mf * 960, 900 + b) for b in range(B)])
+    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=64)
+    iq = eng.tx(torch.tensor(feats, device=torch_dev))
+    rx = eng.channel(iq, sigma_from_EbNodB(0.0), fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=torch.tensor(G, device=torch_dev), seed=5)
+    f, st, _ = eng.rx(rx)
+    acq_calls, ok = [], 0
+    for b in range(B):
+        t = eng.rx_trace(b)
+        entry = np.nonzero((t["state_before"] == 1) & (t["state_after"] == 2))[0]
+        assert len(entry) > 0, b
+        c = int(entry[0])
+        acq_calls.append(c)
+        # modem frame k starts at sample n_pre + 960 k; its pilot body follows the 32-sample cyclic prefix and leaves the
+        # band-pass filter 50 + 2 samples later (dsp.py:55 vs :96); rx_buf holds the last 2112 samples after c + 1 calls
+        t_true = (n_pre + 32 + 52 - (960 * (c + 1) - 2112)) % 960
+        dt = (int(t["tmax"][c]) - t_true + 480) % 960 - 480
+        ok += int(-20 < dt < 20 + 16 and abs(float(t["fmax"][c]) - fo) <= 5.0)      # 2.5 ms window (rx.py:176); the MPP echo is 16 samples late
+    mean_t = (np.mean(acq_calls) + 1) * 0.12 - n_pre / 8000.0
+    assert ok >= 0.8 * B, (ok, B)
+    assert mean_t < 1.5, mean_t
+    eng.close()
+
+
 def _pipe(exe, args, data, cwd):
     import subprocess
     p = subprocess.run([exe] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd, timeout=300)
