@@ -82,10 +82,22 @@ typedef struct {
     const void *G_dev;    /* [B][n_sig][2] complex64 Doppler samples (G1,G2) or NULL = (1,0) */
     const void *noise_dev;/* [B][n_total] complex64, unit variance, or NULL: generate (Philox) from seed; seed 0 = no noise */
     unsigned long long seed;
+    float sine_amp, sine_freq;   /* complex tone added over the whole output, inference.py:285-288 (--sine_amp/--sine_freq); 0 = none */
+    float rx_gain;               /* final scale, inference.py:289 (--rx_gain); 0 is taken as 1 */
 } rade_channel_params;
 /* n_total = n_pre + n_sig + (with_eoo ? 1152 : 0) + n_post samples written per stream; returns n_total */
 int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *rx_out_dev, long rx_stride,
                        const rade_channel_params *p, void *stream);
+
+/* ---- Watterson / Doppler-spread sample generator on the device (doppler_spread.m:7-50, multipath_samples.m:10-31):
+ * per stream two independent paths G1, G2 = complex Gaussian noise at the low rate Fs/low_ratio through the
+ * n_taps Gaussian-PSD FIR (taps designed by the caller, e.g. radae_amd/channel_tools.py), linearly interpolated to
+ * Fs, scaled by hf_gain = 1/sqrt(var G1 + var G2).
+ * noise_low_dev : optional [B][2][n_low + n_taps] complex64 unit-variance-per-component input noise with
+ *                 n_low = max(ceil(n_out / low_ratio), 2); NULL: Philox from seed
+ * G_out_dev     : [B][n_out][2] complex64, the layout rade_channel_params.G_dev takes.  Returns n_out or <0. */
+int rade_batch_multipath_gen(rade_batch *h, const float *fir_taps_host, int n_taps, int low_ratio, int n_out,
+                             const void *noise_low_dev, unsigned long long seed, void *G_out_dev, void *stream);
 float rade_sigma_from_EbNodB(float EbNodB);
 
 /* ---- receive --------------------------------------------------------------------------------

@@ -423,8 +423,23 @@ def gen_bbfm():
     print("bbfm ok Gfm", model.Gfm, "frac below FM threshold (ray):", float(np.mean(20 * np.log10(Hray) + 14.0 < 12)))
 
 
+def gen_wire():
+    """int16 <-> f32 converters: the reference's own scripts (int16tof32.py, f32toint16.py) run as subprocesses on fixed bytes."""
+    import subprocess
+    rng = np.random.default_rng(5)
+    i16 = rng.integers(-32768, 32767, 2001, dtype=np.int16).tobytes()             # odd count: the trailing sample is dropped
+    f32 = np.concatenate([rng.uniform(-1.2, 1.2, 600), [0.99999, -0.99999, 1.0, -1.0, 0.5 / 32767, -0.5 / 32767]]).astype(np.float32).tobytes()
+    run = lambda script, args, data: subprocess.run([sys.executable, os.path.join(REF, script)] + args, input=data, stdout=subprocess.PIPE, check=True).stdout
+    np.savez_compressed(os.path.join(OUT, "wire.npz"), i16=np.frombuffer(i16, np.uint8), f32=np.frombuffer(f32, np.uint8),
+                        i2f=np.frombuffer(run("int16tof32.py", [], i16), np.uint8), i2f_zp=np.frombuffer(run("int16tof32.py", ["--zeropad"], i16), np.uint8),
+                        f2i=np.frombuffer(run("f32toint16.py", [], f32), np.uint8), f2i_real=np.frombuffer(run("f32toint16.py", ["--real"], f32), np.uint8),
+                        f2i_scale=np.frombuffer(run("f32toint16.py", ["--scale", "8192"], f32), np.uint8))
+    print("wire ok")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec", "model05", "bbfm"]
+    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec", "model05", "bbfm", "wire"]
+    if "wire" in which: gen_wire()
     if "consts" in which: gen_consts()
     if "weights" in which: gen_weights_check()
     if "enc" in which: gen_enc_tx()

@@ -37,6 +37,17 @@ def _fir_from_gaussian_psd(spread_hz: float, low_fs: float, ntaps: int = 100) ->
     return h * np.hamming(ntaps)
 
 
+def doppler_plan(spread_hz: float, fs: int, nsam: int):
+    """(FIR taps, Fs/lowFs ratio, low-rate sample count) doppler_spread() uses: the inputs of the device generator."""
+    low_fs = math.ceil(10 * spread_hz)
+    m = fs / low_fs
+    if m != math.floor(m):
+        m = math.floor(m)
+        low_fs = fs / m
+    m = int(m)
+    return _fir_from_gaussian_psd(spread_hz, low_fs, 100), m, max(math.ceil(nsam / m), 2)
+
+
 def doppler_spread(spread_hz: float, fs: int, nsam: int, rng: np.random.Generator) -> np.ndarray:
     """doppler_spread.m:7-50. Returns nsam complex128 samples at rate fs."""
     low_fs = math.ceil(10 * spread_hz)

@@ -140,8 +140,11 @@ typedef struct {
     const rd_tables *tab; const void *tx; long tx_stride; void *rx; long rx_stride;
     const void *G; const void *noise; const float *eoo; void *scratch; /* >= B*64*2 doubles */
     int B, n_sig, n_pre, n_post, with_eoo; float sigma, freq_offset, df_dt; unsigned long long seed;
+    float sine_amp, sine_freq, rx_gain;
 } rd_chan_args;
 int rd_launch_channel(const rd_chan_args *a, rd_stream_t s);
+/* Doppler-spread generator: taps_dev [n_taps] f32, noise optional, G [B][n_out][2] c64 */
+int rd_launch_multipath_gen(const float *taps_dev, int n_taps, int low_ratio, int n_out, const void *noise_low, unsigned long long seed, void *G, int B, rd_stream_t s);
 
 /* CoreDecoderStatefull.forward (radae_base.py:388-430) for the pending rows of one stream, run inside the receiver
  * kernel by the stream's own workgroup (rx_decode_pending -> ds_layers): buffers and weights of that stage. */

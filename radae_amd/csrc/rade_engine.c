@@ -374,10 +374,23 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
     a.tab = h->d_tab; a.tx = tx_dev; a.tx_stride = tx_stride; a.rx = rx_out_dev; a.rx_stride = rx_stride; a.G = p->G_dev; a.noise = p->noise_dev;
     a.eoo = h->eoo; a.scratch = h->chan_scratch; a.B = h->B; a.n_sig = p->n_sig; a.n_pre = p->n_pre; a.n_post = p->n_post; a.with_eoo = p->with_eoo;
     a.sigma = p->sigma; a.freq_offset = p->freq_offset; a.df_dt = p->df_dt; a.seed = p->seed;
+    a.sine_amp = p->sine_amp; a.sine_freq = p->sine_freq; a.rx_gain = p->rx_gain != 0.0f ? p->rx_gain : 1.0f;
     PROF_BEGIN(h, stream);
     if (rd_launch_channel(&a, stream)) return -1;
     PROF_END(h, stream, RADE_PROF_CHAN, 0.0);
     return p->n_pre + p->n_sig + (p->with_eoo ? RD_NEOO : 0) + p->n_post;
+}
+
+int rade_batch_multipath_gen(rade_batch *h, const float *fir_taps_host, int n_taps, int low_ratio, int n_out,
+                             const void *noise_low_dev, unsigned long long seed, void *G_out_dev, void *stream)
+{
+    if (!h || !fir_taps_host || n_taps <= 0 || n_taps > 1024 || !G_out_dev) return -1;
+    float *taps = dev_upload(fir_taps_host, sizeof(float) * n_taps);
+    if (!taps) return -1;
+    const int rc = rd_launch_multipath_gen(taps, n_taps, low_ratio, n_out, noise_low_dev, seed, G_out_dev, h->B, stream);
+    hipStreamSynchronize((hipStream_t)stream);          /* the tap buffer is released right away */
+    hipFree(taps);
+    return rc ? -1 : n_out;
 }
 
 /* ---- receive ----------------------------------------------------------------------------------- */

@@ -877,8 +877,67 @@ __global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double
             if (real_noise) v.x += a.sigma * g.x;                                  // inference.py:277-284: real-valued randn
             else { v.x += a.sigma * 0.70710678f * g.x; v.y += a.sigma * 0.70710678f * g.y; }   // complex randn: 1/2 per component
         }
-        rx[j] = v;
+        if (a.sine_amp != 0.0f) {                                                  // inference.py:285-288, phase taken mod 1 cycle in double
+            const double cyc = (double)j * (double)a.sine_freq / 8000.0;
+            float sn, cs; sincosf((float)(6.283185307179586 * (cyc - floor(cyc))), &sn, &cs);
+            v.x += a.sine_amp * cs; v.y += a.sine_amp * sn;
+        }
+        rx[j] = make_float2(v.x * a.rx_gain, v.y * a.rx_gain);
     }
+}
+
+// Watterson / Doppler-spread samples (doppler_spread.m:7-50, multipath_samples.m:25-31): one workgroup per stream.
+// Low-rate noise -> FIR (double) into LDS, then two sweeps over the Fs-rate interpolation: variance, scaled write.
+#define DG_MAXLOW 2048
+__global__ __launch_bounds__(256) void k_multipath_gen(const float *taps, int n_taps, int low_ratio, int n_out, const float2 *noise_low,
+                                                       unsigned long long seed, float2 *G)
+{
+    __shared__ double2 y[2][DG_MAXLOW];
+    __shared__ double red[256][6];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n_low = max((n_out + low_ratio - 1) / low_ratio, 2), n_x = n_low + n_taps;
+    for (int idx = tid; idx < 2 * n_low; idx += 256) {
+        const int p = idx / n_low, i = idx - p * n_low;
+        double ar = 0.0, ai = 0.0;
+        for (int k = 0; k < n_taps; k++) {                         // np.convolve(x, b)[ntaps:][i] = sum_k b[k] x[i + ntaps - k]
+            const int xi = i + n_taps - k;
+            float2 x;
+            if (noise_low) x = noise_low[((size_t)b * 2 + p) * n_x + xi];
+            else { uint32_t r[4]; philox4x32((uint32_t)xi, (uint32_t)(b * 2 + p), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r); x = gauss_pair(r[0], r[1]); }
+            ar += (double)taps[k] * x.x; ai += (double)taps[k] * x.y;
+        }
+        y[p][i] = make_double2(ar, ai);
+    }
+    __syncthreads();
+    auto interp = [&](int p, int n) {                               // linear interpolation, extrapolating past the last low-rate point
+        const double pos = (double)n / (double)low_ratio;
+        const int i0 = min((int)pos, n_low - 2);
+        const double fr = pos - (double)i0;
+        const double2 a0 = y[p][i0], a1 = y[p][i0 + 1];
+        return make_double2(a0.x + (a1.x - a0.x) * fr, a0.y + (a1.y - a0.y) * fr);
+    };
+    double s[6] = { 0, 0, 0, 0, 0, 0 };                             // per path: sum re, sum im, sum |g|^2
+    for (int n = tid; n < n_out; n += 256)
+        for (int p = 0; p < 2; p++) { const double2 g = interp(p, n); s[3 * p] += g.x; s[3 * p + 1] += g.y; s[3 * p + 2] += g.x * g.x + g.y * g.y; }
+    for (int k = 0; k < 6; k++) red[tid][k] = s[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) for (int k = 0; k < 6; k++) red[tid][k] += red[tid + off][k]; __syncthreads(); }
+    double var = 0.0;
+    for (int p = 0; p < 2; p++) { const double mr = red[0][3 * p] / n_out, mi = red[0][3 * p + 1] / n_out; var += red[0][3 * p + 2] / n_out - (mr * mr + mi * mi); }
+    const double hf_gain = 1.0 / sqrt(var);                         // np.var: population variance of the complex samples
+    float2 *Gb = G + (size_t)b * n_out * 2;
+    for (int n = tid; n < n_out; n += 256) {
+        const double2 g1 = interp(0, n), g2 = interp(1, n);
+        Gb[2 * n] = make_float2((float)(hf_gain * g1.x), (float)(hf_gain * g1.y));
+        Gb[2 * n + 1] = make_float2((float)(hf_gain * g2.x), (float)(hf_gain * g2.y));
+    }
+}
+extern "C" int rd_launch_multipath_gen(const float *taps_dev, int n_taps, int low_ratio, int n_out, const void *noise_low, unsigned long long seed, void *G, int B, rd_stream_t s)
+{
+    if (B <= 0 || n_out <= 0) return 0;
+    if (low_ratio < 1 || n_taps < 1 || (n_out + low_ratio - 1) / low_ratio > DG_MAXLOW) return -1;
+    hipLaunchKernelGGL(k_multipath_gen, dim3(B), dim3(256), 0, (hipStream_t)s, taps_dev, n_taps, low_ratio, n_out, (const float2 *)noise_low, seed, (float2 *)G);
+    return (int)hipGetLastError();
 }
 
 // Symbol-domain channels of the non-OFDM configurations.

@@ -26,7 +26,8 @@ class BatchConfig(C.Structure):
 
 class ChannelParams(C.Structure):
     _fields_ = [("n_sig", C.c_int), ("n_pre", C.c_int), ("n_post", C.c_int), ("with_eoo", C.c_int), ("sigma", C.c_float), ("freq_offset", C.c_float),
-                ("df_dt", C.c_float), ("G_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("seed", C.c_ulonglong)]
+                ("df_dt", C.c_float), ("G_dev", C.c_void_p), ("noise_dev", C.c_void_p), ("seed", C.c_ulonglong),
+                ("sine_amp", C.c_float), ("sine_freq", C.c_float), ("rx_gain", C.c_float)]
 
 
 class RxStatus(C.Structure):
@@ -61,6 +62,7 @@ def load_library() -> C.CDLL:
     L.rade_batch_tx_eoo.argtypes = [vp, vp, C.c_long, vp]
     L.rade_batch_tx_reset.argtypes = [vp]
     L.rade_batch_channel.argtypes = [vp, vp, C.c_long, vp, C.c_long, C.POINTER(ChannelParams), vp]
+    L.rade_batch_multipath_gen.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, vp, C.c_ulonglong, vp, vp]
     L.rade_sigma_from_EbNodB.restype = C.c_float; L.rade_sigma_from_EbNodB.argtypes = [C.c_float]
     L.rade_batch_rx.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_int), C.c_int, vp, C.c_long, vp, C.POINTER(RxStatus), vp]
     L.rade_batch_rx_reset.argtypes = [vp]
@@ -83,7 +85,7 @@ EXPORTED_SYMBOLS = [
     "rade_freq_offset", "rade_snrdB_3k_est",
     # include/rade_batch.h
     "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_set_eoo_bits",
-    "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
+    "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
 ]
@@ -225,14 +227,15 @@ class BatchEngine:
 
     # ---- channel ----------------------------------------------------------------------------
     def channel(self, tx, sigma: float, freq_offset: float = 0.0, n_pre: int = 0, n_post: int = 0, with_eoo: bool = False,
-                G=None, noise=None, seed: int = 0, df_dt: float = 0.0):
-        """tx complex64 [B, n_sig]; G complex64 [B, n_sig, 2] or None; noise complex64 [B, n_total] or None."""
+                G=None, noise=None, seed: int = 0, df_dt: float = 0.0, sine_amp: float = 0.0, sine_freq: float = 0.0, rx_gain: float = 1.0):
+        """tx complex64 [B, n_sig]; G complex64 [B, n_sig, 2] or None; noise complex64 [B, n_total] or None;
+        sine_amp/sine_freq: complex tone over the whole output, rx_gain: final scale (inference.py:285-289)."""
         import torch
         assert tx.is_cuda and tx.dtype == torch.complex64 and tx.is_contiguous() and tx.shape[0] == self.B
         n_sig = tx.shape[1]
         n_total = n_pre + n_sig + (NEOO if with_eoo else 0) + n_post
         rx = torch.empty((self.B, n_total), dtype=torch.complex64, device=tx.device)
-        p = ChannelParams(n_sig, n_pre, n_post, int(with_eoo), sigma, freq_offset, df_dt, None, None, seed)
+        p = ChannelParams(n_sig, n_pre, n_post, int(with_eoo), sigma, freq_offset, df_dt, None, None, seed, sine_amp, sine_freq, rx_gain)
         if G is not None:
             assert G.is_cuda and G.dtype == torch.complex64 and G.is_contiguous() and tuple(G.shape) == (self.B, n_sig, 2)
             p.G_dev = G.data_ptr()
@@ -243,6 +246,24 @@ class BatchEngine:
         if r != n_total:
             raise RuntimeError("rade_batch_channel failed")
         return rx
+
+    def multipath_gen(self, channel: str, n_out: int, seed: int = 1, noise_low=None, fs: int = 8000):
+        """Doppler-spread samples G [B, n_out, 2] complex64 generated on the device (multipath_samples.m presets
+        mpg / mpp / mpd).  noise_low: optional complex64 [B, 2, n_low + 100] unit-variance-per-component low-rate
+        input noise (parity with channel_tools.multipath_g); otherwise Philox from `seed`."""
+        import torch
+        from .channel_tools import PRESETS, doppler_plan
+        taps, ratio, n_low = doppler_plan(PRESETS[channel][0], fs, n_out)
+        G = torch.empty((self.B, n_out, 2), dtype=torch.complex64, device=self.device)
+        tp = np.ascontiguousarray(taps, dtype=np.float32)
+        nz = None
+        if noise_low is not None:
+            assert noise_low.is_cuda and noise_low.dtype == torch.complex64 and noise_low.is_contiguous() and tuple(noise_low.shape) == (self.B, 2, n_low + len(tp))
+            nz = noise_low.data_ptr()
+        r = self.lib.rade_batch_multipath_gen(self.h, tp.ctypes.data_as(C.POINTER(C.c_float)), len(tp), ratio, n_out, nz, seed, G.data_ptr(), _stream_ptr())
+        if r != n_out:
+            raise RuntimeError("rade_batch_multipath_gen failed")
+        return G
 
     # ---- receive ----------------------------------------------------------------------------
     def rx_reset(self, lcg_seeds: Optional[Sequence[int]] = None):

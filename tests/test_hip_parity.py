@@ -365,6 +365,51 @@ def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model):
     eng.close()
 
 
+def test_device_multipath_generator(Engine, torch_dev):
+    """the Watterson / Doppler-spread generator on the device.  With the host generator's own low-rate
+    noise as input it reproduces radae_amd.channel_tools.multipath_g (FIR, interpolation, hf_gain); from its Philox noise
+    the statistics are right: var G1 + var G2 = 1 per stream and the Gaussian-PSD autocorrelation exp(-2 pi^2 sigma^2 tau^2)."""
+    import torch
+    from radae_amd.channel_tools import multipath_g, doppler_plan, PRESETS
+    B, n = 6, 40 * 960
+    eng = Engine(B, max_tx_mf=1)
+    for ch in ("mpp", "mpd"):
+        taps, ratio, n_low = doppler_plan(PRESETS[ch][0], 8000, n)
+        noise = np.zeros((B, 2, n_low + len(taps)), np.complex64); ref = []
+        for b in range(B):
+            rng = np.random.default_rng(40 + b)
+            for p in range(2):                              # the draw order of doppler_spread(): real block, then imaginary block, per path
+                noise[b, p] = rng.standard_normal(n_low + len(taps)) + 1j * rng.standard_normal(n_low + len(taps))
+            ref.append(multipath_g(ch, 8000, n, 40 + b))
+        G = eng.multipath_gen(ch, n, noise_low=torch.tensor(noise, device=torch_dev)).cpu().numpy()
+        assert np.abs(G - np.stack(ref)).max() < 2e-5, ch     # complex64 input noise vs the host's float64 draw
+    Bs, n = 6, 84 * 960
+    G = eng.multipath_gen("mpp", n, seed=1234).cpu().numpy().astype(np.complex128)
+    for b in range(Bs):
+        assert abs(np.var(G[b, :, 0]) + np.var(G[b, :, 1]) - 1.0) < 1e-5
+    sigma = PRESETS["mpp"][0] / 2.0
+    for tau, tol in ((0.1, 0.08), (0.5, 0.25)):
+        lag = int(tau * 8000)
+        num = np.mean([np.real(np.vdot(G[b, :-lag, p], G[b, lag:, p])) / np.real(np.vdot(G[b, :, p], G[b, :, p])) for b in range(Bs) for p in range(2)])
+        assert abs(num - np.exp(-2 * np.pi ** 2 * sigma ** 2 * tau ** 2)) < tol, (tau, num)
+    assert np.abs(G[0] - G[1]).max() > 0.1                 # streams are independent
+    eng.close()
+
+
+def test_channel_sine_interferer_and_gain(Engine, torch_dev, golden):
+    """inference.py:285-289: --sine_amp/--sine_freq add a complex tone over the whole output, --rx_gain scales it."""
+    import torch
+    e = golden("enc_tx")
+    eng = Engine(2, max_tx_mf=10)
+    iq = eng.tx(torch.tensor(e["features"], device=torch_dev))
+    base = eng.channel(iq, 0.0, 0.0, n_pre=100, n_post=50).cpu().numpy()
+    out = eng.channel(iq, 0.0, 0.0, n_pre=100, n_post=50, sine_amp=0.3, sine_freq=1234.5, rx_gain=0.5).cpu().numpy()
+    nidx = np.arange(base.shape[1])
+    want = 0.5 * (base + 0.3 * np.exp(1j * nidx * 2 * np.pi * 1234.5 / 8000.0)[None])
+    assert np.abs(out - want).max() < 2e-6
+    eng.close()
+
+
 @pytest.mark.parametrize("kind", ["noise", "sine"])
 def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind):
     """The reference's acq_noise / acq_sine ctests (CMakeLists.txt:191-208): real-valued noise, or a 1 kHz sine in noise,

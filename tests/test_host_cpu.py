@@ -171,3 +171,15 @@ def test_blob_writer_reproduces_the_reference_format(tmp_path, lib):
     assert lib.rd_model_parse(blob, len(blob), C.byref(cm)) == 0
     w = np.ctypeslib.as_array(cm.dec_gru[1].w_ih, shape=(288 * 224,)).reshape(288, 224)
     assert np.array_equal(w, m2.dec_gru[1].w_ih)
+
+
+def test_wire_format_converters_match_reference_scripts(golden):
+    """radae_amd.wire restates int16tof32.py / f32toint16.py; tests/golden/wire.npz holds the reference scripts' outputs."""
+    from radae_amd import wire
+    g = golden("wire")
+    i16, f32 = g["i16"].tobytes(), g["f32"].tobytes()
+    assert wire.int16_to_f32(i16) == g["i2f"].tobytes()
+    assert wire.int16_to_f32(i16, zeropad=True) == g["i2f_zp"].tobytes()
+    assert wire.f32_to_int16(f32) == g["f2i"].tobytes()
+    assert wire.f32_to_int16(f32, real=True) == g["f2i_real"].tobytes()
+    assert wire.f32_to_int16(f32, scale=8192.0) == g["f2i_scale"].tobytes()
