@@ -264,13 +264,12 @@ def test_streams_are_independent_and_ragged(Engine, torch_dev, golden):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["mpp", "foff"])
-def test_many_identical_streams_agree(Engine, torch_dev, golden, name):
-    """Race / slot-dependence guard: 96 copies of one golden stream (more workgroups than fit one XCD) must come out
-    bit-identical in every slot, twice in a row, and equal to the golden trace."""
+@pytest.mark.parametrize("name,B", [("mpp", 96), ("foff", 96), ("mpp", 300)])
+def test_many_identical_streams_agree(Engine, torch_dev, golden, name, B):
+    """Race / slot-dependence guard: many copies of one golden stream (96: more workgroups than fit one XCD; 300: more than
+    the chip runs at once) must come out bit-identical in every slot, twice in a row, and equal to the golden trace."""
     import torch
     g = golden("rxtrace_" + name)
-    B = 96
     buf = torch.tensor(np.stack([g["rx_in"]] * B), device=torch_dev)
     eng = Engine(B, max_tx_mf=1, rx_trace_calls=64, flags=4 if name == "foff" else 0)
     for rep in range(2):
