@@ -60,6 +60,14 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 // thread index through an opaque asm: inside the receiver's per-call loop this keeps the compiler from hoisting every
 // thread-derived address computation of every phase out of the loop (hundreds of registers live across all phases)
 __device__ __forceinline__ int rx_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+// lane exchange inside a quad on the DPP path (v_mov_b32_dpp quad_perm): __shfl / __shfl_xor go through ds_bpermute, an
+// LDS-pipe round trip on the serial chain of the recurrences
+template <int CTRL> __device__ __forceinline__ float quad_dpp(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
+#define QUAD_XOR1 0xB1   /* [1,0,3,2] */
+#define QUAD_XOR2 0x4E   /* [2,3,0,1] */
+#define QUAD_BC0  0x00   /* [0,0,0,0] */
+#define QUAD_BC1  0x55
+#define QUAD_BC2  0xAA
 __device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
 // gate activations of the GRU recurrences on the hardware exp2 / rcp units (about 1 ulp each): the recurrence is a
 // serial chain, so the libm-grade expf / tanhf / IEEE division sequences would dominate every time step
@@ -396,42 +404,51 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
     float hj = a.h[(size_t)b * H + j];
     if (p == 0) hs[0][j] = hj;
     const float *gi = a.gi + (size_t)b * a.gi_sb + (p < 3 ? p * H + j : j);   // lane part p < 3 fetches gate p of unit j
-    float g0 = 0.0f, g1 = 0.0f;                      // gi of step t and t+1 (prefetched)
-    if (Tb > 0) g0 = gi[0];
-    if (Tb > 1) g1 = gi[a.gi_st];
+    // gi is fetched four steps at a time, one block ahead: a load issued inside the step that consumes an older one makes
+    // the compiler wait for all of them (vmcnt(0)), i.e. one L2 round trip per step on the serial chain
+    float gcur[4], gnxt[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { gcur[u] = u < Tb ? gi[(size_t)u * a.gi_st] : 0.0f; gnxt[u] = 4 + u < Tb ? gi[(size_t)(4 + u) * a.gi_st] : 0.0f; }
     __syncthreads();
     int cur = 0;
-    for (int t = 0; t < Tb; t++) {
-        if (a.reset && rst[t]) {                       // uniform over the workgroup
-            hj = 0.0f;
-            __syncthreads();
-            if (p == 0) hs[cur][j] = 0.0f;
-            __syncthreads();
-        }
-        float g2 = 0.0f;
-        if (t + 2 < Tb) g2 = gi[(size_t)(t + 2) * a.gi_st];
-        float sr = 0.0f, sz = 0.0f, sn = 0.0f;
-        const float *hp = hs[cur] + p * KP;
+    for (int t0 = 0; t0 < Tb; t0 += 4) {
 #pragma unroll
-        for (int k = 0; k < KP; k += 4) {
-            const f32x4 hv = *(const f32x4 *)(hp + k);
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u;
+            if (t >= Tb) break;
+            if (a.reset && rst[t]) {                       // uniform over the workgroup
+                hj = 0.0f;
+                __syncthreads();
+                if (p == 0) hs[cur][j] = 0.0f;
+                __syncthreads();
+            }
+            float sr = 0.0f, sz = 0.0f, sn = 0.0f;
+            const float *hp = hs[cur] + p * KP;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { sr += wr[k + u] * hv[u]; sz += wz[k + u] * hv[u]; sn += wn[k + u] * hv[u]; }
+            for (int k = 0; k < KP; k += 4) {
+                const f32x4 hv = *(const f32x4 *)(hp + k);
+#pragma unroll
+                for (int q = 0; q < 4; q++) { sr += wr[k + q] * hv[q]; sz += wz[k + q] * hv[q]; sn += wn[k + q] * hv[q]; }
+            }
+            sr += quad_dpp<QUAD_XOR1>(sr); sz += quad_dpp<QUAD_XOR1>(sz); sn += quad_dpp<QUAD_XOR1>(sn);
+            sr += quad_dpp<QUAD_XOR2>(sr); sz += quad_dpp<QUAD_XOR2>(sz); sn += quad_dpp<QUAD_XOR2>(sn);
+            const float g0 = gcur[u];
+            const float gr = quad_dpp<QUAD_BC0>(g0), gz = quad_dpp<QUAD_BC1>(g0), gn = quad_dpp<QUAD_BC2>(g0);
+            const float r = gate_sigmoid((sr + br) + gr);
+            const float z = gate_sigmoid((sz + bz) + gz);
+            const float n = gate_tanh(gn + (sn + bn) * r);
+            hj = (hj - n) * z + n;
+            if (p == 0) {
+                hs[cur ^ 1][j] = hj;
+                a.out[(size_t)b * a.out_sb + (size_t)t * a.out_st + j] = clamp1(hj);
+            }
+            cur ^= 1;
+            __syncthreads();
         }
-        sr += __shfl_xor(sr, 1); sz += __shfl_xor(sz, 1); sn += __shfl_xor(sn, 1);
-        sr += __shfl_xor(sr, 2); sz += __shfl_xor(sz, 2); sn += __shfl_xor(sn, 2);
-        const float gr = __shfl(g0, (tid & 60) + 0), gz = __shfl(g0, (tid & 60) + 1), gn = __shfl(g0, (tid & 60) + 2);
-        const float r = gate_sigmoid((sr + br) + gr);
-        const float z = gate_sigmoid((sz + bz) + gz);
-        const float n = gate_tanh(gn + (sn + bn) * r);
-        hj = (hj - n) * z + n;
-        if (p == 0) {
-            hs[cur ^ 1][j] = hj;
-            a.out[(size_t)b * a.out_sb + (size_t)t * a.out_st + j] = clamp1(hj);
-        }
-        g0 = g1; g1 = g2;
-        cur ^= 1;
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; u++) gcur[u] = gnxt[u];         // loaded a whole block ago: no stall
+#pragma unroll
+        for (int u = 0; u < 4; u++) gnxt[u] = t0 + 8 + u < Tb ? gi[(size_t)(t0 + 8 + u) * a.gi_st] : 0.0f;
     }
     if (p == 0) a.h[(size_t)b * H + j] = hj;
 }
@@ -591,9 +608,9 @@ __device__ void ds_scan(DecShared *sh, int tid, const float *gi_, int gi_st, con
 #pragma unroll
             for (int u = 0; u < 4; u++) { sr += wr[k + u] * hv[u]; sz += wz[k + u] * hv[u]; sn += wn[k + u] * hv[u]; }
         }
-        sr += __shfl_xor(sr, 1); sz += __shfl_xor(sz, 1); sn += __shfl_xor(sn, 1);
-        sr += __shfl_xor(sr, 2); sz += __shfl_xor(sz, 2); sn += __shfl_xor(sn, 2);
-        const float gr = __shfl(g0, (tid & 60) + 0), gz = __shfl(g0, (tid & 60) + 1), gn = __shfl(g0, (tid & 60) + 2);
+        sr += quad_dpp<QUAD_XOR1>(sr); sz += quad_dpp<QUAD_XOR1>(sz); sn += quad_dpp<QUAD_XOR1>(sn);
+        sr += quad_dpp<QUAD_XOR2>(sr); sz += quad_dpp<QUAD_XOR2>(sz); sn += quad_dpp<QUAD_XOR2>(sn);
+        const float gr = quad_dpp<QUAD_BC0>(g0), gz = quad_dpp<QUAD_BC1>(g0), gn = quad_dpp<QUAD_BC2>(g0);
         const float r = gate_sigmoid((sr + br) + gr);
         const float z = gate_sigmoid((sz + bz) + gz);
         const float n = gate_tanh(gn + (sn + bn) * r);
