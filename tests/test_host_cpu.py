@@ -19,6 +19,33 @@ def lib():
     return engine.load_library()
 
 
+def test_built_kernels_do_not_spill_ahead_of_exec_restore(lib):
+    """Code-generation guard for the shipped library (tools/check_spill_exec.py): a VGPR spill placed in a control-flow
+    join block before `s_or_b64 exec, exec, ...` is lost when the wavefront skipped the branch; the checker itself is
+    exercised on a hand-made disassembly of the bad and the good placement."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_spill_exec as chk
+    from radae_amd import engine
+    assert chk.scan(chk.disassemble(engine.LIB_PATH)) == []
+    bad = """
+0000000000001000 <k>:
+\ts_and_saveexec_b64 s[2:3], s[14:15]  // 000000001000: BE82200E
+\ts_cbranch_execz 3  // 000000001004: BF880003 <k+0x14>
+\tds_write_b32 v4, v3  // 000000001008: D81A0000 00000304
+\ts_nop 0  // 000000001010: BF800000
+\ts_movk_i32 s34, 0x1bf  // 000000001014: B02201BF
+\tscratch_store_dwordx2 off, v[190:191], off offset:212  // 000000001018: DC7440D4 007FBE00
+\ts_or_b64 exec, exec, s[2:3]  // 000000001020: 87FE027E
+\ts_endpgm  // 000000001024: BF810000
+"""
+    hits = chk.scan(bad)
+    assert len(hits) == 1 and hits[0][0] == "k" and hits[0][1] == 0x1020
+    good = bad.replace("\tscratch_store_dwordx2 off, v[190:191], off offset:212  // 000000001018: DC7440D4 007FBE00\n\ts_or_b64 exec, exec, s[2:3]  // 000000001020: 87FE027E",
+                       "\ts_or_b64 exec, exec, s[2:3]  // 000000001018: 87FE027E\n\tscratch_store_dwordx2 off, v[190:191], off offset:212  // 00000000101C: DC7440D4 007FBE00")
+    assert good != bad and chk.scan(good) == []
+
+
 def test_library_exports_every_declared_symbol(lib):
     declared = set()
     for hdr in ("rade_api.h", "rade_batch.h"):
