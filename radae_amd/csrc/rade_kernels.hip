@@ -68,6 +68,36 @@ template <int CTRL> __device__ __forceinline__ float quad_dpp(float x) { return 
 #define QUAD_BC0  0x00   /* [0,0,0,0] */
 #define QUAD_BC1  0x55
 #define QUAD_BC2  0xAA
+#define ROW_ROR4  0x124  /* rotate right by 4 inside each row of 16 lanes */
+#define ROW_ROR8  0x128
+template <int CTRL> __device__ __forceinline__ int quad_dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)quad_dpp_i<CTRL>((int)(unsigned)b), hi = (unsigned)quad_dpp_i<CTRL>((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the wavefront, the same value in every lane: quad and row steps on DPP, the four row totals through readlane
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_f64<QUAD_XOR1>(v); v += dpp_f64<QUAD_XOR2>(v); v += dpp_f64<ROW_ROR4>(v); v += dpp_f64<ROW_ROR8>(v);
+    const long long b = __double_as_longlong(v);
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 16 * r), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 16 * r);
+        t += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return t;
+}
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += quad_dpp<QUAD_XOR1>(v); v += quad_dpp<QUAD_XOR2>(v); v += quad_dpp<ROW_ROR4>(v); v += quad_dpp<ROW_ROR8>(v);
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * r));
+    return t;
+}
 __device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
 // gate activations of the GRU recurrences on the hardware exp2 / rcp units (about 1 ulp each): the recurrence is a
 // serial chain, so the libm-grade expf / tanhf / IEEE division sequences would dominate every time step
@@ -1247,10 +1277,19 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
 __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
 {
     const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
+    // max under a total order: any combination order gives the same winner; quad / row steps on DPP, rows through readlane
+#define ARGMAX_STEP(CTRL) do { const float ov = quad_dpp<CTRL>(v); const int o0 = quad_dpp_i<CTRL>(k0), o1 = quad_dpp_i<CTRL>(k1); \
+        if (ov > v || (ov == v && (o0 < k0 || (o0 == k0 && o1 < k1)))) { v = ov; k0 = o0; k1 = o1; } } while (0)
+    ARGMAX_STEP(QUAD_XOR1); ARGMAX_STEP(QUAD_XOR2); ARGMAX_STEP(ROW_ROR4); ARGMAX_STEP(ROW_ROR8);
+#undef ARGMAX_STEP
+    {
+        float bv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); int b0 = __builtin_amdgcn_readlane(k0, 0), b1 = __builtin_amdgcn_readlane(k1, 0);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(v, off); const int o0 = __shfl_xor(k0, off), o1 = __shfl_xor(k1, off);
-        if (ov > v || (ov == v && (o0 < k0 || (o0 == k0 && o1 < k1)))) { v = ov; k0 = o0; k1 = o1; }
+        for (int r = 1; r < 4; r++) {
+            const float ov = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * r)); const int o0 = __builtin_amdgcn_readlane(k0, 16 * r), o1 = __builtin_amdgcn_readlane(k1, 16 * r);
+            if (ov > bv || (ov == bv && (o0 < b0 || (o0 == b0 && o1 < b1)))) { bv = ov; b0 = o0; b1 = o1; }
+        }
+        v = bv; k0 = b0; k1 = b1;
     }
     __syncthreads();                                   // previous readers of slot 0 are done
     if (lane == 0) { sh->redf[1 + wave] = v; sh->redi[1 + wave] = k0; sh->redj[1 + wave] = k1; }
@@ -1272,9 +1311,7 @@ __device__ void block_sum_multi(RxShared *sh, double (&v)[NV])
 {
     const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; k++)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    for (int k = 0; k < NV; k++) v[k] = wave_sum_f64(v[k]);
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
@@ -1632,7 +1669,13 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const int oldb = cached ? S->dt_valid - 1 : 0, newb = 1 - oldb;
             float *cache = a.dtcache + (size_t)b * 2 * RD_NFC * RD_NMF;      // [2][f][t] |Dt| surfaces
             if (tid == 0) { S->lds_sync = 0; S->dt_new = newb; }
-            if (cached) for (int t = tid; t < RD_NMF; t += NT_RX) sh->rowsum1[t] = sh->rowsum2[t];
+            {   // rowsum1 <- rowsum2 when the previous |Dt2| surface is reused as |Dt1|; branch-free (two slots per thread, the
+                // clamped duplicates write equal values) so that no divergent join sits in front of the correlator
+                const int t2 = min(tid + NT_RX, RD_NMF - 1);
+                const float r1a = sh->rowsum1[tid], r1b = sh->rowsum1[t2], r2a = sh->rowsum2[tid], r2b = sh->rowsum2[t2];
+                __syncthreads();
+                sh->rowsum1[tid] = cached ? r2a : r1a; sh->rowsum1[t2] = cached ? r2b : r1b;
+            }
             __syncthreads();
             PH(16);
             rx_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb, best, bt, bfi);
@@ -1795,7 +1838,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 #pragma unroll
                     for (int u = 0; u < 4; u++) acc[u] = cadd(acc[u], cmul(x[n + u], sh->wfwd[80 * hf + n + u][c]));
                 float2 t = cadd(cadd(acc[0], acc[1]), cadd(acc[2], acc[3]));
-                t.x += __shfl_xor(t.x, 1); t.y += __shfl_xor(t.y, 1);
+                t.x += quad_dpp<QUAD_XOR1>(t.x); t.y += quad_dpp<QUAD_XOR1>(t.y);
                 if (hf == 0) sh->sym[s][c] = t;
             }
             __syncthreads();
@@ -1829,8 +1872,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                         const float ap = hypotf(pc.x, pc.y); s1 = ap * ap; s2 = fabsf(rc.y) * fabsf(rc.y);
                         const float a0 = hypotf(r0.x, r0.y), a1 = hypotf(r1.x, r1.y); pm = a0 * a0 + a1 * a1;
                     }
-#pragma unroll
-                    for (int off = 16; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); pm += __shfl_xor(pm, off); }
+                    s1 = wave_sum_f32(s1); s2 = wave_sum_f32(s2); pm = wave_sum_f32(pm);      // lanes >= Nc hold zeros
                     if (tid == 0) {
                         const float S1 = s1, S2 = s2 + 1e-12f;
                         float snr = S1 / (2.0f * S2) - 1.0f;
