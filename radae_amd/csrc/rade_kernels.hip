@@ -285,8 +285,8 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
                 const int bb = rr / a.T, tt = rr - bb * a.T;
                 if (a.n_rows && tt >= a.n_rows[bb]) continue;
                 float v = acc[q][i][j] * 0x1p-18f + bias;
-                if (a.act == 1) v = clamp1(tanhf(v));
-                else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * sigmoid_f(v));
+                if (a.act == 1) v = clamp1(gate_tanh(v));                 // hardware exp2 / rcp, as in the recurrences
+                else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * gate_sigmoid(v));
                 a.y[bb * a.y_sb + tt * a.y_st + col] = v;
             }
         }
@@ -585,8 +585,8 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
                     const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
                     if (tt >= Tb) continue;
                     v = v * 0x1p-18f + bias;
-                    if (act == 1) v = clamp1(tanhf(v));
-                    else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * sigmoid_f(v));
+                    if (act == 1) v = clamp1(gate_tanh(v));               // libm tanhf / expf here cost a third of the decoder GEMM time
+                    else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * gate_sigmoid(v));
                     y[(size_t)tt * y_st + col] = v;
                 }
             }
