@@ -143,6 +143,45 @@ void rade_batch_profile(rade_batch *h, int enable);
 /* accumulated since enable: device milliseconds, algorithmic FLOPs, launches */
 int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches);
 
+/* ---- single-carrier modem for BBFM symbols ------------------------------------------------
+ * Batched form of the reference's `single_carrier` class (radae/dsp.py:579-860; drivers sc_tx.py:58-75,
+ * sc_rx.py:83-112): BPSK at Rs symbols/s, Fs = 4 Rs, 16-symbol frame-sync word + 80 payload symbols per frame,
+ * 24-tap root-Nyquist filters (gen_rn_coeffs, dsp.py:532-562), fine timing from the symbol-rate line of the
+ * envelope, squared-symbol phase tracker, frame-sync state machine.  One independent modem per stream; all state
+ * lives on the device between calls. */
+typedef struct rade_sc rade_sc;
+typedef struct {          /* end-of-call state of one stream */
+    int n_frames;         /* frames demodulated by this call */
+    int consumed;         /* samples consumed */
+    int state;            /* 0 search, 1 sync */
+    int nin;              /* samples the next frame needs: 96 M - 1, 96 M or 96 M + 1 (dsp.py:697-702) */
+    int fs_s;             /* frame-sync position inside the two-frame symbol buffer */
+    float g;              /* amplitude normalisation from the sync word (dsp.py:805-806) */
+    float max_cs_re, max_cs_im, norm_rx_timing, phase_ambiguity;
+} rade_sc_status;
+typedef struct {          /* per-frame record, what sc_rx.py prints at -v 2 */
+    int state, nin, fs_s, pad;
+    float norm_rx_timing, g, max_cs_re, max_cs_im, phase_ambiguity, pad2[3];
+} rade_sc_frame;
+/* Rs, Fs, fcentreHz, alpha as single_carrier.__init__ (dsp.py:581); Fs must equal 4 Rs.  NULL without a GPU. */
+rade_sc *rade_sc_open(int n_streams, double Rs, double Fs, double fcentreHz, double alpha, int device);
+void rade_sc_close(rade_sc *h);
+void rade_sc_reset(rade_sc *h);
+int rade_sc_n_streams(const rade_sc *h);
+int rade_sc_n_tx_out(const rade_sc *h);       /* 384 samples per frame */
+int rade_sc_nin_max(const rade_sc *h);        /* 385 */
+int rade_sc_n_payload(const rade_sc *h);      /* 80 */
+void rade_sc_rrc(const rade_sc *h, double *taps_out /* [24] */);
+/* single_carrier.tx (dsp.py:636-662) for n_frames frames per stream: symbs_dev [B][n_frames][80] float ->
+ * iq_out_dev [B][iq_stride] complex64, n_frames * 384 samples each.  Returns samples per stream or -1. */
+int rade_sc_tx(rade_sc *h, const float *symbs_dev, int n_frames, void *iq_out_dev, long iq_stride, void *stream);
+/* single_carrier.rx (dsp.py:773-829) over every whole frame in the first n_avail samples of each stream (at most
+ * max_frames): payload_out_dev [B][max_frames][80] complex64 = the returned symbols, zhat_out_dev [B][max_frames][80]
+ * = g * Re(payload) where the modem is in sync after the frame, else 0 (sc_rx.py:99-101); frames_out_dev
+ * [B][max_frames]; any of the three may be NULL.  status_host[B] is filled after a stream synchronisation. */
+int rade_sc_rx(rade_sc *h, const void *rx_dev, long rx_stride, int n_avail, int max_frames, void *payload_out_dev, float *zhat_out_dev,
+               rade_sc_frame *frames_out_dev, rade_sc_status *status_host, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
