@@ -514,7 +514,7 @@ struct DecShared {
 // fly (VALU, overlapped with the matrix pipe); the weights come pre-split from rd_pack_weights_f16x2.
 template <int NT>
 __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, int K1, const float *a0, int a0_st, int K0, const int *rst,
-                          const rd_lin w, float *y, int y_st, int act, int Tb)
+                          const rd_lin w, float *y, int y_st, int act, int Tb, int nt_begin = 0, int nt_end = 1 << 20)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int ntt = (w.N + 31) >> 5;
@@ -525,7 +525,7 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
         const float *p1 = a1 + (size_t)t * a1_st + 8 * half;
         const float *p0 = nullptr;
         if (K0) p0 = ((rst && rst[t]) ? g_zero_row : a0 + (size_t)t * a0_st) + 8 * half;
-        for (int nt0 = 0; nt0 < ntt; nt0 += NT) {
+        for (int nt0 = nt_begin; nt0 < min(ntt, nt_end); nt0 += NT) {
             f32x16 acc[NT];
 #pragma unroll
             for (int i = 0; i < NT; i++)
@@ -591,6 +591,63 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
                 }
             }
             __syncthreads();
+        }
+    }
+}
+
+// Wide outputs (the GRU input projection, N = 288 = 9 column tiles): wave w owns column tile w with the whole K, so nothing is
+// reduced through LDS and no barrier falls inside the product; with a single 32x32 accumulator the wave can keep D k-blocks
+// of operands in flight, which is what the L2-latency-bound loop needs.  Tiles beyond the eighth go through ds_gemm16.
+template <int D>
+__device__ void ds_gemm16_cols(const float *a1, int a1_st, int K1, const rd_lin w, float *y, int y_st, int Tb)
+{
+    const int lane = threadIdx.x & 63, nt = threadIdx.x >> 6, half = lane >> 5;
+    const int ntt = (w.N + 31) >> 5, nkb = K1 >> 4;
+    if (nt >= ntt) return;
+    const size_t wstep = (size_t)ntt * 2 * 64 * 8;
+    const unsigned short *wbase = w.wp16 + ((size_t)nt * 2 * 64 + lane) * 8;
+    const int col = nt * 32 + (lane & 31);
+    const float bias = (w.bias && col < w.N) ? w.bias[col] : 0.0f;
+    for (int r0 = 0; r0 < Tb; r0 += 32) {
+        const int t = min(r0 + (lane & 31), Tb - 1);
+        const float *p1 = a1 + (size_t)t * a1_st + 8 * half;
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] = 0.0f;
+        f32x4 av[D][2]; f16x8 bh[D], bl[D];
+        auto fetch = [&](int d, int kb) {
+            if (kb < nkb) {
+                av[d][0] = *(const f32x4 *)(p1 + kb * 16); av[d][1] = *(const f32x4 *)(p1 + kb * 16 + 4);
+                bh[d] = *(const f16x8 *)(wbase + kb * wstep); bl[d] = *(const f16x8 *)(wbase + kb * wstep + 64 * 8);
+            } else { bh[d] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; bl[d] = bh[d]; av[d][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; av[d][1] = av[d][0]; }
+        };
+#pragma unroll
+        for (int d = 0; d < D; d++) fetch(d, d);
+#pragma unroll 1
+        for (int kb = 0; kb < nkb; kb += D) {          // k-blocks past the end contribute zeros
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                f16x8 ah, al;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float x = 256.0f * av[d][j >> 2][j & 3];
+                    const _Float16 hi = (_Float16)x;
+                    ah[j] = hi; al[j] = (_Float16)(x - (float)hi);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[d], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[d], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[d], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(d, kb + d + D);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (col < w.N) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                if (tt < Tb) y[(size_t)tt * y_st + col] = acc[j] * 0x1p-18f + bias;
+            }
         }
     }
 }
@@ -667,7 +724,8 @@ __device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb, i
 #pragma unroll 1
     for (int l = 0; l < 5; l++) {
         const int in = 96 + 128 * l, cin = in + 96;      // radae_base.py:378-386
-        ds_gemm16<DS_NT>(sh, tid, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb);
+        ds_gemm16_cols<4>(x, W, in, a.gin[l], gi, 288, Tb);                                   // column tiles 0..7, one per wave
+        ds_gemm16<1>(sh, tid, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb, 8, 9);   // tile 8: K over the 8 waves
         PH(21);
         ds_scan(sh, tid, gi, 288, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, hb, 96, true, Tb);
         PH(23);
