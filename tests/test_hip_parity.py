@@ -658,3 +658,33 @@ def test_sc_loopback_batch_vs_oracle_and_chunking(torch_dev):
     assert len(outs) == st[0].n_frames
     assert np.array_equal(np.stack(outs), pay.cpu().numpy()[0, :len(outs)])
     m.close(); m1.close()
+
+
+@pytest.mark.gpu
+def test_sc_edge_cases(torch_dev, golden):
+    """Short input (no whole frame), max_frames cap, reset, and argument checking of the single-carrier entry points."""
+    import torch
+    from radae_amd.sc import SingleCarrierBatch
+    g = golden("sc_rx_clean")
+    x = torch.tensor(g["rx_in"][None], device=torch_dev)
+    m = SingleCarrierBatch(1, fcentreHz=float(g["fcentre"]))
+    pay, zh, fr, st = m.rx(x[:, :383].contiguous(), max_frames=4)          # fewer than nin samples: nothing consumed
+    assert st[0].n_frames == 0 and st[0].consumed == 0 and st[0].nin == 384 and st[0].state == 0
+    pay, zh, fr, st = m.rx(x, max_frames=3)                                   # capped: the caller resumes at `consumed`
+    assert st[0].n_frames == 3 and st[0].consumed == int(np.sum(np.concatenate([[384], g["nin"][:2]])))
+    pay2, zh2, fr2, st2 = m.rx(x[:, st[0].consumed:].contiguous())
+    nf = len(g["state"])
+    assert st2[0].n_frames == nf - 3
+    assert np.array_equal(np.concatenate([fr[0, :3]["state"], fr2[0, :nf - 3]["state"]]), g["state"])
+    p = np.concatenate([pay.cpu().numpy()[0, :3], pay2.cpu().numpy()[0, :nf - 3]])
+    assert np.abs(p - g["payload"]).max() < 1e-5
+    m.reset()                                                                  # back to the constructor state: same answer again
+    pay3, _, fr3, st3 = m.rx(x)
+    assert st3[0].n_frames == nf and np.abs(pay3.cpu().numpy()[0, :nf] - g["payload"]).max() < 1e-5
+    # argument errors are reported, not crashed on
+    L = m.L
+    assert L.rade_sc_tx(m.h, None, 1, None, 384, None) == -1
+    assert L.rade_sc_rx(m.h, None, 0, 0, 1, None, None, None, None, None) == -1
+    assert not L.rade_sc_open(0, 2400.0, 9600.0, 0.0, 0.25, 0)
+    assert not L.rade_sc_open(1, 2400.0, 8000.0, 0.0, 0.25, 0)              # Fs must be 4 Rs
+    m.close()
