@@ -25,6 +25,7 @@
 
 typedef struct { float *wp, *bias; unsigned short *wp16; int N, K; } dev_lin;
 
+#define RADE_PROF_MAXEV 256   /* launches recorded per profiled interval before the events are drained */
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
@@ -47,7 +48,7 @@ struct rade_batch {
     unsigned *lcg_seeds;             /* host copy for resets */
     unsigned *d_lcg_seeds;
     /* optional per-kernel-class timing with HIP events (bench.py roofline leg; never on in timed runs) */
-    int prof_on; hipEvent_t prof_ev[2];
+    int prof_on, prof_cnt; hipEvent_t prof_ev[2 * RADE_PROF_MAXEV]; int prof_cls[RADE_PROF_MAXEV]; double prof_fl[RADE_PROF_MAXEV];
     double prof_ms[RADE_PROF_NCLASS], prof_flops[RADE_PROF_NCLASS]; long prof_n[RADE_PROF_NCLASS];
     long rx_calls_search, rx_calls_sync;
 };
@@ -225,7 +226,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     for (size_t b = 0; b < B; b++) h->lcg_seeds[b] = 1u;
     h->d_lcg_seeds = dev_upload(h->lcg_seeds, sizeof(unsigned) * B);
     if (!h->d_lcg_seeds) goto fail;
-    CHK(hipEventCreate(&h->prof_ev[0])); CHK(hipEventCreate(&h->prof_ev[1]));
+    for (int i = 0; i < 2 * RADE_PROF_MAXEV; i++) CHK(hipEventCreate(&h->prof_ev[i]));
     rade_batch_rx_reset(h);
     if (rd_launch_eoo_build(h->d_tab, NULL, h->eoo, h->B, NULL)) goto fail;
     CHK(hipDeviceSynchronize());
@@ -264,8 +265,7 @@ void rade_batch_close(rade_batch *h)
         for (int i = 0; i < 7; i++) if (p[i]) hipFree(p[i]);
     }
     if (h->h_small) hipHostFree(h->h_small);
-    if (h->prof_ev[0]) hipEventDestroy(h->prof_ev[0]);
-    if (h->prof_ev[1]) hipEventDestroy(h->prof_ev[1]);
+    for (int i = 0; i < 2 * RADE_PROF_MAXEV; i++) if (h->prof_ev[i]) hipEventDestroy(h->prof_ev[i]);
     free(h->lcg_seeds);
     free(h);
 }
@@ -273,18 +273,32 @@ void rade_batch_close(rade_batch *h)
 int rade_batch_n_streams(const rade_batch *h) { return h->B; }
 
 /* ---- per-kernel-class timing (HIP events on the launch stream) -------------------------------- */
-#define PROF_BEGIN(h, st) do { if ((h)->prof_on) hipEventRecord((h)->prof_ev[0], (hipStream_t)(st)); } while (0)
-#define PROF_END(h, st, cls, fl) do { if ((h)->prof_on) { float ms_ = 0; hipEventRecord((h)->prof_ev[1], (hipStream_t)(st)); hipEventSynchronize((h)->prof_ev[1]); \
-    hipEventElapsedTime(&ms_, (h)->prof_ev[0], (h)->prof_ev[1]); (h)->prof_ms[cls] += ms_; (h)->prof_flops[cls] += (fl); (h)->prof_n[cls]++; } } while (0)
+/* Events are only recorded while the work is queued and read back afterwards (prof_drain): a profiled step runs back to
+ * back like a timed one, without a host synchronisation (and the clock ramp-down that follows it) after every kernel. */
+static void prof_drain(rade_batch *h)
+{
+    for (int i = 0; i < h->prof_cnt; i++) {
+        float ms = 0;
+        if (hipEventSynchronize(h->prof_ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) == hipSuccess) {
+            h->prof_ms[h->prof_cls[i]] += ms; h->prof_flops[h->prof_cls[i]] += h->prof_fl[i]; h->prof_n[h->prof_cls[i]]++;
+        }
+    }
+    h->prof_cnt = 0;
+}
+#define PROF_BEGIN(h, st) do { if ((h)->prof_on) { if ((h)->prof_cnt >= RADE_PROF_MAXEV) prof_drain(h); hipEventRecord((h)->prof_ev[2 * (h)->prof_cnt], (hipStream_t)(st)); } } while (0)
+#define PROF_END(h, st, cls, fl) do { if ((h)->prof_on) { hipEventRecord((h)->prof_ev[2 * (h)->prof_cnt + 1], (hipStream_t)(st)); \
+    (h)->prof_cls[(h)->prof_cnt] = (cls); (h)->prof_fl[(h)->prof_cnt] = (fl); (h)->prof_cnt++; } } while (0)
 
 void rade_batch_profile(rade_batch *h, int enable)
 {
+    if (!enable && h->prof_on) prof_drain(h);
     h->prof_on = enable;
-    if (enable) { memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_flops, 0, sizeof h->prof_flops); memset(h->prof_n, 0, sizeof h->prof_n); }
+    if (enable) { h->prof_cnt = 0; memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_flops, 0, sizeof h->prof_flops); memset(h->prof_n, 0, sizeof h->prof_n); }
 }
 int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches)
 {
     if (cls < 0 || cls >= RADE_PROF_NCLASS) return -1;
+    prof_drain(h);
     *ms = h->prof_ms[cls]; *work = h->prof_flops[cls]; *launches = h->prof_n[cls];
     return 0;
 }
