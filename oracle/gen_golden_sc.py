@@ -66,7 +66,19 @@ def rx_case(name, fcentre, nframes, seed, EbNodB, phase_off, freq_off, mag, ppm,
     print(name, "frames", len(st), "synced", int(st.sum()), "nin values", sorted(set(log["nin"])), "fs_s", sorted(set(log["fs_s"])))
 
 
+def wire_case():
+    """The reference's own filters end to end: 12 frames of latents | sc_tx.py | sc_rx.py (int16 real samples at 1500 Hz)."""
+    import subprocess
+    rng = np.random.default_rng(11)
+    z = np.clip(rng.standard_normal((12, 80)), -1, 1).astype(np.float32)
+    env = dict(os.environ, PYTHONPATH="/root/reference", MPLBACKEND="Agg")
+    t = subprocess.run([sys.executable, "/root/reference/sc_tx.py"], input=z.tobytes(), capture_output=True, env=env, check=True).stdout
+    zh = subprocess.run([sys.executable, "/root/reference/sc_rx.py", "-v", "0"], input=t, capture_output=True, env=env, check=True).stdout
+    np.savez_compressed(os.path.join(OUT, "sc_wire.npz"), z=z, t_int16=np.frombuffer(t, np.int16), zhat=np.frombuffer(zh, np.float32).reshape(-1, 80))
+
+
 if __name__ == "__main__":
+    wire_case()
     tx_case("bpsk_1500", 1500.0, 6, 1, False)
     tx_case("analog_0", 0.0, 5, 2, True)
     rx_case("clean", 1500.0, 12, 3, 100.0, 0.0, 0.0, 1.0, 0, 37)

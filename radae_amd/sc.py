@@ -87,3 +87,46 @@ class SingleCarrierBatch:
             raise RuntimeError("rade_sc_rx failed")
         frames = fr.cpu().numpy().view(_FRAME_DT).reshape(self.B, F)
         return pay, zh, frames, list(st)
+
+
+# ---- the reference's stdin/stdout filters (sc_tx.py:58-75, sc_rx.py:83-112) over whole streams ----------------------
+def sc_tx_stream(z: np.ndarray, fcentreHz=1500.0, scale=16384.0, real=True) -> np.ndarray:
+    """[frames, 80] float32 latents -> int16 samples (real part, or I/Q interleaved with real=False)."""
+    z = np.ascontiguousarray(z, np.float32).reshape(1, -1, 80)
+    m = SingleCarrierBatch(1, fcentreHz=fcentreHz)
+    tx = (scale * m.tx(torch.tensor(z, device=m.dev))).cpu().numpy()[0]
+    m.close()
+    if real:
+        return tx.real.astype(np.int16)
+    return np.stack([tx.real, tx.imag], axis=1).astype(np.int16).reshape(-1)
+
+
+def sc_rx_stream(samples: np.ndarray, fcentreHz=1500.0, real=True) -> np.ndarray:
+    """int16 samples -> [synced frames, 80] float32 z_hat = g Re(payload), one row per frame that ends in sync."""
+    x = np.asarray(samples, np.int16)
+    rx = x.astype(np.float32).astype(np.complex64) if real else (x[0::2].astype(np.float32) + 1j * x[1::2].astype(np.float32)).astype(np.complex64)
+    m = SingleCarrierBatch(1, fcentreHz=fcentreHz)
+    _, zh, fr, st = m.rx(torch.tensor(rx[None], device=m.dev))
+    m.close()
+    k = st[0].n_frames
+    return zh.cpu().numpy()[0, :k][fr[0, :k]["state"] == 1]
+
+
+def main(argv=None):
+    import argparse, sys
+    ap = argparse.ArgumentParser(description="single-carrier modem filters on the GPU (the reference's sc_tx.py / sc_rx.py)")
+    ap.add_argument("mode", choices=["tx", "rx"])
+    ap.add_argument("--fcentreHz", type=float, default=1500.0)
+    ap.add_argument("--scale", type=float, default=16384.0)
+    ap.add_argument("--complex", dest="real", action="store_false")
+    a = ap.parse_args(argv)
+    data = sys.stdin.buffer.read()
+    if a.mode == "tx":
+        n = len(data) // 320
+        sys.stdout.buffer.write(sc_tx_stream(np.frombuffer(data[:n * 320], np.float32).reshape(n, 80), a.fcentreHz, a.scale, a.real).tobytes())
+    else:
+        sys.stdout.buffer.write(sc_rx_stream(np.frombuffer(data[:len(data) // 2 * 2], np.int16), a.fcentreHz, a.real).astype(np.float32).tobytes())
+
+
+if __name__ == "__main__":
+    main()

@@ -688,3 +688,19 @@ def test_sc_edge_cases(torch_dev, golden):
     assert not L.rade_sc_open(0, 2400.0, 9600.0, 0.0, 0.25, 0)
     assert not L.rade_sc_open(1, 2400.0, 8000.0, 0.0, 0.25, 0)              # Fs must be 4 Rs
     m.close()
+
+
+@pytest.mark.gpu
+def test_sc_wire_filters_match_reference_scripts(golden):
+    """latents | sc_tx | sc_rx with the reference's own scripts (tests/golden/sc_wire.npz) vs the GPU filters: int16 samples equal up
+    to the truncation of values within float rounding of an integer, z_hat equal to the quantisation noise that leaves."""
+    from radae_amd.sc import sc_tx_stream, sc_rx_stream
+    g = golden("sc_wire")
+    t = sc_tx_stream(g["z"])
+    assert t.dtype == np.int16 and t.shape == g["t_int16"].shape
+    d = np.abs(t.astype(int) - g["t_int16"].astype(int))
+    assert d.max() <= 1 and (d == 0).mean() > 0.97
+    zh = sc_rx_stream(g["t_int16"])                       # the reference's samples in: isolates the receiver
+    assert zh.shape == g["zhat"].shape and np.abs(zh - g["zhat"]).max() < 2e-5 * max(1.0, np.abs(g["zhat"]).max())
+    zh2 = sc_rx_stream(t)                                  # our own samples: +-1 LSB differences only
+    assert zh2.shape == g["zhat"].shape and np.abs(zh2 - g["zhat"]).max() < 2e-3
