@@ -9,7 +9,7 @@ every lane.  In k_rx_sync this silently corrupted a long-lived f64 polynomial co
 estimates off by 0.01 Hz) in builds that differed from the good one only by an unrelated reduction helper.
 
 This script disassembles the gfx950 code object embedded in a built object / shared library and reports every basic
-block in which a scratch access precedes the EXEC restore.  Exit status 1 if any is found.
+block in which a scratch access precedes the EXEC restore (`s_or_b64 exec, exec, ...` or `s_or_saveexec_b64`).  Exit status 1 if any is found.
 
     python tools/check_spill_exec.py radae_amd/libradehip.so
 """
@@ -64,8 +64,8 @@ def scan(text):
             pend = []
         if op.startswith("scratch_store") or op.startswith("scratch_load"):
             pend.append(f"{addr:#x}: {op} {args}")
-        elif op == "s_or_b64" and args.replace(" ", "").startswith("exec,exec,"):
-            if pend:
+        elif (op == "s_or_b64" and args.replace(" ", "").startswith("exec,exec,")) or op == "s_or_saveexec_b64":
+            if pend:                  # EXEC widens here (join after an if, or the else side taking over the remaining lanes)
                 hits.append((fn, addr, pend))
             pend = []
         elif "exec" in args.split(",")[0] or op == "s_barrier" or "saveexec" in op:
