@@ -158,6 +158,7 @@ def main():
     eng.close()
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()                   # rank 0 may still be in its roofline leg: leave the group together
         dist.destroy_process_group()
 
 
