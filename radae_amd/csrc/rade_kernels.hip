@@ -1190,17 +1190,15 @@ typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(1))) float glb_float;
 __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], lds_float *scr, const glb_float *__restrict__ tw, int lane)
 {
+    // the inter-pass twiddles e^{-j2pi lane q/2048} are fetched before the first in-lane DFT, which hides their L2 round trip
+    float2 w1[32];
+#pragma unroll
+    for (int q = 1; q < 32; q++) w1[q] = make_float2(tw[2 * (q * 64 + lane)], tw[2 * (q * 64 + lane) + 1]);
+    __builtin_amdgcn_sched_barrier(0);
     dft32_inlane(v);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        float2 w[8];                                    // issue the 8 loads together, then consume (the barriers pin that order)
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int q = 8 * c + u; w[u] = make_float2(tw[2 * (q * 64 + lane)], tw[2 * (q * 64 + lane) + 1]); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int q = 8 * c + u; if (q) v[brev5(q)] = cmul(v[brev5(q)], w[u]); }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    for (int q = 1; q < 32; q++) v[brev5(q)] = cmul(v[brev5(q)], w1[q]);
     const int q2 = lane >> 1, h = lane & 1;
     float ur[32], ui[32];
 #pragma unroll
@@ -1217,20 +1215,15 @@ __device__ __forceinline__ void fft2048_wave(float2 (&v)[32], lds_float *scr, co
     __builtin_amdgcn_wave_barrier();
     // radix-2 DIF stage over l <-> l + 32 (the partner lane): even outputs on h = 0, odd outputs (twiddled) on h = 1
     const float sg = h ? -1.0f : 1.0f;
-    const glb_float *w64 = tw + 2 * (2048 + h * 32);                                          // h = 0: ones, h = 1: e^{-j2pi l/64}
+    // h = 0: u + o;  h = 1: (o - u) e^{-j2pi l/64}, the twiddle as a literal (no table fetch inside the transform)
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        float2 w[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) w[u] = make_float2(w64[2 * (8 * c + u)], w64[2 * (8 * c + u) + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int l = 8 * c + u;
-            const float sr = fmaf(ur[l], sg, lane_swap1(ur[l])), si = fmaf(ui[l], sg, lane_swap1(ui[l]));   // h = 0: u + o;  h = 1: o - u
-            v[l] = l ? cmul(make_float2(sr, si), w[u]) : make_float2(sr, si);
+    for (int l = 0; l < 32; l++) {
+        const float sr = fmaf(ur[l], sg, lane_swap1(ur[l])), si = fmaf(ui[l], sg, lane_swap1(ui[l]));
+        if (l == 0) v[l] = make_float2(sr, si);
+        else {
+            const float2 t = cmul(make_float2(sr, si), make_float2(C64[l], -S64[l]));
+            v[l] = h ? t : make_float2(sr, si);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     dft32_inlane(v);
 }
