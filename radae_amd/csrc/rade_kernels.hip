@@ -1263,16 +1263,13 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
                 }
             } else {
                 const glb_float *Gf = G + (size_t)f * FFT_N * 2;
+                float2 g[32];                                                 // one L2 round trip for the whole spectrum row, not four
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    float2 g[8];
+                for (int u = 0; u < 32; u++) { const int k = lane + 64 * u; g[u] = make_float2(Gf[2 * k], Gf[2 * k + 1]); }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < 8; u++) { const int k = lane + 64 * (8 * c + u); g[u] = make_float2(Gf[2 * k], Gf[2 * k + 1]); }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 8; u++) { const int k = lane + 64 * (8 * c + u); const float2 y = cmul(make_float2(Xf[2 * k], Xf[2 * k + 1]), g[u]); v[8 * c + u] = make_float2(y.y, y.x); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int u = 0; u < 32; u++) { const int k = lane + 64 * u; const float2 y = cmul(make_float2(Xf[2 * k], Xf[2 * k + 1]), g[u]); v[u] = make_float2(y.y, y.x); }
+                __builtin_amdgcn_sched_barrier(0);
             }
             const int t0 = q2 + 32 * h;                                       // this lane's outputs: t = t0 + 64 p < Nmf
             float d1[15];                                                     // |Dt1| of the same (f, t): fetched now, used after the transform
