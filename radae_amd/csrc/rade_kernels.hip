@@ -532,6 +532,9 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
 #pragma unroll
                 for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
             const unsigned short *wbase = w.wp16 + ((size_t)nt0 * 2 * 64 + lane) * 8;
+            float biasv[NT];                                           // fetched now, used after the k loop and the reduction
+#pragma unroll
+            for (int i = 0; i < NT; i++) { const int col = (nt0 + i) * 32 + (lane & 31); biasv[i] = (w.bias && nt0 + i < ntt && col < w.N) ? w.bias[col] : 0.0f; }
             f32x4 a_lo4 = { 0.0f, 0.0f, 0.0f, 0.0f }, a_hi4 = a_lo4;   // this block's 8 activations (f32)
             f16x8 bh[NT], bl[NT];
             auto fetch = [&](int kb) {
@@ -575,7 +578,7 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
             for (int i = 0; i < NT; i++) {
                 const int col = (nt0 + i) * 32 + (lane & 31);
                 if (nt0 + i >= ntt || col >= w.N) continue;
-                const float bias = w.bias ? w.bias[col] : 0.0f;
+                const float bias = biasv[i];
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++) {
                     const int j = wave * 2 + jj;
@@ -1653,6 +1656,9 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         float2 filt[3];
         {
             const int i0 = 3 * tid;
+            float2 eup[3];                                  // mix-up phasors of this thread's outputs: fetched ahead of the FIR
+#pragma unroll
+            for (int j = 0; j < 3; j++) eup[j] = ld2(tab->bpf_E, min(i0 + j, RD_NINMAX - 1));
             float ar[3] = { 0.0f, 0.0f, 0.0f }, ai[3] = { 0.0f, 0.0f, 0.0f };
             if (i0 < nin) {
 #pragma unroll 2
@@ -1683,7 +1689,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             for (int j = 0; j < 3; j++) {
                 const int i = i0 + j;
                 filt[j] = make_float2(0.0f, 0.0f);
-                if (i < nin) filt[j] = cmul(make_float2(ar[j], ai[j]), cconj(cmul(bpf_phase, ld2(tab->bpf_E, i))));   // mix back up
+                if (i < nin) filt[j] = cmul(make_float2(ar[j], ai[j]), cconj(cmul(bpf_phase, eup[j])));   // mix back up
             }
         }
         PH(19);
