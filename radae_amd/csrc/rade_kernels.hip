@@ -1449,11 +1449,13 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
     const int ntasks = ((2 * nf + 15) >> 4) * 2;
     const int i = lane & 15, kk = lane >> 4;
     PH_T0();
-    if (tid < nf) {                                                       // sincos per candidate frequency
-        const double w = 2.0 * PI_D * (fstart + tid * delta) / 8000.0;
-        double sn, cs; sincos(-w, &sn, &cs); sh->rtw[tid] = make_double2(cs, sn);
-        sincos(-w * RD_NMF, &sn, &cs); sh->rrot[tid] = make_double2(cs, sn);
-        sincos(-w * 80.0, &sn, &cs); sh->rt80[tid] = make_double2(cs, sn);
+    if (tid < 3 * nf) {                                                   // three phasors per candidate frequency, one thread each
+        const int which = tid / nf, fi = tid - which * nf;
+        const double w = 2.0 * PI_D * (fstart + fi * delta) / 8000.0;
+        const double arg = which == 0 ? -w : (which == 1 ? -w * RD_NMF : -w * 80.0);
+        double sn, cs; sincos(arg, &sn, &cs);
+        double2 *dstp = which == 0 ? sh->rtw : (which == 1 ? sh->rrot : sh->rt80);
+        dstp[fi] = make_double2(cs, sn);
     }
     if (tid >= 64 && tid < 64 + 2 * 176) {                                // the two windows as doubles: (xr, xi, xi, -xr)
         const int j = tid - 64, frame = j / 176, k = j - frame * 176;
