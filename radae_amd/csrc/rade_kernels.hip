@@ -1357,13 +1357,17 @@ __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
 }
 
 // sum NV doubles per thread over the workgroup: wave shuffles, then one LDS pass; result in sh->redd[0..NV)
-template <int NV>
+// Entries k >= KALL are non-zero only in the first NW wavefronts (the caller's contract): the others skip their f64 reductions.
+// redd is private to this routine and every call ends with a barrier, so none is needed before the partials are stored.
+template <int NV, int KALL = NV, int NW = NT_RX / 64>
 __device__ void block_sum_multi(RxShared *sh, double (&v)[NV])
 {
     const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = wave_sum_f64(v[k]);
-    __syncthreads();
+    for (int k = 0; k < NV; k++) {
+        if (k < KALL || wave < NW) v[k] = wave_sum_f64(v[k]);
+        else v[k] = 0.0;
+    }
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < NV; k++) sh->redd[wave * NV + k] = v[k];
@@ -1850,7 +1854,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 rx_corr_term(sh, tm + RD_M + RD_NCP, sn, cs, sh->pendd, red[6], red[7]);
                 rx_corr_term(sh, tm + RD_NMF, sn, cs, sh->pendd, red[8], red[9]);
             }
-            block_sum_multi<10>(sh, red);
+            block_sum_multi<10, 2, (RD_M + 63) / 64>(sh, red);      // the correlation terms live in threads < M
             const float sr = sigma_r_from_sums(red[0], red[1]);
             const double D = hypot(red[2], red[3]) + hypot(red[4], red[5]);
             const double De = hypot(red[6], red[7]) + hypot(red[8], red[9]);
