@@ -602,7 +602,7 @@ __device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, in
 // reduced through LDS and no barrier falls inside the product; with a single 32x32 accumulator the wave can keep D k-blocks
 // of operands in flight, which is what the L2-latency-bound loop needs.  Tiles beyond the eighth go through ds_gemm16.
 template <int D>
-__device__ void ds_gemm16_cols(const float *a1, int a1_st, int K1, const rd_lin w, float *y, int y_st, int Tb)
+__device__ void ds_gemm16_cols(const float *a1, int a1_st, int K1, const rd_lin w, float *y, int y_st, int act, int Tb)
 {
     const int lane = threadIdx.x & 63, nt = threadIdx.x >> 6, half = lane >> 5;
     const int ntt = (w.N + 31) >> 5, nkb = K1 >> 4;
@@ -649,7 +649,11 @@ __device__ void ds_gemm16_cols(const float *a1, int a1_st, int K1, const rd_lin 
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
-                if (tt < Tb) y[(size_t)tt * y_st + col] = acc[j] * 0x1p-18f + bias;
+                if (tt >= Tb) continue;
+                float v = acc[j] * 0x1p-18f + bias;
+                if (act == 1) v = clamp1(gate_tanh(v));
+                else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * gate_sigmoid(v));
+                y[(size_t)tt * y_st + col] = v;
             }
         }
     }
@@ -723,16 +727,19 @@ __device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb, i
     PH_T0();
     float *x = a.x + (size_t)b * a.x_sb;
     float *gi = a.gi + (size_t)b * a.gi_sb, *hb = a.hbuf + (size_t)b * a.hb_sb;
-    ds_gemm16<DS_NT>(sh, tid, a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, nullptr, 0, 0, nullptr, a.dense1, x, W, 1, Tb);
+    // short-K, few-column products (dense1: K = 80, GLU gates: K = 96): one column tile per wave, no split-K reduction
+    ds_gemm16_cols<4>(a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, a.dense1, x, W, 1, Tb);
+    __syncthreads();
 #pragma unroll 1
     for (int l = 0; l < 5; l++) {
         const int in = 96 + 128 * l, cin = in + 96;      // radae_base.py:378-386
-        ds_gemm16_cols<4>(x, W, in, a.gin[l], gi, 288, Tb);                                   // column tiles 0..7, one per wave
+        ds_gemm16_cols<4>(x, W, in, a.gin[l], gi, 288, 0, Tb);                                 // column tiles 0..7, one per wave
         ds_gemm16<1>(sh, tid, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb, 8, 9);   // tile 8: K over the 8 waves
         PH(21);
         ds_scan(sh, tid, gi, 288, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, hb, 96, true, Tb);
         PH(23);
-        ds_gemm16<DS_NT>(sh, tid, hb, 96, 96, nullptr, 0, 0, nullptr, a.glu[l], x + in, W, 2, Tb);
+        ds_gemm16_cols<4>(hb, 96, 96, a.glu[l], x + in, W, 2, Tb);
+        __syncthreads();
         ds_gemm16<1>(sh, tid, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
     }
     ds_gemm16<DS_NT>(sh, tid, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
