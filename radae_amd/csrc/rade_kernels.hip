@@ -1890,7 +1890,9 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 rx1[n] = cmul(sh->rxb[tmax - RD_NCP + n], make_float2(pr, pi));
             }
             __syncthreads();
-            if (tid == 0) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
+            // the phase accumulator advances on the last wavefront, which has no part in the DFT that follows (a f64 sincos on
+            // thread 0 would hold back wavefront 0 and with it the barrier after the DFT)
+            if (tid == NT_RX - 64) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
             PH(7);
             // receiver_one (dsp.py:487-526): window [16:176] of each 192-sample symbol, 160->30 DFT
             // two lanes per (symbol, carrier), 80 samples each in four independent chains; the halves meet through a lane swap
