@@ -1933,26 +1933,38 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 }
                 __syncthreads();
                 // update_snr_est (dsp.py:438-456) + coarse magnitude (:477-482): per-carrier terms reduced by wave shuffles
-                if (tid < 64) {
-                    float s1 = 0.0f, s2 = 0.0f, pm = 0.0f;
-                    if (tid < RD_NC) {
-                        const float2 r0 = sh->rp[0][tid], r1 = sh->rp[1][tid], pc = sh->sym[0][tid];
-                        const float2 rc = cmul(pc, unit_conj(r0));
-                        const float ap = hypotf(pc.x, pc.y); s1 = ap * ap; s2 = fabsf(rc.y) * fabsf(rc.y);
-                        const float a0 = hypotf(r0.x, r0.y), a1 = hypotf(r1.x, r1.y); pm = a0 * a0 + a1 * a1;
-                    }
-                    s1 = wave_sum_f32(s1); s2 = wave_sum_f32(s2); pm = wave_sum_f32(pm);      // lanes >= Nc hold zeros
-                    if (tid == 0) {
-                        const float S1 = s1, S2 = s2 + 1e-12f;
-                        float snr = S1 / (2.0f * S2) - 1.0f;
-                        if (snr <= 0.0f) snr = 0.1f;
-                        float snrdB = 10.0f * log10f(snr);
-                        snrdB = (snrdB - 2.513f) / 0.8070f;
-                        const float snr3k = snrdB + tab->snr_c1 + tab->snr_c2;
-                        S->snr_est = 0.9f * S->snr_est + 0.1f * snr3k;
-                        float mag = powf(pm / 60.0f, 0.5f) + 1e-6f;
-                        S->mag = (mag * fabsf(tab->P[0])) / tab->pilot_gain;
-                        S->valid_output = 1;
+                // two independent chains on two wavefronts: 0 = coarse magnitude (the EQ below waits for it), 1 = SNR estimate
+                if (tid < 128) {
+                    const int c = tid & 63;
+                    if (tid < 64) {
+                        float pm = 0.0f;
+                        if (c < RD_NC) {
+                            const float2 r0 = sh->rp[0][c], r1 = sh->rp[1][c];
+                            const float a0 = hypotf(r0.x, r0.y), a1 = hypotf(r1.x, r1.y); pm = a0 * a0 + a1 * a1;
+                        }
+                        pm = wave_sum_f32(pm);                                                   // lanes >= Nc hold zeros
+                        if (c == 0) {
+                            float mag = powf(pm / 60.0f, 0.5f) + 1e-6f;
+                            S->mag = (mag * fabsf(tab->P[0])) / tab->pilot_gain;
+                            S->valid_output = 1;
+                        }
+                    } else {
+                        float s1 = 0.0f, s2 = 0.0f;
+                        if (c < RD_NC) {
+                            const float2 r0 = sh->rp[0][c], pc = sh->sym[0][c];
+                            const float2 rc = cmul(pc, unit_conj(r0));
+                            const float ap = hypotf(pc.x, pc.y); s1 = ap * ap; s2 = fabsf(rc.y) * fabsf(rc.y);
+                        }
+                        s1 = wave_sum_f32(s1); s2 = wave_sum_f32(s2);
+                        if (c == 0) {
+                            const float S1 = s1, S2 = s2 + 1e-12f;
+                            float snr = S1 / (2.0f * S2) - 1.0f;
+                            if (snr <= 0.0f) snr = 0.1f;
+                            float snrdB = 10.0f * log10f(snr);
+                            snrdB = (snrdB - 2.513f) / 0.8070f;
+                            const float snr3k = snrdB + tab->snr_c1 + tab->snr_c2;
+                            S->snr_est = 0.9f * S->snr_est + 0.1f * snr3k;
+                        }
                     }
                 }
                 __syncthreads();
