@@ -1666,6 +1666,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         PH(18);
         // 101-tap FIR, three consecutive outputs per thread over a sliding register window (one LDS read per tap and
         // thread instead of one per tap and output); taps accumulate in ascending order
+        const float2 e_last = ld2(tab->bpf_E, nin - 1);    // next call's starting phase (thread 0, below): fetched ahead of the FIR
         float2 filt[3];
         {
             const int i0 = 3 * tid;
@@ -1719,7 +1720,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         for (int j = 0; j < 3; j++) { const int i = 3 * tid + j; if (i < nin) sh->rxb[RD_RXBUF - nin + i] = filt[j]; }
         if (tid < 102) sh->bmem[tid] = memv;
         if (tid == 0) {
-            S->bpf_phase = cmul(bpf_phase, ld2(tab->bpf_E, nin - 1));
+            S->bpf_phase = cmul(bpf_phase, e_last);
             S->bpf_mem_len = 102; S->consumed_inv += nin; S->consumed_round += nin;
         }
         __syncthreads();
