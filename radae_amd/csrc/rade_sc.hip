@@ -103,6 +103,7 @@ struct ScShared {
     float2 sb[2 * SC_NFRAME];
     double red[4][SC_NT / 64];
     float cabs[SC_NFRAME]; float2 cs[SC_NFRAME];
+    unsigned long long bal[2][2]; float wbest[2]; int wbests[2];
     int nin, state, fs_s, bad_fs, go;
     double2 rx_lo; double phase_fine, phase_coarse, phase_amb, g; float2 max_cs; float norm;
 };
@@ -185,15 +186,29 @@ __global__ __launch_bounds__(SC_NT) void k_sc_rx(sc_stream *stg, const double *r
             sh.fine[tid] = atan2(ai, ar) / 2.0;
         }
         __syncthreads();
-        if (tid == 0) {
-            double pf = sh.phase_fine, pc = sh.phase_coarse;
-            for (int s = 0; s < SC_NFRAME; s++) {
-                const double f = sh.fine[s];
-                if (f - pf < -0.9 * SC_PI) pc += SC_PI;
-                if (f - pf > 0.9 * SC_PI) pc -= SC_PI;
-                pf = f; sh.phase[s] = pc + f;
+        // pi jumps (:722-726) as a prefix count over the frame: +1 where the fine estimate drops by more than 0.9 pi, -1 where it
+        // rises by as much; ballots give every symbol the number of jumps up to and including itself
+        {
+            bool jp = false, jm = false;
+            if (tid < SC_NFRAME) {
+                const double d = sh.fine[tid] - (tid ? sh.fine[tid - 1] : sh.phase_fine);
+                jp = d < -0.9 * SC_PI; jm = d > 0.9 * SC_PI;
             }
-            sh.phase_fine = pf; sh.phase_coarse = pc;
+            const unsigned long long bp = __ballot(jp), bm = __ballot(jm);
+            if (lane == 0 && wave < 2) { sh.bal[wave][0] = bp; sh.bal[wave][1] = bm; }
+            __syncthreads();
+            if (tid < SC_NFRAME) {
+                const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+                int c = __popcll(sh.bal[wave][0] & le) - __popcll(sh.bal[wave][1] & le);
+                if (wave == 1) c += __popcll(sh.bal[0][0]) - __popcll(sh.bal[0][1]);
+                const double pc = sh.phase_coarse + (double)c * SC_PI;
+                sh.phase[tid] = pc + sh.fine[tid];
+                if (tid == SC_NFRAME - 1) { sh.red[2][0] = pc; sh.red[3][0] = sh.fine[tid]; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            sh.phase_coarse = sh.red[2][0]; sh.phase_fine = sh.red[3][0];
             int nn = SC_NFRAME * SC_M;                     // :697-702; M/4 = one sample
             if (norm < -0.35) nn += SC_M / 4;
             if (norm > 0.35) nn -= SC_M / 4;
@@ -226,9 +241,20 @@ __global__ __launch_bounds__(SC_NT) void k_sc_rx(sc_stream *stg, const double *r
                 sh.cs[tid] = c; sh.cabs[tid] = hypotf(c.x, c.y);
             }
             __syncthreads();
+            {   // first maximum of |Cs| over the 96 offsets (strict > in ascending s, dsp.py:789): per-wave shuffles, two partials
+                float v = tid < SC_NFRAME ? sh.cabs[tid] : -1.0f; int si = tid < SC_NFRAME ? tid : 1 << 20;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(v, off); const int oi = __shfl_xor(si, off);
+                    if (ov > v || (ov == v && oi < si)) { v = ov; si = oi; }
+                }
+                if (lane == 0 && wave < 2) { sh.wbest[wave] = v; sh.wbests[wave] = si; }
+            }
+            __syncthreads();
             if (tid == 0) {
                 float best = 0.0f; int ms = 0; float2 mc = make_float2(0.0f, 0.0f);
-                for (int s = 0; s < SC_NFRAME; s++) if (sh.cabs[s] > best) { best = sh.cabs[s]; ms = s; mc = sh.cs[s]; }
+                for (int w = 0; w < 2; w++) if (sh.wbest[w] > best) { best = sh.wbest[w]; ms = sh.wbests[w]; }
+                if (best > 0.0f) mc = sh.cs[ms];
                 sh.max_cs = mc;
                 if (best >= 0.5f) {
                     sh.state = 1; sh.fs_s = ms; sh.bad_fs = 0;
