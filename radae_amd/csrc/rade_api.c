@@ -29,6 +29,10 @@ struct rade {
     int flags, nin, sync, snr;
     float *d_feat_in, *d_feat_out, *d_eoo; void *d_iq, *d_rx;
     pthread_mutex_t lock;
+    /* rade_tx is ~20 short launches for one stream (launch-bound): after the first call the sequence
+     * [features H2D, encoder + modulator kernels, samples D2H] is captured once and replayed as a hipGraph */
+    hipStream_t gs; hipGraphExec_t tx_graph; int tx_calls, tx_graph_off;
+    float *h_feat; RADE_COMP *h_iq;          /* pinned staging buffers the graph copies from / to */
 };
 
 void rade_initialize(void) { /* reference: Py_InitializeEx (rade_api.c:329-332); HIP initialises lazily */ }
@@ -75,6 +79,9 @@ struct rade *rade_open(char model_file[], int flags)
         hipMalloc((void **)&r->d_eoo, sizeof(float) * RD_NEOOBITS) || hipMalloc(&r->d_iq, sizeof(RADE_COMP) * RD_NEOO) ||
         hipMalloc(&r->d_rx, sizeof(RADE_COMP) * RD_NINMAX)) { rade_close(r); return NULL; }
     pthread_mutex_init(&r->lock, NULL);
+    /* optional fast path of rade_tx (hipGraph replay): any failure here or later simply leaves the plain path in use */
+    if (getenv("RADE_NO_GRAPH") || hipStreamCreate(&r->gs) != hipSuccess || hipHostMalloc((void **)&r->h_feat, sizeof(float) * RD_FEAT_MF, 0) != hipSuccess ||
+        hipHostMalloc((void **)&r->h_iq, sizeof(RADE_COMP) * RD_NMF, 0) != hipSuccess) { r->tx_graph_off = 1; (void)hipGetLastError(); }
     if (!(flags & RADE_VERBOSE_0)) fprintf(stderr, "rade_open: model %s, HIP back end\n", path);
     return r;
 }
@@ -82,6 +89,10 @@ struct rade *rade_open(char model_file[], int flags)
 void rade_close(struct rade *r)
 {
     if (!r) return;
+    if (r->tx_graph) hipGraphExecDestroy(r->tx_graph);
+    if (r->h_feat) hipHostFree(r->h_feat);
+    if (r->h_iq) hipHostFree(r->h_iq);
+    if (r->gs) hipStreamDestroy(r->gs);
     if (r->eng) rade_batch_close(r->eng);
     void *p[] = { r->d_feat_in, r->d_feat_out, r->d_eoo, r->d_iq, r->d_rx };
     for (int i = 0; i < 5; i++) if (p[i]) hipFree(p[i]);
@@ -109,9 +120,31 @@ int rade_tx(struct rade *r, RADE_COMP tx_out[], float features_in[])
     assert(r != NULL); assert(features_in != NULL); assert(tx_out != NULL);
     int ret = 0;
     pthread_mutex_lock(&r->lock);
-    if (hipMemcpy(r->d_feat_in, features_in, sizeof(float) * RD_FEAT_MF, hipMemcpyHostToDevice) == hipSuccess &&
+    if (r->tx_calls > 0 && !r->tx_graph_off && r->gs && r->h_feat && r->h_iq) {
+        if (!r->tx_graph) {                                   /* second call: record the sequence (nothing runs during capture) */
+            hipGraph_t g = NULL;
+            int ok = hipStreamBeginCapture(r->gs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                ok = hipMemcpyAsync(r->d_feat_in, r->h_feat, sizeof(float) * RD_FEAT_MF, hipMemcpyHostToDevice, r->gs) == hipSuccess &&
+                     rade_batch_tx(r->eng, r->d_feat_in, 1, r->d_iq, RD_NMF, NULL, r->gs) == RD_NMF &&
+                     hipMemcpyAsync(r->h_iq, r->d_iq, sizeof(RADE_COMP) * RD_NMF, hipMemcpyDeviceToHost, r->gs) == hipSuccess;
+                if (hipStreamEndCapture(r->gs, &g) != hipSuccess) ok = 0;
+            }
+            if (ok && hipGraphInstantiate(&r->tx_graph, g, NULL, NULL, 0) != hipSuccess) { ok = 0; r->tx_graph = NULL; }
+            if (g) hipGraphDestroy(g);
+            if (!ok) { r->tx_graph_off = 1; (void)hipGetLastError(); }
+        }
+        if (r->tx_graph) {
+            memcpy(r->h_feat, features_in, sizeof(float) * RD_FEAT_MF);
+            if (hipGraphLaunch(r->tx_graph, r->gs) == hipSuccess && hipStreamSynchronize(r->gs) == hipSuccess) {
+                memcpy(tx_out, r->h_iq, sizeof(RADE_COMP) * RD_NMF); ret = RD_NMF;
+            }
+        }
+    }
+    if (!ret && hipMemcpy(r->d_feat_in, features_in, sizeof(float) * RD_FEAT_MF, hipMemcpyHostToDevice) == hipSuccess &&
         rade_batch_tx(r->eng, r->d_feat_in, 1, r->d_iq, RD_NMF, NULL, NULL) == RD_NMF &&
         hipMemcpy(tx_out, r->d_iq, sizeof(RADE_COMP) * RD_NMF, hipMemcpyDeviceToHost) == hipSuccess) ret = RD_NMF;
+    r->tx_calls++;
     pthread_mutex_unlock(&r->lock);
     if (!ret) { fprintf(stderr, "rade_tx: device error\n"); exit(1); }       /* reference: check_error() exits (rade_api.c:93-102) */
     return ret;
