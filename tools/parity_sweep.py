@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Randomised receiver parity sweep (developer aid, uses the oracle as the checker like the tests do): N random channels /
+offsets / SNRs; the oracle produces the received samples, the HIP receiver and the oracle receiver both consume exactly those
+samples, every per-call discrete output must be equal and the decoded features equal to 1e-4 RMS."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from radae_amd.engine import BatchEngine, sigma_from_EbNodB
+from radae_amd.channel_tools import multipath_g, synth_features
+from oracle import oracle_py as O
+INT_KEYS = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
+N = int(os.environ.get("SWEEP_N", "48")); n_mf = 24
+O.build(); m = O.Model()
+rng = np.random.default_rng(int(os.environ.get("SWEEP_SEED", "2026")))
+bad = 0; ties = 0; tot_calls = 0; tot_valid = 0
+for case in range(N):
+    seed = int(rng.integers(1, 1 << 30)); eb = float(rng.uniform(-1.0, 12.0)); fo = float(rng.uniform(-40.0, 40.0))
+    chan = ["awgn", "mpp", "mpd", "mpg"][int(rng.integers(0, 4))]
+    r2 = np.random.default_rng(seed)
+    feats = synth_features(seed, n_mf * 12); n_sig = n_mf * 960
+    G = multipath_g(chan, 8000, n_sig, seed + 1) if chan != "awgn" else None
+    n_pre = int(r2.integers(1000, 9000)); n_tot = n_pre + n_sig + 2304
+    noise = ((r2.standard_normal(n_tot) + 1j * r2.standard_normal(n_tot)) / np.sqrt(2)).astype(np.complex64)
+    sigma = sigma_from_EbNodB(eb)
+    tx = O.Tx(m)
+    sig = np.concatenate([tx.frame(feats[12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+    r, fin = O.channel(sig, G, noise[n_pre:n_pre + n_sig], sigma, fo)
+    e = O.channel_eoo(tx.eoo(), noise[n_pre + n_sig:n_pre + n_sig + 1152], sigma, fo, 0.0, fin)
+    full = np.concatenate([sigma * noise[:n_pre], r, e, sigma * noise[-1152:]]).astype(np.complex64)
+    d = O.run_rx_stream(m, full)
+    eng = BatchEngine(1, max_tx_mf=1, rx_trace_calls=64)
+    fo_dev, st, _ = eng.rx(torch.tensor(full[None], device="cuda"))
+    t = eng.rx_trace(0)
+    nv = st[0].n_valid
+    ok = all(np.array_equal(t[k], d[k]) for k in INT_KEYS) and nv == len(d["features_out"])
+    if ok and nv:
+        ok = float(np.sqrt(np.mean((fo_dev.cpu().numpy()[0, :nv] - d["features_out"]) ** 2))) < 1e-4
+    tot_calls += st[0].n_calls; tot_valid += nv
+    if not ok:
+        first = {k: int(np.argmax(t[k] != d[k])) for k in INT_KEYS if not np.array_equal(t[k], d[k])}
+        dfm = float(np.abs(t["fmax"] - d["fmax"]).max()) if len(t["fmax"]) == len(d["fmax"]) else -1.0
+        # refine() picks the arg-max of complex64 magnitudes on a 0.1 Hz grid: when two neighbouring bins are equal to within the
+        # float rounding of the complex128 sums, summation order decides; fmax then moves by 0.1 x 0.1 Hz and the features follow
+        tie = not first and 0.0 < dfm < 0.0501
+        ties += tie; bad += not tie
+        print(f"{'refine near-tie' if tie else 'MISMATCH'} case {case}: seed {seed} {chan} Eb/No {eb!r} dB fo {fo!r} Hz valid {nv}/{len(d['features_out'])} max |fmax diff| {dfm:.4f} first differing call per key {first}")
+    eng.close()
+print(f"{N} cases, {tot_calls} receiver calls, {tot_valid} decoded frames: {bad} mismatching case(s), {ties} with a refine() near-tie resolved the other way")
