@@ -1755,7 +1755,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const float sr = sigma_r_from_rowsums(sh);
             if (tid == 0) {
                 S->Dthresh = (double)(2.0f * sr) * sqrt(-log(0.00001 / 5.0));
-                if (Dmax > 0.0f) { S->tmax = tbest; S->f_ind_max = fbest; S->fmax = tab->fcoarse[fbest]; S->Dtmax12 = (double)Dmax; }
+                if (Dmax > 0.0f) { S->tmax = tbest; S->f_ind_max = fbest; S->fmax = -50.0 + 2.5 * fbest;   /* = tab->fcoarse[fbest] (dsp.py:163), without the dependent global load in the serial section */ S->Dtmax12 = (double)Dmax; }
                 else { S->tmax = 0; S->f_ind_max = 0; S->fmax = 0.0; S->Dtmax12 = 0.0; }
                 S->candidate = S->Dtmax12 > S->Dthresh;
             }
