@@ -1452,7 +1452,21 @@ __device__ __forceinline__ f64x4 refine_tile(const RxShared *sh, int mt, int fra
     return acc0 + acc1;
 }
 
-__device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep)
+// refine()'s three phasors per candidate frequency (e^{-jw}, e^{-jw Nmf}, e^{-jw 80}), one thread each: k in [0, 3 nf)
+__device__ __forceinline__ void refine_tables(RxShared *sh, int k, double fstart, double fstop, double fstep)
+{
+    const int nf = (int)ceil((fstop - fstart) / fstep);                 // np.arange length
+    const double delta = (fstart + fstep) - fstart;                       // np.arange fill rule
+    if (k < 0 || k >= 3 * nf) return;
+    const int which = k / nf, fi = k - which * nf;
+    const double w = 2.0 * PI_D * (fstart + fi * delta) / 8000.0;
+    const double arg = which == 0 ? -w : (which == 1 ? -w * RD_NMF : -w * 80.0);
+    double sn, cs; sincos(arg, &sn, &cs);
+    double2 *dstp = which == 0 ? sh->rtw : (which == 1 ? sh->rrot : sh->rt80);
+    dstp[fi] = make_double2(cs, sn);
+}
+
+__device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep, bool have_tables)
 {
     const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
     const int nf = (int)ceil((fstop - fstart) / fstep);                 // np.arange length
@@ -1460,14 +1474,7 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
     const int ntasks = ((2 * nf + 15) >> 4) * 2;
     const int i = lane & 15, kk = lane >> 4;
     PH_T0();
-    if (tid < 3 * nf) {                                                   // three phasors per candidate frequency, one thread each
-        const int which = tid / nf, fi = tid - which * nf;
-        const double w = 2.0 * PI_D * (fstart + fi * delta) / 8000.0;
-        const double arg = which == 0 ? -w : (which == 1 ? -w * RD_NMF : -w * 80.0);
-        double sn, cs; sincos(arg, &sn, &cs);
-        double2 *dstp = which == 0 ? sh->rtw : (which == 1 ? sh->rrot : sh->rt80);
-        dstp[fi] = make_double2(cs, sn);
-    }
+    if (!have_tables) refine_tables(sh, tid, fstart, fstop, fstep);
     if (tid >= 64 && tid < 64 + 2 * 176) {                                // the two windows as doubles: (xr, xi, xi, -xr)
         const int j = tid - 64, frame = j / 176, k = j - frame * 176;
         const float2 x = sh->rxb[min(t0 + frame * RD_NMF + k, RD_RXBUF - 1)];
@@ -1667,6 +1674,9 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // 101-tap FIR, three consecutive outputs per thread over a sliding register window (one LDS read per tap and
         // thread instead of one per tap and output); taps accumulate in ascending order
         const float2 e_last = ld2(tab->bpf_E, nin - 1);    // next call's starting phase (thread 0, below): fetched ahead of the FIR
+        // in sync, refine() of this call searches fmax +-1 Hz: its f64 sincos tables only depend on last call's fmax, so the last
+        // wavefront (idle during the FIR) prepares them now instead of everybody waiting for them later
+        if (state == ST_SYNC && tid >= NT_RX - 64) { const double fm = S->fmax; refine_tables(sh, tid - (NT_RX - 64), fm - 1.0, fm + 1.0, 0.1); }
         float2 filt[3];
         {
             const int i0 = 3 * tid;
@@ -1767,7 +1777,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 const int tm = S->tmax; const double fm = S->fmax;
                 const int t0 = max(0, tm - 8);
                 int tnew = tm; double fhat = fm;
-                rx_refine(sh, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1);
+                rx_refine(sh, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true);      // tables: see the BPF stage
                 if (tid == 0) { S->tmax = tnew; S->fmax = 0.9 * fm + 0.1 * fhat; }
             }
             PH(4);
@@ -2003,7 +2013,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const int tm = S->tmax; const double fm = S->fmax;
             const int t0 = max(0, tm - 1);
             int tnew = tm; double fnew = fm;
-            rx_refine(sh, &tnew, &fnew, t0, tm + 2 - t0, fm - 10.0, fm + 10.0, 0.25);
+            rx_refine(sh, &tnew, &fnew, t0, tm + 2 - t0, fm - 10.0, fm + 10.0, 0.25, false);
             if (tid == 0) { S->tmax = tnew; S->fmax = fnew + S->foff_err; S->foff_err = 0.0; }
             __syncthreads();
         }
