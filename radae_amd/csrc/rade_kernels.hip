@@ -1677,6 +1677,12 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // in sync, refine() of this call searches fmax +-1 Hz: its f64 sincos tables only depend on last call's fmax, so the last
         // wavefront (idle during the FIR) prepares them now instead of everybody waiting for them later
         if (state == ST_SYNC && tid >= NT_RX - 64) { const double fm = S->fmax; refine_tables(sh, tid - (NT_RX - 64), fm - 1.0, fm + 1.0, 0.1); }
+        if (state == ST_SYNC && tid >= NT_RX - 128 && tid < NT_RX - 128 + 48) {      // check_pilots' 48 row draws of this call, likewise
+            const int k = tid - (NT_RX - 128);
+            const uint32_t x = LCG_A[k] * S->lcg + LCG_C[k];
+            sh->rows48[k] = (int)((x >> 8) % RD_NMF);
+            if (k == 47) sh->redi[15] = (int)x;                                        // the new LCG state, committed after the barrier below
+        }
         float2 filt[3];
         {
             const int i0 = 3 * tid;
@@ -1731,6 +1737,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         if (tid < 102) sh->bmem[tid] = memv;
         if (tid == 0) {
             S->bpf_phase = cmul(bpf_phase, e_last);
+            if (state == ST_SYNC) S->lcg = (uint32_t)sh->redi[15];
             S->bpf_mem_len = 102; S->consumed_inv += nin; S->consumed_round += nin;
         }
         __syncthreads();
@@ -1783,16 +1790,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             PH(4);
             // check_pilots (dsp.py:273-320): refresh 48 pseudo-random rows
             // x_{i+1} = 1664525 x_i + 1013904223 (mod 2^32), 48 draws: thread i jumps straight to draw i (x_i = A^i x_0 + C_i)
-            {
-                const uint32_t x0 = S->lcg;
-                __syncthreads();
-                if (tid < 48) {
-                    const uint32_t x = LCG_A[tid] * x0 + LCG_C[tid];
-                    sh->rows48[tid] = (int)((x >> 8) % RD_NMF);
-                    if (tid == 47) S->lcg = x;
-                }
-            }
-            __syncthreads();
+            // (the draws were made during the BPF stage by an idle wavefront: rows48)
             // 96 rows (48 draws x {Dt1, Dt2}) x 40 frequencies on the f16 matrix cores, operands split in two binary16
             // planes: six tasks = 3 row tiles x {f-tiles 0-2, f-tiles 3-4}; the rx window of a row tile is converted
             // once per k-step and reused by the task's f-tiles; the pilot planes stream from L2 (a.corr16)
