@@ -1149,6 +1149,7 @@ struct RxShared {
     int rows48[48];
     double redd[(NT_RX / 64 + 1) * 10];   // block reductions (double): per-wave partials + totals
     float redf[16]; int redi[16]; int redj[16];   // arg-max reduction: slot 0 result, 1.. per-wave partials
+    double corrp[2][8];                   // pilot / end-of-over correlations at (tmax, fmax): partial sums of the two side wavefronts
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1780,12 +1781,14 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             PH(3);
         } else {
             // ---- in sync: refine, check_pilots, slips, UW, frequency correction, demod
+            int tm_ref; double fm_ref;                  // refine()'s result, known to every thread (S->tmax / S->fmax become visible at the next barrier)
             {
                 const int tm = S->tmax; const double fm = S->fmax;
                 const int t0 = max(0, tm - 8);
                 int tnew = tm; double fhat = fm;
                 rx_refine(sh, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true);      // tables: see the BPF stage
-                if (tid == 0) { S->tmax = tnew; S->fmax = 0.9 * fm + 0.1 * fhat; }
+                tm_ref = tnew; fm_ref = 0.9 * fm + 0.1 * fhat;
+                if (tid == 0) { S->tmax = tm_ref; S->fmax = fm_ref; }
             }
             PH(4);
             // check_pilots (dsp.py:273-320): refresh 48 pseudo-random rows
@@ -1847,6 +1850,43 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                         sh->absd[2 * row][f] = 0x1p-20f * hypotf(accA[q][0], accA[q][1]); sh->absd[2 * row][f + 1] = 0x1p-20f * hypotf(accA[q][2], accA[q][3]);
                         sh->absd[2 * row + 1][f] = 0x1p-20f * hypotf(accB[q][0], accB[q][1]); sh->absd[2 * row + 1][f + 1] = 0x1p-20f * hypotf(accB[q][2], accB[q][3]);
                     }
+                } else {
+                    // ---- wavefronts 6 and 7 have no matrix work here.  refine() has fixed (tmax, fmax), so they prepare what the
+                    // phases after this one used to compute with everybody waiting: the four correlations of check_pilots
+                    // (dsp.py:307-313) and the frequency-corrected window the demodulator reads (radae_rxe.py:209-218, :227-233)
+                    const int k = tid - 6 * 64;
+                    const int tm = tm_ref; const double w = 2.0 * PI_D * fm_ref / 8000.0;
+                    double cr[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+                    for (int n = k; n < RD_M; n += 128) {
+                        const float2 cf = cis_reduced(-w * n);
+                        const double sn = cf.y, cs = cf.x;
+                        const double2 rp = sh->pd[n], re = sh->pendd[n];
+                        const int t0s[4] = { tm, tm + RD_NMF, tm + RD_M + RD_NCP, tm + RD_NMF };
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const float2 x = sh->rxb[t0s[q] + n];
+                            const double qr = cs * x.x - sn * x.y, qi = -(cs * x.y + sn * x.x);    // conj(w_vec*rx)
+                            const double2 r = q < 2 ? rp : re;
+                            cr[2 * q] += qr * r.x - qi * r.y; cr[2 * q + 1] += qr * r.y + qi * r.x;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) cr[q] = wave_sum_f64(cr[q]);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int q = 0; q < 8; q++) sh->corrp[wave - 6][q] = cr[q];
+                    }
+                    int t2 = tm;                                                  // timing slip, as the state update below applies it
+                    if (t2 >= RD_NMF - RD_M) t2 -= RD_M;
+                    if (t2 < RD_M) t2 += RD_M;
+                    const double rph_r = S->rph_r, rph_i = S->rph_i;
+                    float2 *rx1 = sh->xm;                                         // free between refine() and the next call's BPF
+                    for (int n = k; n < RD_NEOO; n += 128) {
+                        const float2 cs = cis_reduced(-w * (double)(n + 1));
+                        const double c = cs.x, s_ = cs.y;
+                        const float pr = (float)(rph_r * c - rph_i * s_), pi = (float)(rph_r * s_ + rph_i * c);
+                        rx1[n] = cmul(sh->rxb[t2 - RD_NCP + n], make_float2(pr, pi));
+                    }
                 }
             }
             __syncthreads();
@@ -1862,15 +1902,13 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const int tm = S->tmax; const double w = 2.0 * PI_D * S->fmax / 8000.0;
             double red[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
             for (int t = tid; t < RD_NMF; t += NT_RX) { red[0] += (double)sh->rowsum1[t]; red[1] += (double)sh->rowsum2[t]; }
-            if (tid < RD_M) {
-                const float2 cf = cis_reduced(-w * tid);
-                const double sn = cf.y, cs = cf.x;
-                rx_corr_term(sh, tm, sn, cs, sh->pd, red[2], red[3]);
-                rx_corr_term(sh, tm + RD_NMF, sn, cs, sh->pd, red[4], red[5]);
-                rx_corr_term(sh, tm + RD_M + RD_NCP, sn, cs, sh->pendd, red[6], red[7]);
-                rx_corr_term(sh, tm + RD_NMF, sn, cs, sh->pendd, red[8], red[9]);
+            {
+                double rs2[2] = { red[0], red[1] };
+                block_sum_multi<2>(sh, rs2);
+                red[0] = rs2[0]; red[1] = rs2[1];
             }
-            block_sum_multi<10, 2, (RD_M + 63) / 64>(sh, red);      // the correlation terms live in threads < M
+#pragma unroll
+            for (int q = 0; q < 8; q++) red[2 + q] = sh->corrp[0][q] + sh->corrp[1][q];     // prepared during the matrix phase above
             const float sr = sigma_r_from_sums(red[0], red[1]);
             const double D = hypot(red[2], red[3]) + hypot(red[4], red[5]);
             const double De = hypot(red[6], red[7]) + hypot(red[8], red[9]);
@@ -1890,15 +1928,9 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             PH(6);
             const int tmax = S->tmax, endofover = S->endofover, n_rows = S->n_rows;
             const double rph_r = S->rph_r, rph_i = S->rph_i;
-            // frequency correction (:227-233): rx_phase advances e^{-jw} per sample in complex128
+            // frequency correction (:227-233): rx_phase advances e^{-jw} per sample in complex128; the corrected window rx1 was
+            // written by the side wavefronts of the matrix phase
             float2 *rx1 = sh->xm;
-            for (int n = tid; n < RD_NEOO; n += NT_RX) {
-                const float2 cs = cis_reduced(-w * (double)(n + 1));
-                const double c = cs.x, s = cs.y;
-                const float pr = (float)(rph_r * c - rph_i * s), pi = (float)(rph_r * s + rph_i * c);
-                rx1[n] = cmul(sh->rxb[tmax - RD_NCP + n], make_float2(pr, pi));
-            }
-            __syncthreads();
             // the phase accumulator advances on the last wavefront, which has no part in the DFT that follows (a f64 sincos on
             // thread 0 would hold back wavefront 0 and with it the barrier after the DFT)
             if (tid == NT_RX - 64) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
