@@ -1659,6 +1659,40 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         if (S->need_decode) { PH(22); rx_decode_pending(sh, a, b); PH(20); }
         if (!S->go) break;
         const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
+        const int mf0 = S->mf, n_rows0 = S->n_rows;          // stable until this call's state update
+        // state machine (radae_rxe.py:248-297) and per-call bookkeeping, run by ONE thread: thread 0 after a search / candidate call,
+        // the first lane of an idle wavefront during the demodulator of a synchronised call (nothing it writes is read before the
+        // barrier that ends the call: the phases in between use mf0 / n_rows0 and their own locals)
+        auto state_update = [&](int entry, int valid_out, int eoo) {
+            int next_state = state;
+            if (state == ST_SEARCH) {
+                if (S->candidate) { next_state = ST_CANDIDATE; S->tmax_candidate = S->tmax; S->valid_count = 1; }
+            } else if (state == ST_CANDIDATE) {
+                if (entry) {
+                    next_state = ST_SYNC;
+                    S->dec_reset_pending = 1; S->synced_count = 0; S->uw_fail = 0; S->uw_errors = 0; S->uw_from_row = S->n_rows; S->valid_count = 25;
+                } else if (S->candidate && abs(S->tmax - S->tmax_candidate) < RD_NCP) S->valid_count++;
+                else next_state = ST_SEARCH;
+            } else {
+                if (S->candidate) S->valid_count = 25;
+                else { S->valid_count--; if (S->valid_count == 0) next_state = ST_SEARCH; }
+                if (eoo || S->uw_fail) next_state = ST_SEARCH;
+            }
+            S->dt_valid = (state != ST_SYNC && next_state != ST_SYNC) ? S->dt_new + 1 : 0;   // next call's Dt1 == this call's Dt2 (buffer dt_new)
+            S->state = next_state;
+            if (next_state == ST_SEARCH) S->nin = RD_NMF;
+            S->mf++;
+            const int ret = valid_out | (eoo << 1);
+            const int call_idx = S->mf - 2;                   // 0-based index of this call since reset
+            if (valid_out) {
+                for (int k = 0; k < 3; k++) { const int rf = (k == 0) ? S->dec_reset_pending : 0; rnd->row_reset[S->n_rows + k] = rf; }
+                S->dec_reset_pending = 0; S->n_rows += 3; S->pending_valid++; S->valid_inv++;
+            }
+            if (eoo) { S->has_eoo = 1; S->eoo_inv++; }
+            const int nc = S->n_calls;
+            rnd->call_ret[nc] = ret; rnd->call_row_lo[nc] = S->uw_from_row; rnd->call_row_hi[nc] = S->n_rows; rnd->call_trace_idx[nc] = call_idx;
+            S->n_calls = nc + 1; S->calls_inv++;
+        };
         const float2 bpf_phase = S->bpf_phase;
         if (state == ST_SYNC && !S->lds_sync) {      // the demod / check_pilots tables share LDS with the FFT correlator
             for (int i = tid; i < RD_M * RD_NC; i += NT_RX) sh->wfwd[i / RD_NC][i % RD_NC] = make_float2(tab->Wfwd[i / RD_NC][i % RD_NC][0], tab->Wfwd[i / RD_NC][i % RD_NC][1]);
@@ -1926,7 +1960,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             __syncthreads();
             PH(6);
-            const int tmax = S->tmax, endofover = S->endofover, n_rows = S->n_rows;
+            const int tmax = S->tmax, endofover = S->endofover, n_rows = n_rows0;
             const double rph_r = S->rph_r, rph_i = S->rph_i;
             // frequency correction (:227-233): rx_phase advances e^{-jw} per sample in complex128; the corrected window rx1 was
             // written by the side wavefronts of the matrix phase
@@ -1934,6 +1968,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             // the phase accumulator advances on the last wavefront, which has no part in the DFT that follows (a f64 sincos on
             // thread 0 would hold back wavefront 0 and with it the barrier after the DFT)
             if (tid == NT_RX - 64) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
+            if (tid == NT_RX - 128) state_update(0, !endofover, endofover);   // valid_output of a synchronised call = !endofover (set by the EQ below)
             PH(7);
             // receiver_one (dsp.py:487-526): window [16:176] of each 192-sample symbol, 160->30 DFT
             // two lanes per (symbol, carrier), 80 samples each in four independent chains; the halves meet through a lane swap
@@ -1955,7 +1990,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             PH(8);
             float *zrow = a.zrows + ((size_t)b * a.dec_rows + n_rows) * RD_LATENT;   // 3 rows = 240 contiguous floats
             float *eoo_dst = a.eoo_out ? a.eoo_out + (size_t)b * RD_NEOOBITS : nullptr;
-            const int call_idx0 = S->mf - 1;
+            const int call_idx0 = mf0 - 1;
             if (!endofover) {
                 // est_pilots (dsp.py:418-435) for pilot rows 0 and 5
                 if (tid < 2 * RD_NC) {
@@ -2047,41 +2082,15 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             if (tid == 0) { S->tmax = tnew; S->fmax = fnew + S->foff_err; S->foff_err = 0.0; }
             __syncthreads();
         }
-        if (tid == 0) {
-            int next_state = state;
-            if (state == ST_SEARCH) {
-                if (S->candidate) { next_state = ST_CANDIDATE; S->tmax_candidate = S->tmax; S->valid_count = 1; }
-            } else if (state == ST_CANDIDATE) {
-                if (do_entry) {
-                    next_state = ST_SYNC;
-                    S->dec_reset_pending = 1; S->synced_count = 0; S->uw_fail = 0; S->uw_errors = 0; S->uw_from_row = S->n_rows; S->valid_count = 25;
-                } else if (S->candidate && abs(S->tmax - S->tmax_candidate) < RD_NCP) S->valid_count++;
-                else next_state = ST_SEARCH;
-            } else {
-                if (S->candidate) S->valid_count = 25;
-                else { S->valid_count--; if (S->valid_count == 0) next_state = ST_SEARCH; }
-                if (S->endofover || S->uw_fail) next_state = ST_SEARCH;
-            }
-            S->dt_valid = (state != ST_SYNC && next_state != ST_SYNC) ? S->dt_new + 1 : 0;   // next call's Dt1 == this call's Dt2 (buffer dt_new)
-            S->state = next_state;
-            if (next_state == ST_SEARCH) S->nin = RD_NMF;
-            S->mf++;
-            const int ret = S->valid_output | (S->endofover << 1);
-            const int call_idx = S->mf - 2;                   // 0-based index of this call since reset
-            if (S->valid_output) {
-                for (int k = 0; k < 3; k++) { const int rf = (k == 0) ? S->dec_reset_pending : 0; rnd->row_reset[S->n_rows + k] = rf; }
-                S->dec_reset_pending = 0; S->n_rows += 3; S->pending_valid++; S->valid_inv++;
-            }
-            if (S->endofover) { S->has_eoo = 1; S->eoo_inv++; }
-            const int nc = S->n_calls;
-            rnd->call_ret[nc] = ret; rnd->call_row_lo[nc] = S->uw_from_row; rnd->call_row_hi[nc] = S->n_rows; rnd->call_trace_idx[nc] = call_idx;
-            if (a.trace && call_idx < a.trace_cap) {
+        if (tid == 0 && state != ST_SYNC) state_update(do_entry, S->valid_output, S->endofover);   // (in sync: done during the demodulator, above)
+        if (tid == 0 && a.trace) {                        // per-call trace record: after the EQ, it carries this call's SNR estimate
+            const int call_idx = S->mf - 2;               // 0-based index of this call since reset
+            if (call_idx < a.trace_cap) {
                 rd_rx_trace *tr = a.trace + (size_t)b * a.trace_cap + call_idx;
-                tr->state_before = S->state_before; tr->state_after = S->state; tr->nin_before = S->nin_before; tr->nin_after = S->nin; tr->ret = ret;
+                tr->state_before = S->state_before; tr->state_after = S->state; tr->nin_before = S->nin_before; tr->nin_after = S->nin; tr->ret = S->valid_output | (S->endofover << 1);
                 tr->tmax = S->tmax; tr->f_ind_max = S->f_ind_max; tr->valid_count = S->valid_count; tr->uw_errors = S->uw_errors; tr->synced_count = S->synced_count;
                 tr->snr_int = (int)S->snr_est; tr->fmax = S->fmax; tr->Dthresh = S->Dthresh; tr->Dtmax12 = S->Dtmax12; tr->Dtmax12_eoo = S->Dtmax12_eoo; tr->snrdB_3k_est = S->snr_est;
             }
-            S->n_calls = nc + 1; S->calls_inv++;
         }
         __syncthreads();
         PH(10);
