@@ -9,6 +9,12 @@ already resident in HBM.  N > 1: one process per GPU (torchrun), utterances shar
 collective; the only collective is the RCCL broadcast of the weight blob.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
+`--config 2` instead measures BASELINE.json configs[1] (one stream through the rade_core.h-level encoder / decoder,
+latency-bound by construction) and prints its own line.
+
+roofline block: `frac` prices the work the dominant kernel EXECUTES (FFT correlator, decoder, in-sync
+DSP -- the constants below) at the f32 peak; the reference-formulation figure (98 MFLOP of GEMM per search call that this
+kernel never performs in that form) is reported separately as `equiv_ref_formulation` and is not a roofline.
 """
 import argparse
 import json
@@ -25,21 +31,32 @@ import torch
 NMF = 960
 F32_PEAK_TFLOPS = 157.3          # MI355X f32 matrix == f32 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0      # detect_pilots: 98.3 MFLOP per call
-SYNC_CALL_FLOP = 866560 * 8.0                    # in-sync DSP per modem frame: 6.93 MFLOP
-DEC_FRAME_FLOP = 3 * 904064 * 2.0                # CoreDecoder, 3 steps per modem frame (runs inside k_rx_sync): 5.42 MFLOP
-ALGO_BYTES_PER_FRAME = 4128
+# ---- executed-work model of k_rx_sync (SURVEY.md 8d figures) --------------------------------------------
+SYNC_CALL_FLOP = 866560 * 8.0                    # in-sync DSP per modem frame (BPF, refine, check_pilots, DFT; 8 flop per cMAC): 6.93 MFLOP
+DEC_MF_FLOP = 3 * 904064 * 2.0                   # CoreDecoder, 3 steps per decoded modem frame (runs inside k_rx_sync): 5.42 MFLOP = 0.452 MFLOP per feature frame
+BPF_CALL_FLOP = 960 * 101 * 8.0                  # the BPF of a search / candidate call (it is inside SYNC_CALL_FLOP for synchronised ones): 0.78 MFLOP
+FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface by FFT convolution: 1 forward + 40 inverse 2048-point FFTs (5 N log2 N) + 40 spectral products: 5.11 MFLOP
+REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation of detect_pilots (two surfaces as GEMMs): 98.3 MFLOP -- NOT executed here
+ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
+RX_ALGO_BYTES_PER_FRAME = 640 + 144              # the receiver kernel's share: IQ in + features out
+PROFILE_TAG = "r02"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
+
+
+def executed_flop(search_calls, sync_calls, decoded_mf):
+    return sync_calls * SYNC_CALL_FLOP + decoded_mf * DEC_MF_FLOP + search_calls * (FFT_SURFACE_FLOP + BPF_CALL_FLOP)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1008, help="10 ms feature frames per utterance (multiple of 12)")
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="3: the headline batch workload; 2: single-stream core encoder/decoder latency")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -47,6 +64,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.config == 2:
+        return config2(args, dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -54,7 +73,7 @@ def main():
 
     from radae_amd.channel_tools import multipath_g, synth_features
     from radae_amd.engine import BatchEngine, DEFAULT_BLOB, sigma_from_EbNodB
-    from radae_amd.parallel import broadcast_blob
+    from radae_amd.parallel import broadcast_blob, gather_stats, shard_range
 
     B, T = args.streams, args.frames
     n_mf = T // 12
@@ -64,9 +83,11 @@ def main():
     blob = broadcast_blob(DEFAULT_BLOB if rank == 0 else None, dev, world)
     eng = BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob)
 
-    # ---- synthetic inputs, resident in HBM before the clock starts
-    u0 = rank * B
-    feats_np = np.stack([synth_features(1000 + u0 + b, T) for b in range(B)])
+    # ---- synthetic inputs, resident in HBM before the clock starts.  Utterance u uses seeds 1000 + u / 5000 + u; rank r owns the
+    # contiguous shard [r B, r B + B) of the B x world utterances
+    u0, u1 = shard_range(B * world, rank, world)
+    assert u1 - u0 == B
+    feats_np = np.stack([synth_features(1000 + u, T) for u in range(u0, u1)])
     feats = torch.tensor(feats_np, device=dev)
     G = torch.empty((B, n_sig, 2), dtype=torch.complex64, device=dev)
     for b in range(B):
@@ -77,7 +98,7 @@ def main():
         eng.reset()
         iq = eng.tx(feats)
         rx = eng.channel(iq, sigma, -11.0, n_pre=n_pre, n_post=n_post, with_eoo=True, G=G, seed=seed)
-        return eng.rx(rx)
+        return eng.rx(rx) + (rx,)
 
     def barrier():
         torch.cuda.synchronize()
@@ -91,17 +112,26 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        fo, st, _ = step(1 + k)
+        fo, st, _, rx_last = step(1 + k)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt = dt_local
+    per_rank_ms = [1e3 * dt_local / args.steps]
     if world > 1:
         import torch.distributed as dist
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        allms = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allms, torch.tensor([1e3 * dt_local / args.steps], dtype=torch.float64, device=dev))
+        per_rank_ms = [float(x.item()) for x in allms]
 
     total_frames = B * T * args.steps * world
     value = total_frames / dt
+    # job-wide statistics of the last step (the only other collective besides the blob broadcast: one small all-reduce)
+    nv = np.array([s.n_valid for s in st]); ncalls = np.array([s.n_calls for s in st]); neoo = np.array([s.has_eoo for s in st])
+    sync_calls = int((nv + neoo).sum()); search_calls = int(ncalls.sum()) - sync_calls
+    job = gather_stats(np.array([B * T, 12.0 * nv.sum(), ncalls.sum(), sync_calls, search_calls, neoo.sum()], dtype=np.float64), dev, world)
 
     out = {
         "metric": "vocoder-feature frames/sec (enc+chan+dec), model19", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -110,86 +140,258 @@ def main():
         "config": {"workload": "model19_check3 streaming radae_txe -> OFDM + MPP multipath/AWGN 3 dB/-11 Hz -> radae_rxe (configs[2])",
                    "streams_per_gpu": B, "frames_per_stream": T, "global_streams": B * world, "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only",
                    "arithmetic": "f32 DSP, f64 refine, matrix products on split-binary16 (2 x 11 bit) MFMA with f32 accumulation"},
+        "value_counts": "offered feature frames: every transmitted frame's samples pass through the receiver, decoded or not",
+        "decoded_frames_per_s": value * job[1] / job[0],
+        "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
+        "job_last_step": {"offered_frames": int(job[0]), "decoded_frames": int(job[1]), "rx_calls": int(job[2]), "sync_calls": int(job[3]),
+                          "search_calls": int(job[4]), "eoo_detected_streams": int(job[5])},
     }
     if rank == 0:
-        # sanity of what was timed: decoded frames and the loss.py-style aligned loss of stream 0
-        from radae_amd.loss import find_loss
-        nv = np.array([s.n_valid for s in st])
         out["decoded_modem_frames_per_stream"] = {"min": int(nv.min()), "mean": float(nv.mean()), "max": int(nv.max())}
-        if nv[0] > 0:
-            l, start = find_loss(feats_np[0], fo[0, :nv[0]].cpu().numpy().reshape(-1, 36))
-            out["loss_stream0"] = {"loss": float(l), "start_frame": int(start)}
 
     if rank == 0 and not args.no_roofline:
-        # ---- roofline leg: per-kernel-class HIP-event timing of the same K steps again (same noise seeds: the receiver
-        # kernel's duration is the slowest stream's and moves by +-5 % with the seed).  Events are recorded on the launch
-        # stream and read back afterwards, so these steps run back to back like the timed ones.
-        eng.profile(True)
-        flops = 0.0
-        for k in range(args.steps):
-            fo, st, _ = step(1 + k)
-            calls = sum(s.n_calls for s in st); sync_calls = sum(s.n_valid + s.has_eoo for s in st)
-            flops += (calls - sync_calls) * SEARCH_CALL_FLOP + sync_calls * SYNC_CALL_FLOP + sum(s.n_valid for s in st) * DEC_FRAME_FLOP
-        torch.cuda.synchronize()
-        eng.profile(False)
-        prof = eng.profile_get()
-        prof["rx_sync"]["flops"] = flops
-        dom = max(prof, key=lambda k: prof[k]["ms"])
-        p = prof[dom]
-        achieved = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
-        # HBM bytes per launch come from the separate rocprofv3 --pmc passes of this same command (profiles/r01_pmc_summary.json)
-        traffic, mfma_busy = None, None
-        try:
-            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))["kernels"][{"rx_sync": "k_rx_sync", "gemm": "void k_gemm16<3, 2>", "gru_scan": "void k_gru_scan<64>"}.get(dom, dom)]
-            traffic = pm["fetch_bytes_per_dispatch"] + pm["write_bytes_per_dispatch"]; mfma_busy = pm["mfma_busy_pct"]
-        except Exception:
-            pass
-        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
-                           "traffic": traffic, "mfma_busy_pct_pmc": mfma_busy, "avg_launch_ms": p["ms"] / max(p["launches"], 1), "launches_per_step": p["launches"] / args.steps,
-                           "note": "algorithmic flops of the reference formulation (98.3 MFLOP per detect_pilots call, 6.93 MFLOP in-sync DSP, 5.42 MFLOP decoder per frame) over the f32 peak 157.3 TFLOP/s; the kernel itself runs the pilot search as FFT convolution and the decoder GEMMs as split-f16 MFMA",
-                           "per_class_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()},
-                           "hbm_frac_whole_job": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9)}
-
+        out["roofline"] = roofline_leg(eng, step, args.steps, B, T, value, world)
+    if rank == 0 and not args.no_parity:
+        out["parity_sample"] = parity_leg(feats_np, fo, st, rx_last, blob, local, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(feats_np, T)
+        out["cpu_baseline_allcores"] = cpu_baseline_allcores(T)
 
     if rank == 0:
         print(json.dumps(out))
     eng.close()
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()                   # rank 0 may still be in its roofline leg: leave the group together
+        dist.barrier()                   # rank 0 may still be in its extra legs: leave the group together
         dist.destroy_process_group()
 
 
-def cpu_baseline(feats_np, T):
-    """The oracle (plain-C restatement, oracle/) timed on one host core over a bounded sample of the same
-    workload.  kind 'port': the reference's own C core cannot be built here (needs xiph/opus)."""
+def roofline_leg(eng, step, steps, B, T, value, world):
+    """Per-kernel-class HIP-event timing of the same K steps again (same noise seeds: the receiver kernel's duration is
+    the slowest stream's and moves by +-5 % with the seed).  Events are recorded on the launch stream and read back
+    afterwards, so these steps run back to back like the timed ones."""
+    steps = min(steps, 25)               # the event pool of the engine is drained every 256 launches; 25 steps is plenty for an average
+    eng.profile(True)
+    search = sync = dec_mf = 0
+    for k in range(steps):
+        _, st, _, _ = step(1 + k)
+        s_sync = sum(s.n_valid + s.has_eoo for s in st)
+        sync += s_sync; search += sum(s.n_calls for s in st) - s_sync; dec_mf += sum(s.n_valid for s in st)
+    torch.cuda.synchronize()
+    eng.profile(False)
+    prof = eng.profile_get()
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    p = prof[dom]
+    launches = max(p["launches"], 1)
+    counts = {"search_calls": search / launches, "sync_calls": sync / launches, "decoded_modem_frames": dec_mf / launches, "offered_frames": B * T}
+    r = {"kernel": dom, "avg_launch_ms": p["ms"] / launches, "launches_per_step": p["launches"] / steps, "steps_profiled": steps,
+         "per_class_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()},
+         "per_class_launches_per_step": {k: v["launches"] / steps for k, v in prof.items()},
+         "hbm_frac_whole_job": value / world * ALGO_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9)}
+    if dom == "rx_sync":
+        fl = executed_flop(counts["search_calls"], counts["sync_calls"], counts["decoded_modem_frames"])
+        achieved = fl / (r["avg_launch_ms"] * 1e-3) / 1e12
+        algo_bytes = RX_ALGO_BYTES_PER_FRAME * B * T
+        r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
+                  "per_launch_counts": counts, "executed_flop_per_launch": fl, "algorithmic_bytes_per_launch": algo_bytes,
+                  "flop_model": {"sync_call": SYNC_CALL_FLOP, "decoded_modem_frame": DEC_MF_FLOP, "search_call": FFT_SURFACE_FLOP + BPF_CALL_FLOP,
+                                 "note": "executed work: in-sync DSP 866,560 cMAC x 8 per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
+                                         "search call = one |Dt| surface by FFT convolution (41 x 5 N log2 N + 40 x 6 N, N = 2048) + BPF; priced at the f32 peak"},
+                  "hbm_frac_kernel": algo_bytes / (r["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                  "equiv_ref_formulation": {"tflops": (counts["sync_calls"] * SYNC_CALL_FLOP + counts["decoded_modem_frames"] * DEC_MF_FLOP + counts["search_calls"] * REF_SEARCH_CALL_FLOP)
+                                            / (r["avg_launch_ms"] * 1e-3) / 1e12,
+                                            "note": "detect_pilots priced as the reference's two 960x40x160 complex GEMMs (98.3 MFLOP per call); work NOT executed in that form -- not a roofline"}})
+    else:
+        achieved = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS})
+    # counters of the same command, collected in separate rocprofv3 --pmc passes (tools/collect_profiles.sh -> profiles/)
+    r["bound"] = "latency (s_waitcnt/s_barrier) + valu-issue"
+    r["traffic"] = None
+    try:
+        pm = json.load(open(os.path.join(REPO, "profiles", f"{PROFILE_TAG}_pmc_summary.json")))
+        k = pm["kernels"][{"rx_sync": "k_rx_sync"}.get(dom, dom)]
+        raw = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
+        r["traffic"] = raw
+        r["traffic_fetch_wide_corrected"] = 2.0 * k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]   # gfx950: FETCH_SIZE halves 16-byte-per-lane loads (upper bound: not every load is that wide)
+        if dom == "rx_sync":
+            r["traffic_ratio"] = raw / (RX_ALGO_BYTES_PER_FRAME * B * T)
+            r["traffic_ratio_wide_corrected"] = r["traffic_fetch_wide_corrected"] / (RX_ALGO_BYTES_PER_FRAME * B * T)
+        r["mfma_busy_pct_pmc"] = k["mfma_busy_pct"]
+        r["counters_from"] = f"profiles/{PROFILE_TAG}_pmc_summary.json (commit {pm.get('commit', '?')})"
+        sq = pm.get("sq_breakdown", {}).get("k_rx_sync")
+        if sq:
+            r["sq_wave_cycle_shares"] = sq
+            r["bound"] = sq.get("bound", r["bound"])
+    except Exception:
+        pass
+    return r
+
+
+def parity_leg(feats_np, fo, st, rx, blob, local, B):
+    """The oracle on the timed workload itself: the received samples of a few streams of the LAST timed step (device Philox noise
+    included) are copied back and run through the CPU oracle; the same samples are replayed through a small traced engine, which
+    must reproduce the timed engine's features bit for bit and the oracle's per-call discrete outputs exactly."""
     from oracle import oracle_py as O
-    from radae_amd.channel_tools import multipath_g
+    from radae_amd.engine import BatchEngine
+    from radae_amd.loss import find_loss
     O.build()
     m = O.Model()
+    idx = sorted({0, B // 3, (2 * B) // 3, B - 1})
+    rx_host = rx[idx].cpu().numpy()
+    e2 = BatchEngine(len(idx), max_tx_mf=1, device=local, blob_bytes=blob, rx_trace_calls=128)
+    fo2, st2, _ = e2.rx(rx[idx].contiguous())
+    torch.cuda.synchronize()
+    keys = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
+    res = {"streams": idx, "discrete_equal": True, "timed_equals_replay_bitwise": True, "feat_rms_max": 0.0, "loss_gpu": [], "loss_oracle": [], "loss_delta_max": 0.0,
+           "refine_near_ties": 0, "calls_compared": 0, "decoded_modem_frames": []}
+    for j, b in enumerate(idx):
+        d = O.run_rx_stream(m, rx_host[j])
+        t = e2.rx_trace(j)
+        nvb = st[b].n_valid
+        f_timed = fo[b, :nvb].cpu().numpy(); f_rep = fo2[j, :st2[j].n_valid].cpu().numpy()
+        if st2[j].n_valid != nvb or not np.array_equal(f_timed, f_rep):
+            res["timed_equals_replay_bitwise"] = False
+        ok = all(np.array_equal(t[k], d[k]) for k in keys) and nvb == len(d["features_out"])
+        res["calls_compared"] += int(len(d["ret"]))
+        res["decoded_modem_frames"].append(int(nvb))
+        if not ok:
+            res["discrete_equal"] = False
+            continue
+        dfm = float(np.abs(t["fmax"] - d["fmax"]).max()) if len(d["fmax"]) else 0.0
+        if 1e-9 < dfm < 0.0501:
+            res["refine_near_ties"] += 1          # a 0.1 Hz refine() bin pair equal to within rounding, resolved the other way (DESIGN.md 4)
+        if nvb:
+            res["feat_rms_max"] = max(res["feat_rms_max"], float(np.sqrt(np.mean((f_timed - d["features_out"]) ** 2))))
+            lg, _ = find_loss(feats_np[b], f_timed.reshape(-1, 36)); lo, _ = find_loss(feats_np[b], d["features_out"].reshape(-1, 36))
+            res["loss_gpu"].append(float(lg)); res["loss_oracle"].append(float(lo)); res["loss_delta_max"] = max(res["loss_delta_max"], abs(float(lg) - float(lo)))
+    e2.close()
+    return res
+
+
+def _oracle_inputs(feats_np, T, n, seed0=11):
+    """Fixture generation for the CPU legs -- OUTSIDE their timed regions (the GPU's timed region has G resident too)."""
+    from radae_amd.channel_tools import multipath_g
+    rng = np.random.default_rng(seed0)
+    n_sig = (T // 12) * NMF
+    items = []
+    for u in range(n):
+        G = multipath_g("mpp", 8000, n_sig, 5000 + u)
+        nz = ((rng.standard_normal(n_sig + 1152) + 1j * rng.standard_normal(n_sig + 1152)) / np.sqrt(2)).astype(np.complex64)
+        items.append((feats_np[u % len(feats_np)], G, nz, rng.standard_normal(8000).astype(np.float32), rng.standard_normal(1152).astype(np.float32)))
+    return items
+
+
+def _oracle_utterance(O, m, sigma, item, T):
+    f, G, nz, pre, post = item
     n_mf = T // 12
+    tx = O.Tx(m)
+    sig = np.concatenate([tx.frame(f[12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+    n = len(sig)
+    r, fin = O.channel(sig, G, nz[:n], sigma, -11.0)
+    e = O.channel_eoo(tx.eoo(), nz[n:], sigma, -11.0, 0.0, fin)
+    full = np.concatenate([sigma * pre, r, e, sigma * post]).astype(np.complex64)
+    O.run_rx_stream(m, full)
+
+
+def cpu_baseline(feats_np, T, budget_s=12.0, n_max=48):
+    """The oracle (plain-C restatement, oracle/) timed on one host core over a bounded sample of the same workload;
+    inputs (features, Doppler samples, noise) are generated before the clock starts.
+    kind 'port': the reference's own C core cannot be built here (needs xiph/opus)."""
+    from oracle import oracle_py as O
+    O.build()
+    m = O.Model()
     sigma = float(O.lib().orc_sigma_from_EbNodB(3.0))
-    rng = np.random.default_rng(11)
+    items = _oracle_inputs(feats_np, T, n_max)
     done, t0 = 0, time.perf_counter()
-    while True:
-        u = done
-        tx = O.Tx(m)
-        sig = np.concatenate([tx.frame(feats_np[u % len(feats_np), 12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
-        G = multipath_g("mpp", 8000, len(sig), 5000 + u)
-        n = len(sig)
-        nz = ((rng.standard_normal(n + 1152) + 1j * rng.standard_normal(n + 1152)) / np.sqrt(2)).astype(np.complex64)
-        r, fin = O.channel(sig, G, nz[:n], sigma, -11.0)
-        e = O.channel_eoo(tx.eoo(), nz[n:], sigma, -11.0, 0.0, fin)
-        full = np.concatenate([sigma * rng.standard_normal(8000), r, e, sigma * rng.standard_normal(1152)]).astype(np.complex64)
-        O.run_rx_stream(m, full)
+    for it in items:
+        _oracle_utterance(O, m, sigma, it, T)
         done += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or done >= 64:
+        if el > budget_s:
             break
+    el = time.perf_counter() - t0
     return {"value": done * T / el, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{done} utterance(s) x {T} frames through oracle enc+mod+MPP channel+rx+dec in {el:.1f} s, 1 thread"}
+            "sample": f"{done} utterance(s) x {T} frames through oracle enc+mod+MPP channel+rx+dec in {el:.1f} s, 1 thread, inputs pre-generated"}
+
+
+def _allcores_worker(args):
+    rank, n_utt, T = args
+    for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[v] = "1"
+    sys.path.insert(0, REPO)
+    from oracle import oracle_py as O
+    from radae_amd.channel_tools import synth_features
+    m = O.Model()
+    sigma = float(O.lib().orc_sigma_from_EbNodB(3.0))
+    feats = np.stack([synth_features(1000 + rank * 8 + u, T) for u in range(n_utt)])
+    items = _oracle_inputs(feats, T, n_utt, seed0=100 + rank)
+    t0 = time.perf_counter()
+    for it in items:
+        _oracle_utterance(O, m, sigma, it, T)
+    return t0, time.perf_counter()
+
+
+def cpu_baseline_allcores(T, n_utt=6):
+    """The same oracle, one utterance stream per process, on the host's cores (SURVEY.md 8d plan (ii)).  Context only."""
+    import multiprocessing as mp
+    ncpu = len(os.sched_getaffinity(0))
+    best = None
+    for procs in sorted({min(16, ncpu), min(64, ncpu)}):
+        with mp.get_context("spawn").Pool(procs) as pool:
+            spans = pool.map(_allcores_worker, [(r, n_utt, T) for r in range(procs)])
+        el = max(s[1] for s in spans) - min(s[0] for s in spans)      # first start to last finish of the oracle loops (process start-up excluded)
+        rate = procs * n_utt * T / el
+        if best is None or rate > best["value"]:
+            best = {"value": rate, "unit": "frames/s", "cores": procs, "kind": "port",
+                    "sample": f"{procs} processes x {n_utt} utterances x {T} frames in {el:.1f} s ({ncpu} logical CPUs visible)"}
+    return best
+
+
+def config2(args, dev):
+    """BASELINE.json configs[1]: one stream through the rade_core.h-level encoder and decoder (include/rade_core.h:
+    rade_core_encoder / rade_core_decoder, one 40 ms step per call, host buffers, PCIe copies included), with the oracle on one
+    host core beside it.  Latency-bound by construction: one stream occupies one workgroup chain."""
+    import ctypes as C
+    from radae_amd import core
+    from radae_amd.channel_tools import synth_features
+    from radae_amd.engine import DEFAULT_BLOB
+    T = args.frames
+    n_steps = T // 4
+    f = synth_features(1000, T)
+    rows = np.concatenate([f[:, :20], -np.ones((T, 1), np.float32)], axis=1).reshape(n_steps, 84).astype(np.float32)
+    enc = core.CoreEncoder(DEFAULT_BLOB); dec = core.CoreDecoder(DEFAULT_BLOB)
+    z = np.zeros((n_steps, 80), np.float32); fh = np.zeros((n_steps, 84), np.float32)
+    for i in range(min(32, n_steps)):      # warm-up
+        enc.step(rows[i])
+    enc.reset()
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        z[i] = enc.step(rows[i])
+    t1 = time.perf_counter()
+    for i in range(n_steps):
+        fh[i] = dec.step(z[i])
+    t2 = time.perf_counter()
+    from oracle import oracle_py as O
+    O.build()
+    m = O.Model(); oe = O.Encoder(m); od = O.Decoder(m)
+    zo = np.zeros_like(z); fo = np.zeros_like(fh)
+    c0 = time.perf_counter()
+    for i in range(n_steps):
+        zo[i] = oe.step(rows[i])
+    c1 = time.perf_counter()
+    for i in range(n_steps):
+        fo[i] = od.step(zo[i])
+    c2 = time.perf_counter()
+    out = {"metric": "vocoder-feature frames/sec (core enc + dec, single stream), model19_check3", "value": T / (t2 - t0), "unit": "frames/s", "n_gpus": 1,
+           "steps": n_steps, "warmup": min(32, n_steps), "ms_per_step": 1e3 * (t2 - t0) / n_steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "model19_check3 rade_core_encoder + rade_core_decoder, single stream, one 40 ms step per call (configs[1])", "frames": T},
+           "latency_ms": {"encoder_call": 1e3 * (t1 - t0) / n_steps, "decoder_call": 1e3 * (t2 - t1) / n_steps},
+           "parity": {"z_rms": float(np.sqrt(np.mean((z - zo) ** 2))), "features_rms": float(np.sqrt(np.mean((fh - fo) ** 2)))},
+           "cpu_baseline": {"value": T / (c2 - c0), "unit": "frames/s", "cores": 1, "kind": "port",
+                            "sample": f"{n_steps} encoder + decoder steps of the oracle, 1 thread ({1e3 * (c1 - c0) / n_steps:.3f} + {1e3 * (c2 - c1) / n_steps:.3f} ms per step)"}}
+    enc.close(); dec.close()
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

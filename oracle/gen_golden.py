@@ -242,10 +242,11 @@ def channel_case(name, T, EbNodB, freq_offset, chan, seed, prepend_s=1.0, append
     return d
 
 
-def run_rx(rx_stream, foff_err=0.0):
+def run_rx(rx_stream, foff_err=0.0, disable_unsync=0.0):
     """Drive the reference radae_rx exactly like radae_rxe.py:349-356 and record a per-call trace."""
     rx = new_rx()
     rx.foff_err = foff_err
+    rx.disable_unsync = disable_unsync          # radae_rxe.py:65, :277-281
     zlog = []
     orig = rx.receiver.receiver_one
     def hook(r, eoo, _o=orig):
@@ -315,6 +316,32 @@ def gen_chan_rx():
     tr = run_rx(d["rx_full"], foff_err=10.0)
     np.savez_compressed(os.path.join(OUT, "rxtrace_foff.npz"), rx_in=d["rx_full"], features_in=d["features"], **tr)
     print(f"rx foff: states {tr['state_after'].tolist()} uw {tr['uw_errors'].tolist()}")
+
+
+def gen_knobs():
+    """The test-mode knobs the reference's ctests use and the first fixture set left at their defaults:
+    df_dt (frequency drift, radae.py:547-552 + inference.py:270; ctest radae_rx_dfdt, CMakeLists.txt:363-371) and
+    --disable_unsync (radae_rxe.py:277-281; ctests radae_rx_mpp / radae_rx_mpg, CMakeLists.txt:326-347)."""
+    keep = ("features", "noise", "sigma", "EbNodB", "freq_offset", "df_dt", "tx", "rx", "noise_eoo", "noise_pre", "noise_post", "rx_full", "final_phase")
+    for name, dfdt in (("dfdt_pos", 0.5), ("dfdt_neg", -0.5)):
+        d = channel_case(name, 120, 10.0, 13.0, "awgn", 1010, prepend_s=0.5, append_s=0.2, df_dt=dfdt)
+        np.savez_compressed(os.path.join(OUT, f"chan_{name}.npz"), **{k: d[k] for k in keep})
+        print(f"chan {name}: final phase {d['final_phase']}")
+    # receiver trace through a drifting offset, the ctest's recipe at reduced length (Eb/No 1 dB, +13 Hz, 0.1 Hz/s)
+    d = channel_case("dfdt", 240, 1.0, 13.0, "awgn", 1011, prepend_s=1.0, append_s=0.3, df_dt=0.1)
+    tr = run_rx(d["rx_full"])
+    np.savez_compressed(os.path.join(OUT, "rxtrace_dfdt.npz"), rx_in=d["rx_full"], features_in=d["features"], **tr)
+    print(f"rx dfdt: calls {len(tr['ret'])} valid {int((tr['ret'] & 1).sum())} fmax {tr['fmax'][[10, -3]]}")
+    # --disable_unsync: MPP at 0 dB with a deep fade, unsync paths switched off after 1 s of sync (41 frames at the ctest's 5 s
+    # would outlast a short fixture); the same samples without the flag lose sync, so the pair pins both branches
+    d = channel_case("nounsync", 360, 0.0, -11.0, "mpp", 1012, prepend_s=0.5, append_s=0.3)
+    x = d["rx_full"].copy()
+    n0 = int(0.5 * 8000) + 150 * 80                     # 1.5 s into the signal: 2.6 s of noise only (valid_count runs out after 25 frames)
+    x[n0:n0 + 26 * 960] = d["sigma"] * d["noise"][:26 * 960]
+    tr_on = run_rx(x, disable_unsync=1.0); tr_off = run_rx(x)
+    assert not np.array_equal(tr_on["state_after"], tr_off["state_after"]), "fixture does not exercise the flag"
+    np.savez_compressed(os.path.join(OUT, "rxtrace_nounsync.npz"), rx_in=c64(x), features_in=d["features"], disable_unsync=np.float64(1.0), **tr_on)
+    print(f"rx nounsync: states with flag {tr_on['state_after'].tolist()}\n            without {tr_off['state_after'].tolist()}")
 
 
 def gen_dec_loss():
@@ -438,8 +465,9 @@ def gen_wire():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec", "model05", "bbfm", "wire"]
+    which = sys.argv[1:] or ["consts", "weights", "enc", "chanrx", "dec", "model05", "bbfm", "wire", "knobs"]
     if "wire" in which: gen_wire()
+    if "knobs" in which: gen_knobs()
     if "consts" in which: gen_consts()
     if "weights" in which: gen_weights_check()
     if "enc" in which: gen_enc_tx()

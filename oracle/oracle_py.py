@@ -67,6 +67,7 @@ def lib():
         L.orc_rx_new.restype = vp; L.orc_rx_new.argtypes = [vp]
         L.orc_rx_set_lcg.argtypes = [vp, C.c_uint]
         L.orc_rx_set_foff_err.argtypes = [vp, C.c_double]
+        L.orc_rx_set_disable_unsync.argtypes = [vp, C.c_double]
         for n in ("orc_rx_nin", "orc_rx_sync", "orc_rx_snr"):
             getattr(L, n).argtypes = [vp]
         L.orc_rx_frame.argtypes = [vp, vp, vp, vp, vp]
@@ -191,9 +192,9 @@ class Bpf:
 
 
 class Rx:
-    def __init__(self, model, lcg_seed=1, foff_err=0.0):
+    def __init__(self, model, lcg_seed=1, foff_err=0.0, disable_unsync=0.0):
         self.m = model; self.h = lib().orc_rx_new(model.h)
-        lib().orc_rx_set_lcg(self.h, lcg_seed); lib().orc_rx_set_foff_err(self.h, foff_err)
+        lib().orc_rx_set_lcg(self.h, lcg_seed); lib().orc_rx_set_foff_err(self.h, foff_err); lib().orc_rx_set_disable_unsync(self.h, disable_unsync)
 
     def nin(self):
         return lib().orc_rx_nin(self.h)
@@ -213,10 +214,10 @@ class Rx:
         t = Trace(); lib().orc_rx_get_trace(self.h, C.byref(t)); return t
 
 
-def run_rx_stream(model, stream, lcg_seed=1, foff_err=0.0):
+def run_rx_stream(model, stream, lcg_seed=1, foff_err=0.0, disable_unsync=0.0):
     """Drive the oracle receiver like radae_rxe.py:349-356; returns the same trace dict layout as
     oracle/gen_golden.py:run_rx."""
-    rx = Rx(model, lcg_seed, foff_err)
+    rx = Rx(model, lcg_seed, foff_err, disable_unsync)
     keys_i = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
     keys_f = ["fmax", "Dthresh", "Dtmax12", "Dtmax12_eoo", "snrdB_3k_est"]
     tr = {k: [] for k in keys_i + keys_f}

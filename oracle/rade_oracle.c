@@ -787,6 +787,7 @@ struct orc_rx {
     orc_c32 rx_buf[ORC_RXBUF];
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf;
     double fmax, foff_err; c64d rx_phase; float snrdB_3k_est;
+    double disable_unsync;                  /* radae_rxe.py:277-281: seconds of sync after which unsync paths are switched off (0 = normal) */
 };
 
 orc_rx *orc_rx_new(const orc_model *m)
@@ -800,6 +801,7 @@ orc_rx *orc_rx_new(const orc_model *m)
 void orc_rx_free(orc_rx *r) { free(r); }
 void orc_rx_set_lcg(orc_rx *r, unsigned seed) { r->acq.lcg = seed; }
 void orc_rx_set_foff_err(orc_rx *r, double hz) { r->foff_err = hz; }
+void orc_rx_set_disable_unsync(orc_rx *r, double seconds) { r->disable_unsync = seconds; }
 int orc_rx_nin(const orc_rx *r) { return r->nin; }
 int orc_rx_sync(const orc_rx *r) { return r->state == ST_SYNC; }
 int orc_rx_snr(const orc_rx *r) { return (int)r->snrdB_3k_est; }
@@ -864,9 +866,11 @@ int orc_rx_frame(orc_rx *r, float features_out[432], float eoo_out[180], const o
             }
         } else next_state = ST_SEARCH;
     } else {
+        int unsync_enable = 1;                                                         /* :277-281 (test mode --disable_unsync) */
+        if (r->disable_unsync != 0.0 && r->synced_count > (int)(r->disable_unsync * 8000.0 / ORC_NMF)) unsync_enable = 0;
         if (candidate) r->valid_count = Nmf_unsync;
-        else { r->valid_count--; if (r->valid_count == 0) next_state = ST_SEARCH; }
-        if (endofover || uw_fail) next_state = ST_SEARCH;
+        else { r->valid_count--; if (unsync_enable && r->valid_count == 0) next_state = ST_SEARCH; }
+        if (unsync_enable && (endofover || uw_fail)) next_state = ST_SEARCH;
     }
     r->state = next_state;
     if (r->state == ST_SEARCH) r->nin = Nmf;

@@ -82,6 +82,7 @@ orc_rx *orc_rx_new(const orc_model *m);
 void orc_rx_free(orc_rx *r);
 void orc_rx_set_lcg(orc_rx *r, unsigned seed);      /* row-refresh generator, see gen_golden.py */
 void orc_rx_set_foff_err(orc_rx *r, double hz);     /* RADE_FOFF_TEST (rade_api.c:263-264) */
+void orc_rx_set_disable_unsync(orc_rx *r, double seconds);   /* radae_rxe.py --disable_unsync (:277-281, :337) */
 int orc_rx_nin(const orc_rx *r);
 int orc_rx_sync(const orc_rx *r);
 int orc_rx_snr(const orc_rx *r);

@@ -21,12 +21,13 @@
 #include "rade_api.h"
 #include "rade_batch.h"
 #include "rade_dev.h"
+#include "rade_host.h"
 
 #define RADE_API_VERSION 1      /* rade_api.c:37 */
 
 struct rade {
     rade_batch *eng;
-    int flags, nin, sync, snr;
+    int flags, nin, sync, snr, device;
     float *d_feat_in, *d_feat_out, *d_eoo; void *d_iq, *d_rx;
     pthread_mutex_t lock;
     /* rade_tx is ~20 short launches for one stream (launch-bound): after the first call the sequence
@@ -47,7 +48,7 @@ static int is_blob(const char *path)
     return ok;
 }
 
-static const char *find_model(const char *hint, char *buf, size_t n)
+const char *rd_find_default_model(const char *hint, char *buf, size_t n)
 {
     if (is_blob(hint)) return hint;
     const char *env = getenv("RADE_MODEL_FILE");
@@ -66,7 +67,7 @@ static const char *find_model(const char *hint, char *buf, size_t n)
 struct rade *rade_open(char model_file[], int flags)
 {
     char buf[4096];
-    const char *path = find_model(model_file, buf, sizeof buf);
+    const char *path = rd_find_default_model(model_file, buf, sizeof buf);
     if (!path) { fprintf(stderr, "rade_open: no DNNw weight blob found (tried \"%s\", $RADE_MODEL_FILE, weights/model19_check3.bin)\n", model_file ? model_file : ""); return NULL; }
     struct rade *r = calloc(1, sizeof *r);
     rade_batch_config cfg = { 1, 1, 0, flags, 0 };
@@ -74,7 +75,7 @@ struct rade *rade_open(char model_file[], int flags)
     if (dev) cfg.device = atoi(dev);
     r->eng = rade_batch_open(path, &cfg);
     if (!r->eng) { free(r); return NULL; }
-    r->flags = flags; r->nin = RD_NMF;
+    r->flags = flags; r->nin = RD_NMF; r->device = cfg.device;
     if (hipMalloc((void **)&r->d_feat_in, sizeof(float) * RD_FEAT_MF) || hipMalloc((void **)&r->d_feat_out, sizeof(float) * RD_FEAT_MF) ||
         hipMalloc((void **)&r->d_eoo, sizeof(float) * RD_NEOOBITS) || hipMalloc(&r->d_iq, sizeof(RADE_COMP) * RD_NEOO) ||
         hipMalloc(&r->d_rx, sizeof(RADE_COMP) * RD_NINMAX)) { rade_close(r); return NULL; }
@@ -111,6 +112,7 @@ void rade_tx_set_eoo_bits(struct rade *r, float eoo_bits[])
 {
     assert(r != NULL); assert(eoo_bits != NULL);
     pthread_mutex_lock(&r->lock);
+    (void)hipSetDevice(r->device);          /* any thread may call; the staging copies below must target the engine's device */
     rade_batch_tx_set_eoo_bits(r->eng, eoo_bits);
     pthread_mutex_unlock(&r->lock);
 }
@@ -120,6 +122,7 @@ int rade_tx(struct rade *r, RADE_COMP tx_out[], float features_in[])
     assert(r != NULL); assert(features_in != NULL); assert(tx_out != NULL);
     int ret = 0;
     pthread_mutex_lock(&r->lock);
+    (void)hipSetDevice(r->device);          /* any thread may call; the staging copies below must target the engine's device */
     if (r->tx_calls > 0 && !r->tx_graph_off && r->gs && r->h_feat && r->h_iq) {
         if (!r->tx_graph) {                                   /* second call: record the sequence (nothing runs during capture) */
             hipGraph_t g = NULL;
@@ -155,6 +158,7 @@ int rade_tx_eoo(struct rade *r, RADE_COMP tx_eoo_out[])
     assert(r != NULL); assert(tx_eoo_out != NULL);
     int ret = 0;
     pthread_mutex_lock(&r->lock);
+    (void)hipSetDevice(r->device);          /* any thread may call; the staging copies below must target the engine's device */
     if (rade_batch_tx_eoo(r->eng, r->d_iq, RD_NEOO, NULL) == RD_NEOO &&
         hipMemcpy(tx_eoo_out, r->d_iq, sizeof(RADE_COMP) * RD_NEOO, hipMemcpyDeviceToHost) == hipSuccess) ret = RD_NEOO;
     pthread_mutex_unlock(&r->lock);
@@ -167,6 +171,7 @@ int rade_rx(struct rade *r, float features_out[], int *has_eoo_out, float eoo_ou
     assert(r != NULL); assert(features_out != NULL); assert(rx_in != NULL);
     rade_rx_status st; int ok = 0;
     pthread_mutex_lock(&r->lock);
+    (void)hipSetDevice(r->device);          /* any thread may call; the staging copies below must target the engine's device */
     const int nin = r->nin;
     if (hipMemcpy(r->d_rx, rx_in, sizeof(RADE_COMP) * nin, hipMemcpyHostToDevice) == hipSuccess &&
         rade_batch_rx(r->eng, r->d_rx, RD_NINMAX, &nin, 1, r->d_feat_out, RD_FEAT_MF, r->d_eoo, &st, NULL) == 0) {

@@ -61,6 +61,7 @@ typedef struct {
     double fmax, foff_err, rx_phase[2];
     double Dthresh, Dtmax12, Dtmax12_eoo;
     float snr_est, bpf_phase[2], pad2;
+    unsigned rxmax[4];                  /* float bits: largest |re|,|im| of the filtered samples of the last three calls (check_pilots operand scale) */
     long long consumed;                 /* samples consumed since reset */
     float bpf_mem[102][2];
     float rx_buf[RD_RXBUF][2];
@@ -169,6 +170,7 @@ typedef struct {
     int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
     rd_decs_args dec;                                    /* the decoder runs inside the stream's workgroup (rx_decode_pending) */
     float *features_out; long feat_stride;               /* [B][cap][432] */
+    int feat_cap;                                        /* valid modem frames features_out holds per stream: a stream stops making calls once it has produced that many */
     const unsigned short *corr16;                        /* rd_corr16_table_fill(): [5][10][2][64][8] binary16 */
     const float *fftG, *ffttw;                           /* rd_fft_tables_fill(): [RD_NFC][2048][2], [2048 + 64][2] */
     float *zrows;                                        /* [B][dec_rows][80] */

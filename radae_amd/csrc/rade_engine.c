@@ -25,6 +25,10 @@
 
 typedef struct { float *wp, *bias; unsigned short *wp16; int N, K; } dev_lin;
 
+/* every public entry point runs on its engine's device, whatever device the calling thread had current (one host thread may
+ * drive several engines, and an engine may be called from a thread other than the one that opened it) */
+#define ON_DEV(h) do { if (h) (void)hipSetDevice((h)->device); } while (0)
+
 #define RADE_PROF_MAXEV 256   /* launches recorded per profiled interval before the events are drained */
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
@@ -90,7 +94,10 @@ static int upload_lin(dev_lin *d, const float *w, const float *b, int N, int K, 
     if (Kpad % 16 == 0) {                  /* two-plane f16 copy for the receiver's in-kernel decoder (f16 matrix cores) */
         const long n16 = rd_packed16_size(N, Kpad);
         unsigned short *p16 = malloc(sizeof(unsigned short) * n16);
-        rd_pack_weights_f16x2(wsrc, N, Kpad, p16);
+        if (!p16 || rd_pack_weights_f16x2(wsrc, N, Kpad, p16) < 0) {
+            fprintf(stderr, "rade: a weight exceeds the range of the split-binary16 operand planes (|w| < 63.9)\n");
+            free(p16); free(packed); free(tmp); return -1;
+        }
         d->wp16 = dev_upload(p16, sizeof(unsigned short) * n16);
         free(p16);
     }
@@ -113,19 +120,20 @@ static void tx_reset_on(rade_batch *h, void *stream)
     hipMemsetAsync(h->enc_x, 0, sizeof(float) * (size_t)h->B * (2 + h->Tcap) * RD_ENC_W, st);
 }
 
-void rade_batch_rx_reset(rade_batch *h) { rx_reset_on(h, NULL); hipDeviceSynchronize(); }
+void rade_batch_rx_reset(rade_batch *h) { ON_DEV(h); rx_reset_on(h, NULL); hipDeviceSynchronize(); }
 
 /* stream-ordered reset of both directions (start of a new batch of utterances) */
-void rade_batch_reset(rade_batch *h, void *stream) { tx_reset_on(h, stream); rx_reset_on(h, stream); }
+void rade_batch_reset(rade_batch *h, void *stream) { ON_DEV(h); tx_reset_on(h, stream); rx_reset_on(h, stream); }
 
 void rade_batch_rx_set_lcg(rade_batch *h, const unsigned *seeds_host)
 {
+    ON_DEV(h);
     for (int b = 0; b < h->B; b++) h->lcg_seeds[b] = seeds_host ? seeds_host[b] : 1u;
     hipMemcpy(h->d_lcg_seeds, h->lcg_seeds, sizeof(unsigned) * h->B, hipMemcpyHostToDevice);
     rade_batch_rx_reset(h);
 }
 
-void rade_batch_tx_reset(rade_batch *h) { tx_reset_on(h, NULL); hipDeviceSynchronize(); }
+void rade_batch_tx_reset(rade_batch *h) { ON_DEV(h); tx_reset_on(h, NULL); hipDeviceSynchronize(); }
 
 rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_batch_config *cfg)
 {
@@ -255,6 +263,7 @@ static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFr
 void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
+    ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
                      h->rx_progress, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
@@ -291,12 +300,14 @@ static void prof_drain(rade_batch *h)
 
 void rade_batch_profile(rade_batch *h, int enable)
 {
+    ON_DEV(h);
     if (!enable && h->prof_on) prof_drain(h);
     h->prof_on = enable;
     if (enable) { h->prof_cnt = 0; memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_flops, 0, sizeof h->prof_flops); memset(h->prof_n, 0, sizeof h->prof_n); }
 }
 int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches)
 {
+    ON_DEV(h);
     if (cls < 0 || cls >= RADE_PROF_NCLASS) return -1;
     prof_drain(h);
     *ms = h->prof_ms[cls]; *work = h->prof_flops[cls]; *launches = h->prof_n[cls];
@@ -325,7 +336,10 @@ static int encode_core(rade_batch *h, int T, float *z, void *stream)
     const long xsb = (long)(2 + h->Tcap) * W;
     float *x = h->enc_x + 2 * W;               /* time row 0 of each stream; rows -2,-1 hold the conv history */
     int e = 0;
-    e |= gemm(h, &h->enc_dense1, h->enc_xin, (long)T * h->enc_kpad, h->enc_kpad, h->enc_kpad, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
+    /* dense1 reads raw features: the one encoder operand that is not tanh-bounded, so it stays on the f32 matrix cores
+     * (the 2^8-scaled binary16 planes of the split-f16 kernels overflow beyond +-255.9) */
+    dev_lin d1 = h->enc_dense1; d1.wp16 = NULL;
+    e |= gemm(h, &d1, h->enc_xin, (long)T * h->enc_kpad, h->enc_kpad, h->enc_kpad, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = ENC_IN[l];
         e |= gemm(h, &h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, h->enc_gi, (long)T * 192, 192, B, T, 0, stream);
@@ -343,6 +357,7 @@ static int encode_core(rade_batch *h, int T, float *z, void *stream)
 /* ---- transmit (radae_txe.py:108-135 for n_mf modem frames and B streams at once) -------------- */
 int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, float *z_out_dev, void *stream)
 {
+    ON_DEV(h);
     if (!h || n_mf <= 0 || n_mf > h->max_tx_mf || h->feat_in != 84) return -1;
     const int B = h->B, T = 3 * n_mf;
     float *z = z_out_dev ? z_out_dev : h->enc_z;
@@ -356,6 +371,7 @@ int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_o
 /* ---- core encoder / decoder alone (the rade_core_encoder / rade_core_decoder level, src/rade_core.h:42-46) ---- */
 int rade_batch_encode(rade_batch *h, const float *features_dev, int n_steps, float *z_out_dev, void *stream)
 {
+    ON_DEV(h);
     if (!h || n_steps <= 0 || n_steps > h->Tcap || !z_out_dev) return -1;
     int e = rd_launch_pad_rows(features_dev, h->enc_xin, (long)h->B * n_steps, h->feat_in, h->enc_kpad, stream);
     e |= encode_core(h, n_steps, z_out_dev, stream);
@@ -364,6 +380,7 @@ int rade_batch_encode(rade_batch *h, const float *features_dev, int n_steps, flo
 
 int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host)
 {
+    ON_DEV(h);
     if (bits_host && hipMemcpy(h->eoo_bits, bits_host, sizeof(float) * h->B * RD_NEOOBITS, hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (rd_launch_eoo_build(h->d_tab, bits_host ? h->eoo_bits : NULL, h->eoo, h->B, NULL)) return -1;
     return hipDeviceSynchronize() == hipSuccess ? 0 : -1;
@@ -371,6 +388,7 @@ int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host)
 
 int rade_batch_tx_eoo(rade_batch *h, void *iq_out_dev, long iq_stride, void *stream)
 {
+    ON_DEV(h);
     return rd_launch_copy_eoo(h->eoo, iq_out_dev, iq_stride, h->B, stream) ? -1 : RD_NEOO;
 }
 
@@ -383,6 +401,7 @@ float rade_sigma_from_EbNodB(float EbNodB)
 
 int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *rx_out_dev, long rx_stride, const rade_channel_params *p, void *stream)
 {
+    ON_DEV(h);
     rd_chan_args a;
     memset(&a, 0, sizeof a);
     a.tab = h->d_tab; a.tx = tx_dev; a.tx_stride = tx_stride; a.rx = rx_out_dev; a.rx_stride = rx_stride; a.G = p->G_dev; a.noise = p->noise_dev;
@@ -398,6 +417,7 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
 int rade_batch_multipath_gen(rade_batch *h, const float *fir_taps_host, int n_taps, int low_ratio, int n_out,
                              const void *noise_low_dev, unsigned long long seed, void *G_out_dev, void *stream)
 {
+    ON_DEV(h);
     if (!h || !fir_taps_host || n_taps <= 0 || n_taps > 1024 || !G_out_dev) return -1;
     float *taps = dev_upload(fir_taps_host, sizeof(float) * n_taps);
     if (!taps) return -1;
@@ -417,7 +437,8 @@ static int decoder_layers(rade_batch *h, const float *z, int T, int Tio, int Tca
     const long xsb = (long)(1 + Tcap) * W;
     float *x = xbuf + W;
     int e = 0;
-    e |= gemm(h, &h->dec_dense1, z, (long)Tio * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
+    dev_lin d1 = h->dec_dense1; d1.wp16 = NULL;       /* z_hat is unbounded: f32 matrix cores (see encode_core) */
+    e |= gemm(h, &d1, z, (long)Tio * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = DEC_IN[l];
         e |= gemm(h, &h->dec_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, nr, gi, (long)T * 288, 288, B, T, 0, stream);
@@ -448,6 +469,7 @@ static void fill_dec_args(const rade_batch *h, rd_decs_args *d)
 
 int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *features_out_dev, int reset_state, void *stream)
 {
+    ON_DEV(h);
     if (!h || n_steps <= 0 || n_steps > h->Tcap || !features_out_dev) return -1;
     hipStream_t st = (hipStream_t)stream;
     if (reset_state) {
@@ -462,6 +484,7 @@ int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *fea
 int rade_batch_channel_symbol(rade_batch *h, const float *z_dev, const float *H_dev, const float *noise_dev, float *z_hat_dev, int n_steps,
                               int mode, float p0, float p1, unsigned long long seed, void *stream)
 {
+    ON_DEV(h);
     if (!h || n_steps <= 0 || (mode != 0 && mode != 1)) return -1;
     return rd_launch_chan_symbol(z_dev, H_dev, noise_dev, z_hat_dev, (long)h->B * n_steps * RD_LATENT, mode, p0, p1, seed, stream) ? -1 : n_steps;
 }
@@ -469,7 +492,8 @@ int rade_batch_channel_symbol(rade_batch *h, const float *z_dev, const float *H_
 int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *n_avail_host, int max_calls,
                   float *features_out_dev, long feat_stride, float *eoo_out_dev, rade_rx_status *status_host, void *stream)
 {
-    if (!h || !n_avail_host || max_calls <= 0 || h->feat_in != 84) return -1;
+    ON_DEV(h);
+    if (!h || !n_avail_host || max_calls <= 0 || h->feat_in != 84 || !features_out_dev || feat_stride < RD_FEAT_MF) return -1;
     const int B = h->B;
     hipStream_t st = (hipStream_t)stream;
     int *hs = h->h_small;
@@ -482,6 +506,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
+    sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only
      * continues when a stream ran into the per-launch call limit */
     for (;;) {
@@ -513,6 +538,7 @@ fail:
 
 int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls)
 {
+    ON_DEV(h);
     if (!h->trace || b < 0 || b >= h->B) return -1;
     rd_rx_stream *tmp = malloc(sizeof *tmp);
     hipMemcpy(tmp, h->rx_st + b, sizeof *tmp, hipMemcpyDeviceToHost);

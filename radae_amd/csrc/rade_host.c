@@ -119,12 +119,25 @@ static const dnnw_rec *rec_find(const dnnw_rec *r, int n, const char *base, cons
     return NULL;
 }
 
+/* Every record is validated before anything is written: sizes against the shapes they imply, index walks against their
+ * array, allocations against NULL.  The blob path comes from rade_open()'s argument or $RADE_MODEL_FILE, i.e. it is
+ * untrusted input. */
+static int lin_alloc(rd_linear *l)
+{
+    if (l->n_in <= 0 || l->n_out <= 0 || l->n_in > 65536 || l->n_out > 65536) return -1;
+    l->b = malloc(sizeof(float) * (size_t)l->n_out); l->w = calloc((size_t)l->n_in * l->n_out, sizeof(float));
+    if (!l->b || !l->w) { free(l->b); free(l->w); l->b = l->w = NULL; return -1; }
+    return 0;
+}
+
 static int dequant_dense_float(const dnnw_rec *R, int n, const char *name, rd_linear *l)
 {
     const dnnw_rec *b = rec_find(R, n, name, "_bias"), *w = rec_find(R, n, name, "_weights_float");
-    if (!b || !w) return -1;
-    l->n_out = b->size / 4; l->n_in = w->size / 4 / l->n_out;
-    l->b = malloc(sizeof(float) * l->n_out); l->w = malloc(sizeof(float) * l->n_in * l->n_out);
+    if (!b || !w || b->size < 4 || b->size % 4 || w->size < 4 || w->size % 4) return -1;
+    l->n_out = b->size / 4;
+    if ((w->size / 4) % l->n_out) return -1;
+    l->n_in = w->size / 4 / l->n_out;
+    if (lin_alloc(l)) return -1;
     memcpy(l->b, b->data, sizeof(float) * l->n_out);
     const float *src = (const float *)w->data;                     /* stored as W^T: (n_in, n_out) */
     for (int i = 0; i < l->n_in; i++) for (int o = 0; o < l->n_out; o++) l->w[(size_t)o * l->n_in + i] = src[(size_t)i * l->n_out + o];
@@ -134,9 +147,12 @@ static int dequant_dense_float(const dnnw_rec *R, int n, const char *name, rd_li
 static int dequant_dense_int8(const dnnw_rec *R, int n, const char *name, rd_linear *l)
 {
     const dnnw_rec *b = rec_find(R, n, name, "_bias"), *s = rec_find(R, n, name, "_scale"), *q = rec_find(R, n, name, "_weights_int8");
-    if (!b || !s || !q) return -1;
-    l->n_out = b->size / 4; l->n_in = q->size / l->n_out;
-    l->b = malloc(sizeof(float) * l->n_out); l->w = malloc(sizeof(float) * l->n_in * l->n_out);
+    if (!b || !s || !q || b->size < 32 || b->size % 32 || s->size != b->size || q->size <= 0) return -1;   /* n_out a multiple of 8 */
+    l->n_out = b->size / 4;
+    if (q->size % l->n_out) return -1;
+    l->n_in = q->size / l->n_out;
+    if (l->n_in % 4) return -1;
+    if (lin_alloc(l)) return -1;
     memcpy(l->b, b->data, sizeof(float) * l->n_out);
     const float *sc = (const float *)s->data; const signed char *qq = (const signed char *)q->data;
     const int blocks_in = l->n_in / 4;
@@ -155,17 +171,30 @@ static int dequant_blocksparse_int8(const dnnw_rec *R, int n, const char *name, 
 {
     const dnnw_rec *b = rec_find(R, n, name, "_bias"), *s = rec_find(R, n, name, "_scale"), *q = rec_find(R, n, name, "_weights_int8"),
                    *ix = rec_find(R, n, name, "_weights_idx");
-    if (!b || !s || !q || !ix) return -1;
+    if (!b || !s || !q || !ix || b->size < 32 || b->size % 32 || s->size != b->size || ix->size < 4 || ix->size % 4 || q->size < 0) return -1;
     l->n_out = b->size / 4;
     const int *idx = (const int *)ix->data; const int nidx = ix->size / 4;
     const float *sc = (const float *)s->data; const signed char *qq = (const signed char *)q->data;
-    int n_in = 0;
-    for (int p = 0, g = 0; g < l->n_out / 8 && p < nidx; g++) { const int cnt = idx[p++]; for (int k = 0; k < cnt; k++, p++) if (idx[p] + 4 > n_in) n_in = idx[p] + 4; }
+    /* first walk: validate every count and column index, find n_in and the number of 8x4 blocks */
+    int n_in = 0, p = 0; long nblk = 0;
+    for (int g = 0; g < l->n_out / 8; g++) {
+        if (p >= nidx) return -1;
+        const int cnt = idx[p++];
+        if (cnt < 0 || cnt > nidx - p) return -1;
+        for (int k = 0; k < cnt; k++, p++) {
+            const int j = idx[p];
+            if (j < 0 || j > 65536 - 4) return -1;
+            if (j + 4 > n_in) n_in = j + 4;
+        }
+        nblk += cnt;
+    }
+    if (nblk * 32 != (long)q->size) return -1;
     l->n_in = n_in;
-    l->b = malloc(sizeof(float) * l->n_out); l->w = calloc((size_t)l->n_in * l->n_out, sizeof(float));
+    if (lin_alloc(l)) return -1;
     memcpy(l->b, b->data, sizeof(float) * l->n_out);
     size_t pos = 0;
-    for (int p = 0, g = 0; g < l->n_out / 8; g++) {
+    p = 0;
+    for (int g = 0; g < l->n_out / 8; g++) {
         const int cnt = idx[p++];
         for (int k = 0; k < cnt; k++) {
             const int j = idx[p++];
@@ -187,7 +216,8 @@ static int load_gru(const dnnw_rec *R, int n, const char *name, rd_gru *g)
 {
     char nm[64]; rd_linear in, rec;
     snprintf(nm, sizeof nm, "%s_input", name); if (dequant_blocksparse_int8(R, n, nm, &in)) return -1;
-    snprintf(nm, sizeof nm, "%s_recurrent", name); if (dequant_dense_int8(R, n, nm, &rec)) return -1;
+    snprintf(nm, sizeof nm, "%s_recurrent", name); if (dequant_dense_int8(R, n, nm, &rec)) { free(in.w); free(in.b); return -1; }
+    if (rec.n_out != 3 * rec.n_in || in.n_out != rec.n_out) { free(in.w); free(in.b); free(rec.w); free(rec.b); return -1; }
     g->hid = rec.n_in; g->n_in = in.n_in; g->w_ih = in.w; g->b_ih = in.b; g->w_hh = rec.w; g->b_hh = rec.b;
     swap_first_two_thirds(g->w_ih, g->hid * g->n_in); swap_first_two_thirds(g->w_hh, g->hid * g->hid);
     swap_first_two_thirds(g->b_ih, g->hid); swap_first_two_thirds(g->b_hh, g->hid);
@@ -204,7 +234,7 @@ int rd_model_parse(const void *blob, size_t len, rd_model *m)
         int ver, type, size, block;
         if (memcmp(p + off, "DNNw", 4)) { fprintf(stderr, "rade: bad weight blob (offset %zu)\n", off); return -1; }
         memcpy(&ver, p + off + 4, 4); memcpy(&type, p + off + 8, 4); memcpy(&size, p + off + 12, 4); memcpy(&block, p + off + 16, 4);
-        if (ver != 0 || off + 64 + (size_t)block > len) { fprintf(stderr, "rade: truncated weight blob\n"); return -1; }
+        if (ver != 0 || size < 0 || block < size || (size_t)block > len - off - 64) { fprintf(stderr, "rade: corrupt or truncated weight blob (record %d)\n", n); return -1; }
         memset(names[n], 0, 48); memcpy(names[n], p + off + 20, 44);
         recs[n].name = names[n]; recs[n].type = type; recs[n].size = size; recs[n].data = p + off + 64;
         n++; off += 64 + block;
@@ -301,7 +331,8 @@ static float f16_to_f32(unsigned short h)
     float f; memcpy(&f, &x, 4); return f;
 }
 
-/* W[N][K] (K a multiple of 16) -> B operands of v_mfma_f32_32x32x16_f16 in two planes, 2^10 w = hi + lo to 22 bits
+/* Returns the packed size, or -1 when a weight does not fit the planes (|w| 2^10 must stay below binary16's 65504).
+ * W[N][K] (K a multiple of 16) -> B operands of v_mfma_f32_32x32x16_f16 in two planes, 2^10 w = hi + lo to 22 bits
  * (the power-of-two scale keeps the low plane out of binary16's subnormal range; the GEMM epilogue undoes it):
  * out[kb][nt][plane][lane][j] = plane(1024 W[32 nt + lane%32][16 kb + 8 (lane/32) + j]) */
 long rd_packed16_size(int N, int K) { return (long)(K / 16) * ((N + 31) / 32) * 2 * 64 * 8; }
@@ -314,6 +345,7 @@ long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out)
                 for (int j = 0; j < 8; j++) {
                     const int nn = nt * 32 + (lane & 31), k = kb * 16 + 8 * (lane >> 5) + j;
                     const float w = nn < N ? 1024.0f * W[(size_t)nn * K + k] : 0.0f;
+                    if (!(fabsf(w) < 65504.0f)) return -1;                         /* the high plane would be inf (or the weight is NaN) */
                     const unsigned short hi = f32_to_f16(w), lo = f32_to_f16(w - f16_to_f32(hi));
                     unsigned short *o = out + ((((size_t)kb * ntt + nt) * 2) * 64 + lane) * 8 + j;
                     o[0] = hi; o[64 * 8] = lo;

@@ -20,6 +20,9 @@ typedef struct {
     rd_linear dec_glu[5];
 } rd_model;
 
+/* weight blob search order of rade_open(): hint, $RADE_MODEL_FILE, <library dir>/../weights/model19_check3.bin, cwd candidates (rade_api.c) */
+const char *rd_find_default_model(const char *hint, char *buf, size_t n);
+
 void rd_tables_fill(rd_tables *T);
 int rd_model_parse(const void *blob, size_t len, rd_model *m);
 void rd_model_free(rd_model *m);

@@ -98,6 +98,15 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     for (int r = 0; r < 4; r++) t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * r));
     return t;
 }
+// max over the wavefront of non-negative values (lanes DPP cannot reach read 0), the same value in every lane
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = fmaxf(v, quad_dpp<QUAD_XOR1>(v)); v = fmaxf(v, quad_dpp<QUAD_XOR2>(v)); v = fmaxf(v, quad_dpp<ROW_ROR4>(v)); v = fmaxf(v, quad_dpp<ROW_ROR8>(v));
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t = fmaxf(t, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * r)));
+    return t;
+}
 __device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
 // gate activations of the GRU recurrences on the hardware exp2 / rcp units (about 1 ulp each): the recurrence is a
 // serial chain, so the libm-grade expf / tanhf / IEEE division sequences would dominate every time step
@@ -379,7 +388,9 @@ extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
     const int gx = (rows + 31) / 32;
     if (rows <= 16384) {                       // too few row tiles to fill the chip: split K inside the workgroup
         dim3 block(64 * SK_WAVES);
-        static int attr_done = 0;
+        static int attr_done_dev[64];
+        int dev_ = 0; (void)hipGetDevice(&dev_);
+        int &attr_done = attr_done_dev[dev_ & 63];
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void *)k_gemm_splitk<3>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 3 * 16 * 64 * 4);
             (void)hipFuncSetAttribute((const void *)k_gemm_splitk<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SK_WAVES * 2 * 16 * 64 * 4);
@@ -659,6 +670,47 @@ __device__ void ds_gemm16_cols(const float *a1, int a1_st, int K1, const rd_lin 
     }
 }
 
+// The same product on the f32 matrix cores (v_mfma_f32_32x32x2_f32, weights from rd_pack_weights) for the one layer whose
+// input is not bounded: dense1 reads z_hat = symbol / pilot magnitude, which a deep fade or a false sync can push past the
+// +-255.9 the 2^8-scaled binary16 planes hold (an overflow there turns into inf - inf = NaN in the accumulators and poisons
+// the GRU state until the next reset; the reference computes a finite value that tanh squashes).  K = 80, N = 96: the f32
+// instruction's 16/3 lower rate costs ~2 k cycles per decoder batch.  NKB = K / 8 k-blocks, all loads issued up front.
+template <int NKB>
+__device__ void ds_gemm32_cols(const float *a1, int a1_st, const rd_lin w, float *y, int y_st, int act, int Tb)
+{
+    const int lane = threadIdx.x & 63, nt = threadIdx.x >> 6, half = lane >> 5;
+    const int ntt = (w.N + 31) >> 5;
+    if (nt >= ntt) return;
+    const float *wp = w.wp + ((size_t)nt * 64 + lane) * 4;
+    const size_t wstep = (size_t)ntt * 256;
+    const int col = nt * 32 + (lane & 31);
+    const float bias = (w.bias && col < w.N) ? w.bias[col] : 0.0f;
+    for (int r0 = 0; r0 < Tb; r0 += 32) {
+        const int t = min(r0 + (lane & 31), Tb - 1);
+        const float *p1 = a1 + (size_t)t * a1_st + 4 * half;
+        f32x4 av[NKB], bv[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++) { av[kb] = *(const f32x4 *)(p1 + kb * 8); bv[kb] = *(const f32x4 *)(wp + kb * wstep); }
+        f32x16 acc;
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[j] = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb][s], bv[kb][s], acc, 0, 0, 0);
+        if (col < w.N) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
+                if (tt >= Tb) continue;
+                float v = acc[j] + bias;
+                if (act == 1) v = clamp1(gate_tanh(v));
+                y[(size_t)tt * y_st + col] = v;
+            }
+        }
+    }
+}
+
 // GRU recurrence over Tb steps (k_gru_scan<96> inside a 512-thread workgroup: threads >= 384 only keep the barriers)
 __device__ void ds_scan(DecShared *sh, int tid, const float *gi_, int gi_st, const float *Whh, const float *bhh, float *hstate, float *out, int out_st, bool use_rst, int Tb)
 {
@@ -727,8 +779,9 @@ __device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb, i
     PH_T0();
     float *x = a.x + (size_t)b * a.x_sb;
     float *gi = a.gi + (size_t)b * a.gi_sb, *hb = a.hbuf + (size_t)b * a.hb_sb;
-    // short-K, few-column products (dense1: K = 80, GLU gates: K = 96): one column tile per wave, no split-K reduction
-    ds_gemm16_cols<4>(a.z + (size_t)b * a.z_sb, RD_LATENT, RD_LATENT, a.dense1, x, W, 1, Tb);
+    // short-K, few-column products (dense1: K = 80, GLU gates: K = 96): one column tile per wave, no split-K reduction;
+    // dense1 on the f32 matrix cores: its input z_hat is the only unbounded operand of the stack
+    ds_gemm32_cols<RD_LATENT / 8>(a.z + (size_t)b * a.z_sb, RD_LATENT, a.dense1, x, W, 1, Tb);
     __syncthreads();
 #pragma unroll 1
     for (int l = 0; l < 5; l++) {
@@ -1114,6 +1167,7 @@ enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
 struct RxScalars {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
     uint32_t lcg;
+    unsigned rxmax_cur, rxmax_h0, rxmax_h1;   // float bits of max |re|,|im| of the filtered samples of this call / the two calls before (check_pilots operand scale)
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
     int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
     float snr_est, mag; float2 bpf_phase;
@@ -1627,6 +1681,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->state = st->state; S->nin = st->nin; S->tmax = st->tmax; S->tmax_candidate = st->tmax_candidate; S->valid_count = st->valid_count;
         S->uw_errors = st->uw_errors; S->synced_count = st->synced_count; S->mf = st->mf; S->f_ind_max = st->f_ind_max;
         S->dec_reset_pending = st->dec_reset_pending; S->bpf_mem_len = st->bpf_mem_len; S->has_eoo = st->has_eoo; S->lcg = st->lcg;
+        S->rxmax_cur = st->rxmax[0]; S->rxmax_h0 = st->rxmax[1]; S->rxmax_h1 = st->rxmax[2];
         S->fmax = st->fmax; S->foff_err = st->foff_err; S->rph_r = st->rx_phase[0]; S->rph_i = st->rx_phase[1];
         S->Dthresh = st->Dthresh; S->Dtmax12 = st->Dtmax12; S->Dtmax12_eoo = st->Dtmax12_eoo; S->snr_est = st->snr_est;
         S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
@@ -1645,13 +1700,14 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // ---- can this stream make another call right now?  (decided once, by thread 0)
         if (tid == 0) {
             int go = 1;
-            if (S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls) go = 0;
+            if (S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls || S->valid_inv >= a.feat_cap) go = 0;   // feat_cap: room in features_out
             else if (S->consumed_inv + S->nin > avail) go = 0;
             // the decoder runs right here, in this workgroup, when its output is needed: before a unique-word check
             // (radae_rxe.py:220-224 looks at the aux bits of the 8 frames before this one) or when the row buffer is full
             // ... or when this launch ends for the stream (out of samples, call limit)
             S->need_decode = S->n_rows > 0 && (!go || (S->state == ST_SYNC && ((S->synced_count + 1) % 8) == 0) || S->n_rows + 3 > a.dec_rows);
             S->go = go;
+            if (go) { S->rxmax_h1 = S->rxmax_h0; S->rxmax_h0 = S->rxmax_cur; S->rxmax_cur = 0u; }   // rx_buf holds this call's samples and (parts of) the two calls' before
             S->state_before = S->state; S->nin_before = S->nin;
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
         }
@@ -1756,6 +1812,13 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 filt[j] = make_float2(0.0f, 0.0f);
                 if (i < nin) filt[j] = cmul(make_float2(ar[j], ai[j]), cconj(cmul(bpf_phase, eup[j])));   // mix back up
             }
+            // largest component of the new samples: sets the power-of-two scale of check_pilots' binary16 operand planes, so
+            // that no input level (int16-scaled samples, a strong interferer) can overflow them
+            float mloc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; j++) mloc = fmaxf(mloc, fmaxf(fabsf(filt[j].x), fabsf(filt[j].y)));
+            mloc = wave_max_f32(mloc);
+            if ((tid & 63) == 0) atomicMax(&S->rxmax_cur, __float_as_uint(mloc));       // non-negative floats order like their bit patterns
         }
         PH(19);
         // new BPF memory = last 102 of [mem | new]; rx_buf shift (radae_rxe.py:196-197)
@@ -1833,6 +1896,11 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             // once per k-step and reused by the task's f-tiles; the pilot planes stream from L2 (a.corr16)
             {
                 const int wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+                // operand scale 2^(7 - E), E = exponent of the largest component in rx_buf: samples x scale stay below 256 (the
+                // pilot planes carry 2^12); undone exactly in the |Dt| epilogue
+                const unsigned mb = max(max(S->rxmax_cur, S->rxmax_h0), S->rxmax_h1);
+                const int eb = min(max((int)((mb >> 23) & 0xffu), 32), 222);              // biased exponent, clamped so both factors stay normal
+                const float rx_sc = __uint_as_float((unsigned)(127 + 7 - (eb - 127)) << 23), rx_unsc = __uint_as_float((unsigned)(127 - 12 - 7 + (eb - 127)) << 23);
                 if (wave < 6) {
                     const int rt = wave >> 1, nt_base = (wave & 1) ? 3 : 0, ntn = (wave & 1) ? 2 : 3;
                     const int row = rt * 16 + i;
@@ -1857,7 +1925,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 #pragma unroll
                         for (int j = 0; j < 8; j += 2) {
                             float2 va = *(const float2 *)(xa + 32 * sidx + j), vb = *(const float2 *)(xb + 32 * sidx + j);
-                            va.x *= 256.0f; va.y *= 256.0f; vb.x *= 256.0f; vb.y *= 256.0f;       // 2^8 (samples) x 2^12 (pilot planes)
+                            va.x *= rx_sc; va.y *= rx_sc; vb.x *= rx_sc; vb.y *= rx_sc;           // 2^(7-E) (samples) x 2^12 (pilot planes)
                             const _Float16 a0 = (_Float16)va.x, a1 = (_Float16)va.y, b0 = (_Float16)vb.x, b1 = (_Float16)vb.y;
                             ah[j] = a0; ah[j + 1] = a1; al[j] = (_Float16)(va.x - (float)a0); al[j + 1] = (_Float16)(va.y - (float)a1);
                             bh[j] = b0; bh[j + 1] = b1; bl[j] = (_Float16)(vb.x - (float)b0); bl[j + 1] = (_Float16)(vb.y - (float)b1);
@@ -1881,8 +1949,8 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 #pragma unroll
                     for (int q = 0; q < 3; q++) if (q < ntn) {
                         const int f = 8 * (nt_base + q) + 2 * g;
-                        sh->absd[2 * row][f] = 0x1p-20f * hypotf(accA[q][0], accA[q][1]); sh->absd[2 * row][f + 1] = 0x1p-20f * hypotf(accA[q][2], accA[q][3]);
-                        sh->absd[2 * row + 1][f] = 0x1p-20f * hypotf(accB[q][0], accB[q][1]); sh->absd[2 * row + 1][f + 1] = 0x1p-20f * hypotf(accB[q][2], accB[q][3]);
+                        sh->absd[2 * row][f] = rx_unsc * hypotf(accA[q][0], accA[q][1]); sh->absd[2 * row][f + 1] = rx_unsc * hypotf(accA[q][2], accA[q][3]);
+                        sh->absd[2 * row + 1][f] = rx_unsc * hypotf(accB[q][0], accB[q][1]); sh->absd[2 * row + 1][f + 1] = rx_unsc * hypotf(accB[q][2], accB[q][3]);
                     }
                 } else {
                     // ---- wavefronts 6 and 7 have no matrix work here.  refine() has fixed (tmax, fmax), so they prepare what the
@@ -2106,6 +2174,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         st->state = S->state; st->nin = S->nin; st->tmax = S->tmax; st->tmax_candidate = S->tmax_candidate; st->valid_count = S->valid_count;
         st->uw_errors = S->uw_errors; st->synced_count = S->synced_count; st->mf = S->mf; st->f_ind_max = S->f_ind_max;
         st->dec_reset_pending = S->dec_reset_pending; st->bpf_mem_len = S->bpf_mem_len; st->has_eoo = S->has_eoo; st->lcg = S->lcg; st->dt_valid = S->dt_valid;
+        st->rxmax[0] = S->rxmax_cur; st->rxmax[1] = S->rxmax_h0; st->rxmax[2] = S->rxmax_h1;
         st->fmax = S->fmax; st->foff_err = S->foff_err; st->rx_phase[0] = S->rph_r; st->rx_phase[1] = S->rph_i;
         st->Dthresh = S->Dthresh; st->Dtmax12 = S->Dtmax12; st->Dtmax12_eoo = S->Dtmax12_eoo; st->snr_est = S->snr_est;
         st->bpf_phase[0] = S->bpf_phase.x; st->bpf_phase[1] = S->bpf_phase.y; st->consumed += S->consumed_round;
@@ -2114,15 +2183,16 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         a.acc[b * 4 + 0] = S->consumed_inv; a.acc[b * 4 + 1] = S->calls_inv; a.acc[b * 4 + 2] = S->valid_inv; a.acc[b * 4 + 3] = S->eoo_inv;
         a.status[b * 4 + 0] = S->nin; a.status[b * 4 + 1] = S->state == ST_SYNC; a.status[b * 4 + 2] = (int)S->snr_est; a.status[b * 4 + 3] = S->state;
         if (S->n_calls) atomicAdd(&a.progress[0], S->n_calls);
-        if (S->calls_inv < a.max_calls && S->consumed_inv + S->nin <= avail) atomicAdd(&a.progress[1], 1);   // stopped at the per-launch limit
+        if (S->calls_inv < a.max_calls && S->valid_inv < a.feat_cap && S->consumed_inv + S->nin <= avail) atomicAdd(&a.progress[1], 1);   // stopped at the per-launch limit
     }
 }
 
 extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
 {
     if (a->B <= 0) return 0;
-    static int attr_set = 0;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_rx_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared)); attr_set = 1; }
+    static int attr_set_dev[64];                     // the attribute is per device (one engine per GPU in a multi-GPU host process)
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    if (!attr_set_dev[dev_ & 63]) { (void)hipFuncSetAttribute((const void *)k_rx_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared)); attr_set_dev[dev_ & 63] = 1; }
     hipLaunchKernelGGL(k_rx_sync, dim3(a->B), dim3(NT_RX), sizeof(RxShared), (hipStream_t)s, *a);
     return (int)hipGetLastError();
 }

@@ -398,6 +398,7 @@ void rade_sc_rrc(const rade_sc *h, double *taps_out) { if (h && taps_out) memcpy
 int rade_sc_tx(rade_sc *h, const float *symbs_dev, int n_frames, void *iq_out_dev, long iq_stride, void *stream)
 {
     if (!h || !symbs_dev || !iq_out_dev || n_frames <= 0 || iq_stride < (long)n_frames * SC_NFRAME * SC_M) return -1;
+    (void)hipSetDevice(h->device);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sc_tx, dim3(n_frames, h->B), dim3(SC_NFRAME * SC_M), 0, s, h->st, h->d_rrc, h->omega, symbs_dev, n_frames, (float2 *)iq_out_dev, iq_stride);
     hipLaunchKernelGGL(k_sc_tx_finish, dim3(h->B), dim3(64), 0, s, h->st, h->omega, symbs_dev, n_frames);
@@ -408,6 +409,7 @@ int rade_sc_rx(rade_sc *h, const void *rx_dev, long rx_stride, int n_avail, int 
                rade_sc_frame *frames_out_dev, rade_sc_status *status_host, void *stream)
 {
     if (!h || !rx_dev || n_avail < 0 || max_frames <= 0 || rx_stride < n_avail) return -1;
+    (void)hipSetDevice(h->device);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_sc_rx, dim3(h->B), dim3(SC_NT), 0, s, h->st, h->d_rrc, h->omega, (const float2 *)rx_dev, rx_stride, n_avail, max_frames,
                        (float2 *)payload_out_dev, zhat_out_dev, frames_out_dev, h->d_status);

@@ -9,7 +9,7 @@ conv tap flattening :307-311).
 
 This module inverts that export into plain fp32 matrices in *row-major [out][in]* form
 (the orientation torch.nn.Linear uses) so that the same numbers can be
-  * loaded into the C/HIP engine (it has its own C twin of this reader, `csrc/rade_dnnw.c`),
+  * loaded into the C/HIP engine (it has its own C twin of this reader, `csrc/rade_host.c:rd_model_parse`),
   * loaded into the reference's PyTorch modules by `oracle/gen_golden.py`.
 
 De-quantisation rule: the int8 value q and the per-output `scale` array satisfy

@@ -283,6 +283,10 @@ class BatchEngine:
         cap = min(max_calls, int(avail.max()) // 800 + 1)
         if features_out is None:
             features_out = torch.zeros((self.B, cap, FEAT_MF), dtype=torch.float32, device=rx.device)
+        # features_out.shape[1] is the per-stream frame capacity handed to the C ABI: a stream pauses (status.consumed < avail)
+        # once it has filled its rows, so a short buffer never makes the kernel write into the next stream's region
+        assert features_out.is_cuda and features_out.dtype == torch.float32 and features_out.is_contiguous() and features_out.dim() == 3 \
+            and features_out.shape[0] == self.B and features_out.shape[1] >= 1 and features_out.shape[2] == FEAT_MF
         eoo = torch.zeros((self.B, NEOO_BITS), dtype=torch.float32, device=rx.device)
         status = (RxStatus * self.B)()
         r = self.lib.rade_batch_rx(self.h, rx.data_ptr(), N, avail.ctypes.data_as(C.POINTER(C.c_int)), max_calls, features_out.data_ptr(),

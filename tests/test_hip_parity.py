@@ -241,6 +241,101 @@ def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_mod
         eng.close()
 
 
+def test_unbounded_operands_do_not_overflow(Engine, torch_dev, oracle, oracle_model):
+    """The matrix products run on binary16 operand planes; the operands that are NOT tanh-bounded must not overflow them:
+    raw features into the encoder's dense1 (+-300 and beyond), z_hat rows into the decoder's dense1 (+-1e3 / +-1e5: a deep
+    fade or a false sync divides symbols by a tiny pilot magnitude), and the received samples themselves in check_pilots
+    (int16-scaled input, bursts far above the pilots).  The reference computes finite values that tanh squashes
+    (radae_base.py:260-268, :400-404); so must every path here -- small batches (f32 kernels), large ones (split-binary16
+    kernels) and the decoder stage inside the receiver kernel."""
+    import torch
+    from radae_amd.channel_tools import synth_features
+    from radae_amd.engine import sigma_from_EbNodB
+    # (a) encoder, large batch (> 16 k GEMM rows) and single stream
+    B, n_mf = 72, 84
+    feats = np.stack([synth_features(900 + b, 12 * n_mf) for b in range(B)])
+    feats[:, :, :20] *= np.float32(120.0)                     # |f0| up to ~1500, most features past +-256
+    assert np.abs(feats).max() > 300
+    eng = Engine(B, max_tx_mf=n_mf)
+    z = eng.tx(torch.tensor(feats, device=torch_dev), want_z=True)[1].cpu().numpy()
+    eng.close()
+    assert np.isfinite(z).all()
+    small = Engine(1, max_tx_mf=n_mf)
+    for b in (0, 40):
+        tx = oracle.Tx(oracle_model)
+        zr = np.concatenate([tx.frame(feats[b, 12 * k:12 * k + 12].ravel())[1] for k in range(n_mf)]).reshape(-1, 80)
+        assert np.abs(z[b] - zr).max() / np.abs(zr).max() < 2e-5
+        zs = small.tx(torch.tensor(feats[b][None], device=torch_dev), want_z=True)[1].cpu().numpy()[0]
+        assert np.abs(zs - zr).max() / np.abs(zr).max() < 2e-5
+        small.tx_reset()
+    small.close()
+    # (b) stand-alone decoder, rows of +-1e3 and +-1e5
+    rng = np.random.default_rng(77)
+    zin = rng.standard_normal((B, 3 * n_mf, 80)).astype(np.float32)
+    zin[:, 5::7] *= np.float32(1e3); zin[:, 9::11] *= np.float32(1e5)
+    eng = Engine(B, max_tx_mf=n_mf)
+    fh = eng.decode(torch.tensor(zin, device=torch_dev), 84).cpu().numpy()
+    eng.close()
+    assert np.isfinite(fh).all()
+    small = Engine(1, max_tx_mf=n_mf)
+    for b in (3, 60):
+        dec = oracle.Decoder(oracle_model)
+        ref = np.stack([dec.step(r) for r in zin[b]])
+        assert rms(fh[b], ref) < 1e-4
+        assert rms(small.decode(torch.tensor(zin[b][None], device=torch_dev), 84).cpu().numpy()[0], ref) < 1e-4
+    small.close()
+    # (c) the receiver: int16-scaled samples; a burst far above the pilots (check_pilots rows and the end-of-over correlation see
+    # samples of ~2000); pilots faded out by 80 dB at 60 dB Eb/No, so that z_hat = symbol / pilot magnitude leaves +-256
+    n_mf = 30
+    f1, G, n_pre, noise = _make_stream(31, n_mf, 8.0, 7.0, "awgn")
+    tx = oracle.Tx(oracle_model)
+    sig = np.concatenate([tx.frame(f1[12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+    boosted = sig.copy(); faded = sig.copy()
+    for mf in range(12, 18):                                  # data symbols (the four after the pilot symbol) x 2000 in six frames
+        boosted[mf * 960 + 192:(mf + 1) * 960] *= np.float32(2000.0)
+    for mf in range(12, 20):                                  # pilot symbols of eight frames x 1e-4
+        faded[mf * 960:mf * 960 + 192] *= np.float32(1e-4)
+    streams = []
+    for s_in, gain, eb in ((sig, 3.0e4, 8.0), (boosted, 1.0, 8.0), (faded, 1.0, 60.0)):
+        sigma = sigma_from_EbNodB(eb)
+        r, fin = oracle.channel(s_in, None, noise[n_pre:n_pre + len(sig)], sigma, 7.0)
+        e = oracle.channel_eoo(tx.eoo(), noise[n_pre + len(sig):n_pre + len(sig) + 1152], sigma, 7.0, 0.0, fin)
+        streams.append((np.concatenate([sigma * noise[:n_pre], r, e, sigma * noise[-1152:]]) * np.float32(gain)).astype(np.complex64))
+    eng = Engine(3, max_tx_mf=1, rx_trace_calls=64)
+    fo_dev, st, _ = eng.rx(torch.tensor(np.stack(streams), device=torch_dev))
+    for b in range(3):
+        d = oracle.run_rx_stream(oracle_model, streams[b])
+        t = eng.rx_trace(b)
+        for k in INT_KEYS:
+            assert np.array_equal(t[k], d[k]), (b, k)
+        nv = st[b].n_valid
+        assert nv == len(d["features_out"]) and nv > 5
+        out = fo_dev.cpu().numpy()[b, :nv]
+        assert np.isfinite(out).all() and rms(out, d["features_out"]) < 1e-4
+    assert np.abs(eng.rx_trace(2)["z_all"]).max() > 256.0       # the faded pilots really produced out-of-range latents
+    eng.close()
+
+
+def test_rx_output_capacity_is_respected(Engine, torch_dev, golden):
+    """features_out rows are a capacity: a stream that has filled them pauses (consumed < available) instead of writing on;
+    continuing with a fresh buffer gives the same frames as one big call."""
+    import torch
+    g = golden("rxtrace_awgn")
+    x = torch.tensor(g["rx_in"][None], device=torch_dev)
+    eng = Engine(1, max_tx_mf=1)
+    full, st, _ = eng.rx(x)
+    nv = st[0].n_valid
+    assert nv == len(g["features_out"]) and nv > 6
+    eng.rx_reset()
+    guard = torch.full((1, 5 + 1, 432), 7.0, dtype=torch.float32, device=torch_dev)
+    part, st1, _ = eng.rx(x, features_out=guard[:, :5])
+    assert st1[0].n_valid == 5 and st1[0].consumed < x.shape[1] and bool((guard[:, 5] == 7.0).all())      # nothing past row 5
+    rest, st2, _ = eng.rx(x[:, st1[0].consumed:].contiguous())
+    assert st2[0].n_valid == nv - 5
+    assert torch.equal(torch.cat([part[0, :5], rest[0, :nv - 5]]), full[0, :nv])
+    eng.close()
+
+
 def test_streams_are_independent_and_ragged(Engine, torch_dev, golden):
     """Identical streams give bit-identical outputs whatever their slot; ragged / empty inputs are handled."""
     import torch
@@ -495,6 +590,38 @@ def test_stdin_stdout_hosts(golden, tmp_path, which):
     assert feats.shape == g["features_out"].shape and rms(feats, g["features_out"]) < 1e-5
     eoo = np.fromfile(tmp_path / "eoo_rx.f32", np.float32)
     assert eoo.shape == (180,) and np.abs(eoo - g["eoo_out"][-1]).max() < 1e-4
+
+
+def test_core_level_boundary_config2(golden, tmp_path):
+    """include/rade_core.h (rade_core.h:42-46 of the reference): rade_core_encoder / rade_core_decoder one 40 ms step per call
+    against the goldens of the reference's stateful modules, bottleneck 1 = tanh of the same latents, a second state on the
+    same model is independent, and the stdin/stdout filters with the test_rade_enc.c / test_rade_dec.c command lines and wire
+    formats (84-float rows <-> 80-float rows inside 4 x 36-float frames)."""
+    import os
+    from radae_amd import core
+    e, d = golden("enc_tx"), golden("dec_loss")
+    f = e["features"][0]                                               # [120][36]
+    rows = np.concatenate([f[:, :20], -np.ones((120, 1), np.float32)], 1).reshape(30, 84)
+    enc = core.CoreEncoder()
+    z = np.stack([enc.step(r) for r in rows])
+    assert rms(z, e["z"][0]) < 1e-5 and np.abs(z - e["z"][0]).max() < 2e-6 * np.abs(e["z"]).max() + 1e-5
+    enc2 = core.CoreEncoder()                                          # second state, same blob: bottleneck 1, untouched by the first
+    z1 = np.stack([enc2.step(r, bottleneck=1) for r in rows])
+    assert np.abs(z1 - np.tanh(e["z"][0])).max() < 1e-5
+    enc.reset()
+    assert np.array_equal(np.stack([enc.step(r) for r in rows[:5]]), z[:5])          # rade_init_encoder == fresh state
+    with pytest.raises(ValueError):
+        core.CoreEncoder(input_dim=80)                                # model19_check3 carries the aux symbol: 84 only
+    dec = core.CoreDecoder()
+    fh = np.stack([dec.step(r) for r in d["z_hat"]]).reshape(120, 21)
+    assert rms(fh, d["features"]) < 1e-5
+    enc.close(); enc2.close(); dec.close()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = os.path.join(repo, "weights", "model19_check3.bin")
+    zf = np.frombuffer(_pipe(os.path.join(repo, "hosts", "rade_enc_filter"), ["3", "1", blob], f.astype(np.float32).tobytes(), tmp_path), np.float32).reshape(-1, 80)
+    assert np.array_equal(zf, z)                                       # the filter is the same call sequence
+    ff = np.frombuffer(_pipe(os.path.join(repo, "hosts", "rade_dec_filter"), ["1"], d["z_hat"].astype(np.float32).tobytes(), tmp_path), np.float32).reshape(-1, 36)
+    assert ff.shape == (120, 36) and np.array_equal(ff[:, :21], fh) and not ff[:, 21:].any()
 
 
 def test_model05_rate_rs_config1(Engine, torch_dev, golden):

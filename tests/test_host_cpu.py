@@ -48,16 +48,39 @@ def test_built_kernels_do_not_spill_ahead_of_exec_restore(lib):
 
 def test_library_exports_every_declared_symbol(lib):
     declared = set()
-    for hdr in ("rade_api.h", "rade_batch.h"):
+    for hdr in ("rade_api.h", "rade_batch.h", "rade_core.h"):
         src = open(os.path.join(REPO, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        declared |= set(re.findall(r"\b(rade_[a-zA-Z0-9_]+)\s*\(", src))
+        declared |= set(re.findall(r"\b((?:rade|init_rade)[a-zA-Z0-9_]+)\s*\(", src))
     declared -= {"rade_batch", "rade_batch_config", "rade_channel_params", "rade_rx_status", "rade_rx_trace"}
     assert len(declared) >= 35
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     from radae_amd import engine
     assert set(engine.EXPORTED_SYMBOLS) <= declared
+
+
+def test_core_level_model_init_on_cpu(lib):
+    """include/rade_core.h without a GPU: the DNNw walker (Opus parse_weights() role) lists the blob's arrays, init_radeenc /
+    init_radedec accept exactly the dimension the blob was exported with (README.md:582-588: 80 <-> 84 at run time)."""
+    from radae_amd import core, dnnw
+    blob19 = open(os.path.join(REPO, "weights", "model19_check3.bin"), "rb").read()
+    arrays = core.parse_weights(blob19)
+    ref = dnnw.read_records(os.path.join(REPO, "weights", "model19_check3.bin"))
+    assert [a[0] for a in arrays] == list(ref) and all(a[2] == ref[a[0]].nbytes for a in arrays)
+    with pytest.raises(ValueError):
+        core.parse_weights(b"DNNx" + blob19[4:])
+    with pytest.raises(ValueError):
+        core.parse_weights(blob19[:1000])
+    for path, good, bad in (("model19_check3.bin", 84, 80), ("model05.bin", 80, 84)):
+        L = core._lib()
+        buf = C.create_string_buffer(open(os.path.join(REPO, "weights", path), "rb").read())
+        lst = C.POINTER(core.WeightArray)()
+        assert L.rade_parse_weights(C.byref(lst), C.cast(buf, C.c_void_p), len(buf) - 1) > 100
+        m = core._Model()
+        assert L.init_radeenc(C.byref(m), lst, good) == 0 and m.dim == good and m.nb_z == 80
+        assert L.init_radeenc(C.byref(m), lst, bad) != 0 and L.init_radedec(C.byref(m), lst, bad) != 0 and L.init_radedec(C.byref(m), lst, 64) != 0
+        assert L.init_radedec(C.byref(m), lst, good) == 0
 
 
 def test_no_cpu_fallback(lib):
@@ -153,6 +176,46 @@ def test_host_blob_reader_and_packing(lib, golden):
         exp = W[nn, k] if nn < N else 0.0
         assert out[((kb * ntt + nt) * 64 + lane) * 4 + s] == exp
     assert np.sort(out[out != 0]).tolist() == np.sort(W.ravel()).tolist()
+
+
+def test_host_blob_reader_rejects_hostile_headers(lib):
+    """The blob path is caller-controlled (rade_open argument / $RADE_MODEL_FILE): record headers with negative or
+    inconsistent sizes, wild sparse-index entries and zero-sized arrays must be refused before anything is written."""
+    import struct
+    from radae_amd import dnnw, engine
+    blob = bytearray(open(engine.DEFAULT_BLOB, "rb").read())
+    lib.rd_model_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Model)]
+    recs, off = {}, 0                                    # name -> (header offset, size, block)
+    while off + 64 <= len(blob):
+        ver, typ, size, block = struct.unpack_from("<iiii", blob, off + 4)
+        recs[bytes(blob[off + 20:off + 64]).split(b"\0")[0].decode()] = (off, size, block)
+        off += 64 + block
+    assert "enc_gru1_input_weights_idx" in recs and "dec_conv2_bias" in recs
+
+    def rejected(mut):
+        b = bytearray(blob); mut(b)
+        return lib.rd_model_parse(bytes(b), len(b), C.byref(Model())) != 0
+
+    o, size, block = recs["enc_gru1_input_weights_idx"]
+    assert rejected(lambda b: struct.pack_into("<i", b, o + 16, -64))                 # negative block: wraps the bounds check
+    assert rejected(lambda b: struct.pack_into("<i", b, o + 12, -4))                  # negative size
+    assert rejected(lambda b: struct.pack_into("<i", b, o + 12, block + 4096))        # size beyond its block
+    assert rejected(lambda b: struct.pack_into("<i", b, o + 64, 1 << 28))             # first group's block count runs off the index array
+    assert rejected(lambda b: struct.pack_into("<i", b, o + 68, 1 << 30))             # a column index far outside the matrix
+    assert rejected(lambda b: struct.pack_into("<i", b, o + 68, -8))
+    o2, size2, _ = recs["dec_conv2_bias"]
+    assert rejected(lambda b: struct.pack_into("<i", b, o2 + 12, 0))                  # n_out = 0: no division by zero
+    assert rejected(lambda b: struct.pack_into("<i", b, o2 + 12, size2 - 4))          # bias / scale / weight sizes disagree
+    o3, size3, _ = recs["enc_conv1_weights_int8"]
+    assert rejected(lambda b: struct.pack_into("<i", b, o3 + 12, size3 - 96))         # weight count not n_in x n_out
+    o4, size4, _ = recs["enc_gru2_input_weights_int8"]
+    assert rejected(lambda b: struct.pack_into("<i", b, o4 + 12, size4 - 32))         # fewer 8x4 blocks than the index walk needs
+    rng = np.random.default_rng(5)                                                    # random header bytes: refuse or parse, never crash
+    for _ in range(200):
+        b = bytearray(blob)
+        o5 = list(recs.values())[int(rng.integers(0, len(recs)))][0]
+        struct.pack_into("<i", b, o5 + int(rng.choice([8, 12, 16])), int(rng.integers(-2**31, 2**31 - 1)))
+        lib.rd_model_parse(bytes(b), len(b), C.byref(Model()))
 
 
 def test_loss_tool_matches_reference(golden):

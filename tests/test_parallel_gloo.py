@@ -20,7 +20,8 @@ def _worker(rank, world, port, q):
     blob = broadcast_blob(DEFAULT_BLOB if rank == 0 else None, torch.device("cpu"), world)
     lo, hi = shard_range(2048, rank, world)
     stats = gather_stats(np.array([hi - lo, float(rank + 1), len(blob)]), torch.device("cpu"), world)
-    q.put((rank, len(blob), hash(blob), lo, hi, stats.tolist()))
+    import hashlib
+    q.put((rank, len(blob), hashlib.sha256(blob).hexdigest(), lo, hi, stats.tolist()))
     dist.destroy_process_group()
 
 
@@ -33,7 +34,9 @@ def test_blob_broadcast_and_sharding_world2():
     res = sorted(q.get(timeout=120) for _ in range(2))
     [p.join(timeout=60) for p in procs]
     ref = open(os.path.join(REPO, "weights", "model19_check3.bin"), "rb").read()
+    import hashlib
     assert res[0][1] == res[1][1] == len(ref)
+    assert res[0][2] == res[1][2] == hashlib.sha256(ref).hexdigest()      # the bytes, not just their count
     assert (res[0][3], res[0][4], res[1][3], res[1][4]) == (0, 1024, 1024, 2048)
     assert res[0][5] == res[1][5] == [2048.0, 3.0, 2.0 * len(ref)]
 
