@@ -1,0 +1,153 @@
+/*
+ * rade_multi_bench -- BASELINE.json configs[3] from plain C: B utterances per GPU (default 256, i.e. 2048 on 8 GPUs) x 1008 feature
+ * frames through encode -> OFDM mod -> MPP Doppler-spread channel + AWGN 3 dB / -11 Hz -> sync / demod / EQ / decode, one host
+ * process, one host thread per device, utterances sharded contiguously (utterance u: feature seed 1000 + u), the weight blob
+ * broadcast over RCCL, statistics summed with one RCCL all-reduce (include/rade_batch.h: rade_multi_*).  Prints one JSON line.
+ *
+ * usage: rade_multi_bench [--gpus N | --mask HEX] [--streams-per-gpu B] [--frames T] [--steps K] [--warmup W] [weights.bin]
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "rade_batch.h"
+
+#define PI_D 3.14159265358979323846
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+/* xorshift64* + Box-Muller: the features only have to be "speech-like" AR(1) noise, not a particular sequence */
+static uint64_t rng_next(uint64_t *s) { *s ^= *s >> 12; *s ^= *s << 25; *s ^= *s >> 27; return *s * 2685821657736338717ull; }
+static double rng_gauss(uint64_t *s)
+{
+    const double u1 = ((rng_next(s) >> 11) + 0.5) / 9007199254740992.0, u2 = ((rng_next(s) >> 11) + 0.5) / 9007199254740992.0;
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * PI_D * u2);
+}
+static void synth_features(uint64_t seed, int T, float *out /* [T][36] */)
+{   /* x[t] = 0.9 x[t-1] + 0.436 N(0,1); f0 = 4 x0, f18 = 0.5 x18, f19 = clip(0.3 x19, +-0.5) */
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1; double x[20] = { 0 };
+    memset(out, 0, sizeof(float) * (size_t)T * 36);
+    for (int t = 0; t < T; t++)
+        for (int j = 0; j < 20; j++) {
+            x[j] = 0.9 * x[j] + 0.436 * rng_gauss(&s);
+            double f = x[j];
+            if (j == 0) f *= 4.0; else if (j == 18) f *= 0.5; else if (j == 19) { f *= 0.3; if (f > 0.5) f = 0.5; if (f < -0.5) f = -0.5; }
+            out[(size_t)t * 36 + j] = (float)f;
+        }
+}
+/* Gaussian-PSD Doppler filter by frequency sampling (doppler_spread.m:20-32; radae_amd/channel_tools.py): 100 taps at lowFs */
+static void doppler_taps(double spread_hz, double low_fs, float *h /* [100] */)
+{
+    const int ntaps = 100, npt = 512, N = 2 * npt; const double sigma = spread_hz / 2.0;
+    for (int n = 0; n < ntaps; n++) {
+        double acc = 0.0;
+        for (int k = 0; k <= npt; k++) {
+            const double f = low_fs / 2.0 * k / npt, mag = 1.0 / (sigma * sqrt(2 * PI_D)) * exp(-f * f / (2 * sigma * sigma));
+            const double ph = -PI_D * k * (ntaps - 1) / (2.0 * npt) + 2.0 * PI_D * k * n / N;
+            acc += (k == 0 || k == npt ? 1.0 : 2.0) * mag * cos(ph);
+        }
+        h[n] = (float)(acc / N * (0.54 - 0.46 * cos(2.0 * PI_D * n / (ntaps - 1))));
+    }
+}
+
+typedef struct {
+    int T, n_mf, n_sig, n_pre, n_post, n_total, steps, warmup;
+    float taps[100]; int low_ratio;
+    pthread_barrier_t bar;
+    /* per device */
+    float *feat[64], *fout[64]; void *G[64], *iq[64], *rx[64]; int *avail[64]; rade_rx_status *st[64];
+    double t_step[64]; double stats[64][6];
+} job;
+
+static int setup(int i, rade_batch *e, int first, int n, void *arg)
+{
+    job *j = arg;
+    float *hf = malloc(sizeof(float) * (size_t)n * j->T * 36);
+    for (int b = 0; b < n; b++) synth_features(1000 + first + b, j->T, hf + (size_t)b * j->T * 36);
+    if (hipMalloc((void **)&j->feat[i], sizeof(float) * (size_t)n * j->T * 36) || hipMalloc(&j->G[i], 16ull * n * j->n_sig) ||
+        hipMalloc(&j->iq[i], 8ull * n * j->n_sig) || hipMalloc(&j->rx[i], 8ull * n * j->n_total) ||
+        hipMalloc((void **)&j->fout[i], sizeof(float) * (size_t)n * (j->n_mf + 8) * 432)) return -1;
+    if (hipMemcpy(j->feat[i], hf, sizeof(float) * (size_t)n * j->T * 36, hipMemcpyHostToDevice)) return -1;
+    free(hf);
+    if (rade_batch_multipath_gen(e, j->taps, 100, j->low_ratio, j->n_sig, NULL, 5000 + first, j->G[i], NULL) != j->n_sig) return -1;
+    j->avail[i] = malloc(sizeof(int) * n); j->st[i] = malloc(sizeof(rade_rx_status) * n);
+    for (int b = 0; b < n; b++) j->avail[i][b] = j->n_total;
+    return 0;
+}
+
+static int one_step(job *j, int i, rade_batch *e, int n, unsigned long long seed)
+{
+    rade_channel_params p; memset(&p, 0, sizeof p);
+    p.n_sig = j->n_sig; p.n_pre = j->n_pre; p.n_post = j->n_post; p.with_eoo = 1; p.sigma = rade_sigma_from_EbNodB(3.0f); p.freq_offset = -11.0f;
+    p.G_dev = j->G[i]; p.seed = seed;
+    rade_batch_reset(e, NULL);
+    if (rade_batch_tx(e, j->feat[i], j->n_mf, j->iq[i], j->n_sig, NULL, NULL) != j->n_sig) return -1;
+    if (rade_batch_channel(e, j->iq[i], j->n_sig, j->rx[i], j->n_total, &p, NULL) != j->n_total) return -1;
+    return rade_batch_rx(e, j->rx[i], j->n_total, j->avail[i], 1 << 20, j->fout[i], (long)(j->n_mf + 8) * 432, NULL, j->st[i], NULL);
+}
+
+static int run(int i, rade_batch *e, int first, int n, void *arg)
+{
+    job *j = arg;
+    for (int w = 0; w < j->warmup; w++) if (one_step(j, i, e, n, 100 + w)) return -1;
+    hipDeviceSynchronize();
+    pthread_barrier_wait(&j->bar);                               /* all devices start the timed region together */
+    const double t0 = now_s();
+    for (int k = 0; k < j->steps; k++) if (one_step(j, i, e, n, 1 + k)) return -1;
+    hipDeviceSynchronize();
+    j->t_step[i] = (now_s() - t0) / j->steps;
+    pthread_barrier_wait(&j->bar);
+    double *s = j->stats[i]; memset(s, 0, sizeof(double) * 6);
+    for (int b = 0; b < n; b++) {
+        const rade_rx_status *r = &j->st[i][b];
+        s[0] += j->T; s[1] += 12.0 * r->n_valid; s[2] += r->n_calls; s[3] += r->n_valid + r->has_eoo; s[4] += r->has_eoo; s[5] += r->consumed;
+    }
+    (void)first;
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    int gpus = 1, B = 256; unsigned long long mask = 0; const char *blob = NULL;
+    job j; memset(&j, 0, sizeof j);
+    j.T = 1008; j.steps = 20; j.warmup = 3;
+    for (int a = 1; a < argc; a++) {
+        if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--mask") && a + 1 < argc) mask = strtoull(argv[++a], NULL, 16);
+        else if (!strcmp(argv[a], "--streams-per-gpu") && a + 1 < argc) B = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--frames") && a + 1 < argc) j.T = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--steps") && a + 1 < argc) j.steps = atoi(argv[++a]);
+        else if (!strcmp(argv[a], "--warmup") && a + 1 < argc) j.warmup = atoi(argv[++a]);
+        else blob = argv[a];
+    }
+    if (!mask) mask = gpus >= 64 ? ~0ull : (1ull << gpus) - 1;
+    if (!blob) blob = getenv("RADE_MODEL_FILE") ? getenv("RADE_MODEL_FILE") : "weights/model19_check3.bin";
+    int n_dev = 0; for (int g = 0; g < 64; g++) n_dev += (mask >> g) & 1;
+    j.n_mf = j.T / 12; j.n_sig = j.n_mf * 960; j.n_pre = 8000; j.n_post = 1152; j.n_total = j.n_pre + j.n_sig + 1152 + j.n_post;
+    j.low_ratio = 800; doppler_taps(1.0, 10.0, j.taps);         /* MPP: 1 Hz Doppler spread, lowFs = 10 Hz (multipath_samples.m:13) */
+    rade_multi *m = rade_multi_open(blob, B * n_dev, j.n_mf, mask, 0);
+    if (!m) return 1;
+    n_dev = rade_multi_n_devices(m);
+    pthread_barrier_init(&j.bar, NULL, n_dev);
+    if (rade_multi_foreach(m, setup, &j) < 0) { fprintf(stderr, "rade_multi_bench: setup failed\n"); return 1; }
+    if (rade_multi_foreach(m, run, &j) < 0) { fprintf(stderr, "rade_multi_bench: run failed\n"); return 1; }
+    double flat[64 * 6], tot[6], tmax = 0.0;
+    for (int i = 0; i < n_dev; i++) { memcpy(flat + 6 * i, j.stats[i], sizeof(double) * 6); if (j.t_step[i] > tmax) tmax = j.t_step[i]; }
+    if (rade_multi_allreduce_sum(m, flat, 6, tot)) return 1;
+    printf("{\"metric\": \"vocoder-feature frames/sec (enc+chan+dec), model19\", \"value\": %.1f, \"unit\": \"frames/s\", \"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, "
+           "\"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", \"dtype\": \"f32\", \"data\": \"synthetic\", "
+           "\"config\": {\"workload\": \"model19_check3, %d utterances x %d frames sharded over %d GPU(s) from one C host process (configs[3] recipe)\", \"collectives\": \"%s: 1 broadcast (blob), 1 all-reduce (statistics)\"}, "
+           "\"per_device_ms_per_step\": [", tot[0] / tmax, n_dev, j.steps, j.warmup, 1e3 * tmax, B * n_dev, j.T, n_dev, rade_multi_transport(m));
+    for (int i = 0; i < n_dev; i++) printf("%s%.4f", i ? ", " : "", 1e3 * j.t_step[i]);
+    printf("], \"job_last_step\": {\"offered_frames\": %.0f, \"decoded_frames\": %.0f, \"rx_calls\": %.0f, \"sync_calls\": %.0f, \"eoo_detected_streams\": %.0f, \"samples_consumed\": %.0f}}\n",
+           tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
+    rade_multi_close(m);
+    return 0;
+}

@@ -36,6 +36,8 @@ typedef struct {
     int device;           /* HIP device ordinal */
     int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm) */
     int rx_trace_calls;   /* >0: keep a per-call trace of this many do_radae_rx calls per stream (tests) */
+    float disable_unsync; /* test mode of radae_rxe.py --disable_unsync (:277-281, :337): after this many seconds in sync the receiver no longer
+                           * drops back to search (pilot loss, end-of-over, UW failure); 0 = normal operation */
 } rade_batch_config;
 
 /* blob = DNNw weight file (weights/model19_check3.bin).  Returns NULL on failure (message on stderr). */
@@ -104,7 +106,9 @@ float rade_sigma_from_EbNodB(float EbNodB);
  * rx_dev + b*rx_stride points at the first sample stream b has NOT yet consumed; n_avail_host[b]
  * samples are readable there.  Each stream consumes whole do_radae_rx calls (rade_nin() samples
  * each) while enough samples remain and fewer than max_calls calls were made in this invocation.
- * features_out_dev: stream b at + b*feat_stride floats; each valid modem frame appends 432 floats.
+ * features_out_dev: stream b at + b*feat_stride floats; each valid modem frame appends 432 floats.  feat_stride / 432 is the
+ *   stream's capacity in frames: a stream that has filled it makes no further call in this invocation (status consumed < available),
+ *   so nothing is ever written past a stream's rows; the caller continues from rx_dev + consumed with fresh rows.
  * eoo_out_dev: [B][180] soft bits of the most recent end-of-over frame (NULL to skip).
  * status_host: [B] records filled on return (the call synchronises `stream`). */
 typedef struct {
@@ -142,6 +146,24 @@ enum { RADE_PROF_GEMM = 0, RADE_PROF_SCAN, RADE_PROF_MOD, RADE_PROF_CHAN, RADE_P
 void rade_batch_profile(rade_batch *h, int enable);
 /* accumulated since enable: device milliseconds, algorithmic FLOPs, launches */
 int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches);
+
+/* ---- several GPUs from one host process (BASELINE.json configs[3]: 2048 utterances over 8 MI355X) -------------------
+ * The n_streams_total independent utterances are sharded contiguously over the devices of device_mask (bit g = HIP device g),
+ * ceil(total / n_dev) per device; there is no data-path collective.  rade_multi_open reads the DNNw blob once, moves it to the
+ * other devices with ONE ncclBroadcast (RCCL over xGMI; librccl.so is bound at run time and only required for n_dev > 1) and opens
+ * one engine per device (one host thread each).  Per-device work is driven through the ordinary rade_batch_* calls on
+ * rade_multi_engine(m, i); rade_multi_foreach runs a callback on one host thread per device; rade_multi_allreduce_sum adds job
+ * statistics (frames, loss sums, bit errors) with ONE ncclAllReduce.  NULL / <0 on failure, message on stderr. */
+typedef struct rade_multi rade_multi;
+typedef int (*rade_multi_fn)(int i, rade_batch *engine, int first_stream, int n_streams, void *arg);
+rade_multi *rade_multi_open(const char *blob_path, int n_streams_total, int max_tx_mf, unsigned long long device_mask, int flags);
+void rade_multi_close(rade_multi *m);
+int rade_multi_n_devices(const rade_multi *m);
+const char *rade_multi_transport(const rade_multi *m);            /* "rccl" or "none (single device)" */
+rade_batch *rade_multi_engine(rade_multi *m, int i, int *device, int *first_stream, int *n_streams);
+void rade_multi_shard(int n_total, int n_dev, int i, int *first, int *count);      /* the sharding rule, also usable on its own */
+int rade_multi_foreach(rade_multi *m, rade_multi_fn fn, void *arg);
+int rade_multi_allreduce_sum(rade_multi *m, const double *per_device /* [n_dev][n] */, int n, double *out /* [n] */);
 
 /* ---- single-carrier modem for BBFM symbols ------------------------------------------------
  * Batched form of the reference's `single_carrier` class (radae/dsp.py:579-860; drivers sc_tx.py:58-75,

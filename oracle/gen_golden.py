@@ -332,15 +332,15 @@ def gen_knobs():
     tr = run_rx(d["rx_full"])
     np.savez_compressed(os.path.join(OUT, "rxtrace_dfdt.npz"), rx_in=d["rx_full"], features_in=d["features"], **tr)
     print(f"rx dfdt: calls {len(tr['ret'])} valid {int((tr['ret'] & 1).sum())} fmax {tr['fmax'][[10, -3]]}")
-    # --disable_unsync: MPP at 0 dB with a deep fade, unsync paths switched off after 1 s of sync (41 frames at the ctest's 5 s
+    # --disable_unsync: MPP at 0 dB with a deep fade, unsync paths switched off after 0.5 s of sync (41 frames at the ctest's 5 s
     # would outlast a short fixture); the same samples without the flag lose sync, so the pair pins both branches
-    d = channel_case("nounsync", 360, 0.0, -11.0, "mpp", 1012, prepend_s=0.5, append_s=0.3)
+    d = channel_case("nounsync", 504, 0.0, -11.0, "mpp", 1012, prepend_s=0.5, append_s=0.3)
     x = d["rx_full"].copy()
-    n0 = int(0.5 * 8000) + 150 * 80                     # 1.5 s into the signal: 2.6 s of noise only (valid_count runs out after 25 frames)
-    x[n0:n0 + 26 * 960] = d["sigma"] * d["noise"][:26 * 960]
-    tr_on = run_rx(x, disable_unsync=1.0); tr_off = run_rx(x)
+    n0 = int(0.5 * 8000) + 14 * 960                     # 14 frames into the signal: 27 frames of noise only (valid_count runs out after 25)
+    x[n0:n0 + 27 * 960] = d["sigma"] * d["noise"][:27 * 960]
+    tr_on = run_rx(x, disable_unsync=0.5); tr_off = run_rx(x)
     assert not np.array_equal(tr_on["state_after"], tr_off["state_after"]), "fixture does not exercise the flag"
-    np.savez_compressed(os.path.join(OUT, "rxtrace_nounsync.npz"), rx_in=c64(x), features_in=d["features"], disable_unsync=np.float64(1.0), **tr_on)
+    np.savez_compressed(os.path.join(OUT, "rxtrace_nounsync.npz"), rx_in=c64(x), features_in=d["features"], disable_unsync=np.float64(0.5), **tr_on)
     print(f"rx nounsync: states with flag {tr_on['state_after'].tolist()}\n            without {tr_off['state_after'].tolist()}")
 
 

@@ -70,7 +70,7 @@ struct rade *rade_open(char model_file[], int flags)
     const char *path = rd_find_default_model(model_file, buf, sizeof buf);
     if (!path) { fprintf(stderr, "rade_open: no DNNw weight blob found (tried \"%s\", $RADE_MODEL_FILE, weights/model19_check3.bin)\n", model_file ? model_file : ""); return NULL; }
     struct rade *r = calloc(1, sizeof *r);
-    rade_batch_config cfg = { 1, 1, 0, flags, 0 };
+    rade_batch_config cfg = { 1, 1, 0, flags, 0, 0.0f };
     const char *dev = getenv("RADE_DEVICE");
     if (dev) cfg.device = atoi(dev);
     r->eng = rade_batch_open(path, &cfg);

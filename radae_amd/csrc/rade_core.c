@@ -115,7 +115,7 @@ static core_dev *dev_open(const void *blob, int len, int dim)
 {
     core_dev *d = calloc(1, sizeof *d);
     if (!d) return NULL;
-    rade_batch_config cfg = { 1, 1, 0, 0, 0 };
+    rade_batch_config cfg = { 1, 1, 0, 0, 0, 0.0f };
     const char *dv = getenv("RADE_DEVICE");
     if (dv) cfg.device = atoi(dv);
     d->eng = rade_batch_open_mem(blob, (size_t)len, &cfg);

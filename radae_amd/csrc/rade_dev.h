@@ -167,6 +167,7 @@ typedef struct {
     const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
     int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
     int max_calls;                                       /* call budget per stream per invocation */
+    int unsync_off_after;                                /* radae_rxe.py:277-281: synced_count beyond which the unsync paths are disabled; < 0 = never */
     int round_calls, dec_rows;                           /* R calls per stream per launch (<= RD_RX_ROUND_MAX), 3R decoder slots */
     rd_decs_args dec;                                    /* the decoder runs inside the stream's workgroup (rx_decode_pending) */
     float *features_out; long feat_stride;               /* [B][cap][432] */

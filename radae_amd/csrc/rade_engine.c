@@ -33,6 +33,7 @@ typedef struct { float *wp, *bias; unsigned short *wp16; int N, K; } dev_lin;
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
+    int unsync_off_after;                 /* int(disable_unsync * Fs / Nmf) or -1 */
     float *fftG, *ffttw; unsigned short *corr16;
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
@@ -151,6 +152,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h = calloc(1, sizeof *h);
     h->B = cfg->n_streams; h->max_tx_mf = cfg->max_tx_mf; h->device = cfg->device; h->flags = cfg->flags;
     h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
+    h->unsync_off_after = cfg->disable_unsync != 0.0f ? (int)((double)cfg->disable_unsync * 8000.0 / RD_NMF) : -1;    /* radae_rxe.py:279-280 */
     const size_t B = (size_t)h->B, T = (size_t)h->Tcap;
     /* do_radae_rx calls per stream and launch (the per-launch bookkeeping arrays hold RD_RX_ROUND_MAX); RADE_ROUND_CALLS
      * lowers it for tests: the call loop then takes several launches with identical results */
@@ -502,7 +504,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
-    sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows;
+    sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
     sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;

@@ -1730,9 +1730,10 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 } else if (S->candidate && abs(S->tmax - S->tmax_candidate) < RD_NCP) S->valid_count++;
                 else next_state = ST_SEARCH;
             } else {
+                const bool unsync_enable = !(a.unsync_off_after >= 0 && S->synced_count > a.unsync_off_after);     // radae_rxe.py:277-281
                 if (S->candidate) S->valid_count = 25;
-                else { S->valid_count--; if (S->valid_count == 0) next_state = ST_SEARCH; }
-                if (eoo || S->uw_fail) next_state = ST_SEARCH;
+                else { S->valid_count--; if (unsync_enable && S->valid_count == 0) next_state = ST_SEARCH; }
+                if (unsync_enable && (eoo || S->uw_fail)) next_state = ST_SEARCH;
             }
             S->dt_valid = (state != ST_SYNC && next_state != ST_SYNC) ? S->dt_new + 1 : 0;   // next call's Dt1 == this call's Dt2 (buffer dt_new)
             S->state = next_state;

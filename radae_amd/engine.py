@@ -21,7 +21,7 @@ NMF, NEOO, NIN_MAX, FEAT_MF, NEOO_BITS, ZMF = 960, 1152, 1120, 432, 180, 240
 
 
 class BatchConfig(C.Structure):
-    _fields_ = [("n_streams", C.c_int), ("max_tx_mf", C.c_int), ("device", C.c_int), ("flags", C.c_int), ("rx_trace_calls", C.c_int)]
+    _fields_ = [("n_streams", C.c_int), ("max_tx_mf", C.c_int), ("device", C.c_int), ("flags", C.c_int), ("rx_trace_calls", C.c_int), ("disable_unsync", C.c_float)]
 
 
 class ChannelParams(C.Structure):
@@ -88,6 +88,8 @@ EXPORTED_SYMBOLS = [
     "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
+    "rade_multi_open", "rade_multi_close", "rade_multi_n_devices", "rade_multi_transport", "rade_multi_engine", "rade_multi_shard", "rade_multi_foreach",
+    "rade_multi_allreduce_sum",
 ]
 
 
@@ -104,7 +106,7 @@ class BatchEngine:
     """B independent RADE streams on one GPU (one engine per process/GPU)."""
 
     def __init__(self, n_streams: int, max_tx_mf: int = 1, device: int = 0, flags: int = 0, blob: Optional[str] = None,
-                 blob_bytes: Optional[bytes] = None, rx_trace_calls: int = 0):
+                 blob_bytes: Optional[bytes] = None, rx_trace_calls: int = 0, disable_unsync: float = 0.0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("radae_amd.BatchEngine needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU path")
@@ -112,7 +114,7 @@ class BatchEngine:
         self.B = n_streams
         self.device = torch.device("cuda", device)
         self.trace_calls = rx_trace_calls
-        cfg = BatchConfig(n_streams, max_tx_mf, device, flags, rx_trace_calls)
+        cfg = BatchConfig(n_streams, max_tx_mf, device, flags, rx_trace_calls, disable_unsync)
         if blob_bytes is not None:
             buf = C.create_string_buffer(blob_bytes, len(blob_bytes))
             self.h = self.lib.rade_batch_open_mem(C.cast(buf, C.c_void_p), len(blob_bytes), C.byref(cfg))

@@ -83,12 +83,35 @@ def test_core_level_model_init_on_cpu(lib):
         assert L.init_radedec(C.byref(m), lst, good) == 0
 
 
+def test_multi_gpu_sharding_rule(lib):
+    """rade_multi_shard: contiguous ceil(total / n_dev) shards -- config 4: 2048 utterances, GPU g owns [256 g, 256 g + 256) -- and the
+    same rule as the torchrun path's radae_amd.parallel.shard_range; rade_multi_open refuses to run without a GPU."""
+    from radae_amd.parallel import shard_range
+    lib.rade_multi_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]; lib.rade_multi_shard.restype = None
+    for total, ndev in ((2048, 8), (256, 1), (10, 4), (7, 8), (1000, 3)):
+        got = []
+        for i in range(ndev):
+            lo, n = C.c_int(), C.c_int()
+            lib.rade_multi_shard(total, ndev, i, C.byref(lo), C.byref(n))
+            got.append((lo.value, lo.value + n.value))
+        assert got == [shard_range(total, r, ndev) for r in range(ndev)]
+        assert sum(b - a for a, b in got) == total
+    lo, n = C.c_int(), C.c_int()
+    lib.rade_multi_shard(2048, 8, 5, C.byref(lo), C.byref(n))
+    assert (lo.value, n.value) == (1280, 256)
+    import torch
+    if not torch.cuda.is_available():
+        lib.rade_multi_open.restype = C.c_void_p; lib.rade_multi_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_ulonglong, C.c_int]
+        from radae_amd import engine
+        assert not lib.rade_multi_open(engine.DEFAULT_BLOB.encode(), 16, 1, 1, 0)
+
+
 def test_no_cpu_fallback(lib):
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     from radae_amd import engine
-    cfg = engine.BatchConfig(1, 1, 0, 0, 0)
+    cfg = engine.BatchConfig(1, 1, 0, 0, 0, 0.0)
     h = lib.rade_batch_open(engine.DEFAULT_BLOB.encode(), C.byref(cfg))
     assert not h                                     # fails loudly (message on stderr), never computes on the CPU
     with pytest.raises(RuntimeError):

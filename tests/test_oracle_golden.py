@@ -66,12 +66,14 @@ def test_eoo_bits(oracle, oracle_model, golden):
     assert np.abs(tx.eoo() - c["eoo_with_bits"]).max() < 1e-6
 
 
-@pytest.mark.parametrize("name", ["mpp", "awgn"])
+@pytest.mark.parametrize("name", ["mpp", "awgn", "dfdt_pos", "dfdt_neg"])
 def test_channel(oracle, oracle_model, golden, name):
+    """dfdt_*: df_dt = +-0.5 Hz/s (radae.py:547-552, inference.py:270; ctest radae_rx_dfdt): the per-sample float32 omega summed like
+    torch.cumsum, restarted for the EOO frame."""
     g = golden("chan_" + name)
     sigma = float(g["sigma"])
     assert oracle.lib().orc_sigma_from_EbNodB(float(g["EbNodB"])) == pytest.approx(sigma, rel=1e-7)
-    rx, fin = oracle.channel(g["tx"], g["G"], g["noise"], sigma, float(g["freq_offset"]), float(g["df_dt"]))
+    rx, fin = oracle.channel(g["tx"], g["G"] if "G" in g else None, g["noise"], sigma, float(g["freq_offset"]), float(g["df_dt"]))
     assert np.abs(rx - g["rx"]).max() < 2e-6
     assert abs(fin - g["final_phase"].ravel()[0]) < 1e-6
     eoo = oracle.channel_eoo(oracle.Tx(oracle_model).eoo(), g["noise_eoo"], sigma, float(g["freq_offset"]), float(g["df_dt"]), fin)
@@ -79,10 +81,16 @@ def test_channel(oracle, oracle_model, golden, name):
     assert np.abs(full - g["rx_full"]).max() < 5e-6
 
 
-@pytest.mark.parametrize("name", RX_CASES)
+@pytest.mark.parametrize("name", RX_CASES + ["dfdt", "nounsync"])
 def test_rx_trace(oracle, oracle_model, golden, name):
+    """dfdt: a drifting offset (ctest radae_rx_dfdt); nounsync: --disable_unsync (radae_rxe.py:277-281) holding sync through a fade
+    that the same samples lose it in without the flag."""
     g = golden("rxtrace_" + name)
-    d = oracle.run_rx_stream(oracle_model, g["rx_in"], 1, 10.0 if name == "foff" else 0.0)
+    du = float(g["disable_unsync"]) if "disable_unsync" in g else 0.0
+    d = oracle.run_rx_stream(oracle_model, g["rx_in"], 1, 10.0 if name == "foff" else 0.0, du)
+    if du:
+        off = oracle.run_rx_stream(oracle_model, g["rx_in"])
+        assert not np.array_equal(off["state_after"], g["state_after"])        # the flag is what keeps the fixture in sync
     for k in ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]:
         assert np.array_equal(d[k], g[k]), k     # the discrete "indices": bit-exact
     assert np.abs(d["fmax"] - g["fmax"]).max() < 1e-9
