@@ -149,10 +149,12 @@ int rd_launch_multipath_gen(const float *taps_dev, int n_taps, int low_ratio, in
 
 /* CoreDecoderStatefull.forward (radae_base.py:388-430) for the pending rows of one stream, run inside the receiver
  * kernel by the stream's own workgroup (rx_decode_pending -> ds_layers): buffers and weights of that stage. */
-typedef struct { const float *wp, *bias; const unsigned short *wp16; int N, K; } rd_lin;   /* wp16: rd_pack_weights_f16x2 */
+typedef struct { const float *wp, *bias; const unsigned short *wp16, *wa16; const float *wscale; int N, K; } rd_lin;
+/* wp16: rd_pack_weights_f16x2; wa16 (in-kernel decoder): rd_pack_weights_q16_a16 when wscale != NULL (int8-exact layer: one plane of
+ * integers + per-column scales), else rd_pack_weights_f16x2_a16 (two planes) */
 typedef struct {
     const float *z; long z_sb;                 /* [B][.][80] latent rows */
-    float *x; long x_sb;                       /* [B][1 + Tcap][736] DenseNet rows; x points at row 0 of stream 0, row -1 = conv history */
+    float *x; long x_sb;                       /* [B][1 + Tcap][736]; x points at row 0 of stream 0, row -1 = conv history (the in-kernel stage keeps every other row in LDS) */
     float *gi; long gi_sb;                     /* [B][.][288] */
     float *hbuf; long hb_sb;                   /* [B][.][96] */
     float *h[5];                               /* GRU states [B][96] */

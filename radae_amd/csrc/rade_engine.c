@@ -23,7 +23,7 @@
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rade: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); goto fail; } } while (0)
 
-typedef struct { float *wp, *bias; unsigned short *wp16; int N, K; } dev_lin;
+typedef struct { float *wp, *bias; unsigned short *wp16, *wa16; float *wscale; int N, K; } dev_lin;
 
 /* every public entry point runs on its engine's device, whatever device the calling thread had current (one host thread may
  * drive several engines, and an engine may be called from a thread other than the one that opened it) */
@@ -78,7 +78,7 @@ static void *dev_zeros(size_t bytes)
 }
 
 /* pack W[N][K] (optionally padding K up to Kpad with zero columns) and upload */
-static int upload_lin(dev_lin *d, const float *w, const float *b, int N, int K, int Kpad)
+static int upload_lin(dev_lin *d, const float *w, const float *b, const float *row_scale, int N, int K, int Kpad)
 {
     float *wsrc = (float *)w, *tmp = NULL;
     if (Kpad != K) {
@@ -101,6 +101,22 @@ static int upload_lin(dev_lin *d, const float *w, const float *b, int N, int K, 
         }
         d->wp16 = dev_upload(p16, sizeof(unsigned short) * n16);
         free(p16);
+    }
+    d->wa16 = NULL; d->wscale = NULL;
+    if (Kpad % 32 == 0) {                  /* A-operand layout of the in-kernel decoder's 16x16x32 products */
+        const long na = rd_packed16a_size(N, Kpad);
+        unsigned short *pa = malloc(sizeof(unsigned short) * na);
+        float *sc = malloc(sizeof(float) * (size_t)((N + 15) / 16) * 16);
+        long nq = -1;
+        if (pa && sc && row_scale && !getenv("RADE_NO_INT8_EXACT")) nq = rd_pack_weights_q16_a16(wsrc, row_scale, N, Kpad, pa, sc);
+        if (nq > 0) {                      /* int8 in the blob: the integers themselves in ONE binary16 plane (exact), scales apart: half the bytes to stream */
+            d->wa16 = dev_upload(pa, sizeof(unsigned short) * nq);
+            d->wscale = dev_upload(sc, sizeof(float) * (size_t)((N + 15) / 16) * 16);
+        } else {
+            if (!pa || rd_pack_weights_f16x2_a16(wsrc, N, Kpad, pa) < 0) { free(pa); free(sc); free(packed); free(tmp); return -1; }
+            d->wa16 = dev_upload(pa, sizeof(unsigned short) * na);
+        }
+        free(pa); free(sc);
     }
     free(packed); free(tmp);
     return (d->wp && (!b || d->bias)) ? 0 : -1;
@@ -163,7 +179,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
      * left over from before a loss of sync */
     h->dec_rows = getenv("RADE_DEC_ROWS") ? atoi(getenv("RADE_DEC_ROWS")) : 48;
     if (h->dec_rows < 3) h->dec_rows = 3;
-    if (h->dec_rows > RD_DEC_ROWS_MAX) h->dec_rows = RD_DEC_ROWS_MAX;
+    if (h->dec_rows > 63) h->dec_rows = 63;            /* the stage's LDS row flags hold DQ_PEND_MAX = 64 entries (rade_kernels.hip) */
     const size_t DR = (size_t)h->dec_rows;
 
     rd_tables *tab = malloc(sizeof *tab);
@@ -181,16 +197,16 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
-    err |= upload_lin(&h->enc_dense1, m.enc_dense1.w, m.enc_dense1.b, 64, h->feat_in, h->enc_kpad);
-    err |= upload_lin(&h->enc_zdense, m.enc_zdense.w, m.enc_zdense.b, 80, 864, 864);
-    err |= upload_lin(&h->dec_dense1, m.dec_dense1.w, m.dec_dense1.b, 96, 80, 80);
-    err |= upload_lin(&h->dec_output, m.dec_output.w, m.dec_output.b, h->feat_in, 736, 736);
+    err |= upload_lin(&h->enc_dense1, m.enc_dense1.w, m.enc_dense1.b, NULL, 64, h->feat_in, h->enc_kpad);
+    err |= upload_lin(&h->enc_zdense, m.enc_zdense.w, m.enc_zdense.b, NULL, 80, 864, 864);
+    err |= upload_lin(&h->dec_dense1, m.dec_dense1.w, m.dec_dense1.b, NULL, 96, 80, 80);
+    err |= upload_lin(&h->dec_output, m.dec_output.w, m.dec_output.b, NULL, h->feat_in, 736, 736);
     for (int l = 0; l < 5 && !err; l++) {
-        err |= upload_lin(&h->enc_gin[l], m.enc_gru[l].w_ih, m.enc_gru[l].b_ih, 192, ENC_IN[l], ENC_IN[l]);
-        err |= upload_lin(&h->dec_gin[l], m.dec_gru[l].w_ih, m.dec_gru[l].b_ih, 288, DEC_IN[l], DEC_IN[l]);
-        err |= upload_lin(&h->enc_conv[l], m.enc_conv[l].w, m.enc_conv[l].b, 96, m.enc_conv[l].n_in, m.enc_conv[l].n_in);
-        err |= upload_lin(&h->dec_conv[l], m.dec_conv[l].w, m.dec_conv[l].b, 32, m.dec_conv[l].n_in, m.dec_conv[l].n_in);
-        err |= upload_lin(&h->dec_glu[l], m.dec_glu[l].w, NULL, 96, 96, 96);
+        err |= upload_lin(&h->enc_gin[l], m.enc_gru[l].w_ih, m.enc_gru[l].b_ih, m.enc_gru[l].s_ih, 192, ENC_IN[l], ENC_IN[l]);
+        err |= upload_lin(&h->dec_gin[l], m.dec_gru[l].w_ih, m.dec_gru[l].b_ih, m.dec_gru[l].s_ih, 288, DEC_IN[l], DEC_IN[l]);
+        err |= upload_lin(&h->enc_conv[l], m.enc_conv[l].w, m.enc_conv[l].b, m.enc_conv[l].row_scale, 96, m.enc_conv[l].n_in, m.enc_conv[l].n_in);
+        err |= upload_lin(&h->dec_conv[l], m.dec_conv[l].w, m.dec_conv[l].b, m.dec_conv[l].row_scale, 32, m.dec_conv[l].n_in, m.dec_conv[l].n_in);
+        err |= upload_lin(&h->dec_glu[l], m.dec_glu[l].w, NULL, m.dec_glu[l].row_scale, 96, 96, 96);
         h->enc_whh[l] = dev_upload(m.enc_gru[l].w_hh, sizeof(float) * 192 * 64);
         h->enc_bhh[l] = dev_upload(m.enc_gru[l].b_hh, sizeof(float) * 192);
         h->dec_whh[l] = dev_upload(m.dec_gru[l].w_hh, sizeof(float) * 288 * 96);
@@ -261,7 +277,7 @@ rade_batch *rade_batch_open(const char *blob_path, const rade_batch_config *cfg)
     return h;
 }
 
-static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFree(d->bias); if (d->wp16) hipFree(d->wp16); }
+static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFree(d->bias); if (d->wp16) hipFree(d->wp16); if (d->wa16) hipFree(d->wa16); if (d->wscale) hipFree(d->wscale); }
 void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
@@ -463,7 +479,7 @@ static void fill_dec_args(const rade_batch *h, rd_decs_args *d)
     d->gi = h->dec_gi; d->gi_sb = DR * 288; d->hbuf = h->dec_hbuf; d->hb_sb = DR * 96;
     d->out = h->feat84; d->out_sb = DR * h->feat_in; d->out_w = h->feat_in;
     d->B = h->B;
-#define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).wp16 = (src).wp16; (dst).N = (src).N; (dst).K = (src).K; } while (0)
+#define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).wp16 = (src).wp16; (dst).wa16 = (src).wa16; (dst).wscale = (src).wscale; (dst).N = (src).N; (dst).K = (src).K; } while (0)
     LIN(d->dense1, h->dec_dense1); LIN(d->output, h->dec_output);
     for (int l = 0; l < 5; l++) { LIN(d->gin[l], h->dec_gin[l]); LIN(d->glu[l], h->dec_glu[l]); LIN(d->conv[l], h->dec_conv[l]); d->whh[l] = h->dec_whh[l]; d->bhh[l] = h->dec_bhh[l]; d->h[l] = h->dec_h[l]; }
 #undef LIN

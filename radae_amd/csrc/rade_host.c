@@ -125,7 +125,7 @@ static const dnnw_rec *rec_find(const dnnw_rec *r, int n, const char *base, cons
 static int lin_alloc(rd_linear *l)
 {
     if (l->n_in <= 0 || l->n_out <= 0 || l->n_in > 65536 || l->n_out > 65536) return -1;
-    l->b = malloc(sizeof(float) * (size_t)l->n_out); l->w = calloc((size_t)l->n_in * l->n_out, sizeof(float));
+    l->b = malloc(sizeof(float) * (size_t)l->n_out); l->w = calloc((size_t)l->n_in * l->n_out, sizeof(float)); l->row_scale = NULL;
     if (!l->b || !l->w) { free(l->b); free(l->w); l->b = l->w = NULL; return -1; }
     return 0;
 }
@@ -155,6 +155,7 @@ static int dequant_dense_int8(const dnnw_rec *R, int n, const char *name, rd_lin
     if (lin_alloc(l)) return -1;
     memcpy(l->b, b->data, sizeof(float) * l->n_out);
     const float *sc = (const float *)s->data; const signed char *qq = (const signed char *)q->data;
+    if ((l->row_scale = malloc(sizeof(float) * (size_t)l->n_out))) for (int o = 0; o < l->n_out; o++) l->row_scale[o] = sc[o] * 127.0f;
     const int blocks_in = l->n_in / 4;
     size_t pos = 0;                                                  /* walk the [n_out/8][n_in/4][8][4] tiles in storage order */
     for (int og = 0; og < l->n_out / 8; og++)
@@ -192,6 +193,7 @@ static int dequant_blocksparse_int8(const dnnw_rec *R, int n, const char *name, 
     l->n_in = n_in;
     if (lin_alloc(l)) return -1;
     memcpy(l->b, b->data, sizeof(float) * l->n_out);
+    if ((l->row_scale = malloc(sizeof(float) * (size_t)l->n_out))) for (int o = 0; o < l->n_out; o++) l->row_scale[o] = sc[o] * 127.0f;
     size_t pos = 0;
     p = 0;
     for (int g = 0; g < l->n_out / 8; g++) {
@@ -216,11 +218,13 @@ static int load_gru(const dnnw_rec *R, int n, const char *name, rd_gru *g)
 {
     char nm[64]; rd_linear in, rec;
     snprintf(nm, sizeof nm, "%s_input", name); if (dequant_blocksparse_int8(R, n, nm, &in)) return -1;
-    snprintf(nm, sizeof nm, "%s_recurrent", name); if (dequant_dense_int8(R, n, nm, &rec)) { free(in.w); free(in.b); return -1; }
-    if (rec.n_out != 3 * rec.n_in || in.n_out != rec.n_out) { free(in.w); free(in.b); free(rec.w); free(rec.b); return -1; }
-    g->hid = rec.n_in; g->n_in = in.n_in; g->w_ih = in.w; g->b_ih = in.b; g->w_hh = rec.w; g->b_hh = rec.b;
+    snprintf(nm, sizeof nm, "%s_recurrent", name); if (dequant_dense_int8(R, n, nm, &rec)) { free(in.w); free(in.b); free(in.row_scale); return -1; }
+    if (rec.n_out != 3 * rec.n_in || in.n_out != rec.n_out) { free(in.w); free(in.b); free(in.row_scale); free(rec.w); free(rec.b); free(rec.row_scale); return -1; }
+    g->hid = rec.n_in; g->n_in = in.n_in; g->w_ih = in.w; g->b_ih = in.b; g->w_hh = rec.w; g->b_hh = rec.b; g->s_ih = in.row_scale; g->s_hh = rec.row_scale;
     swap_first_two_thirds(g->w_ih, g->hid * g->n_in); swap_first_two_thirds(g->w_hh, g->hid * g->hid);
     swap_first_two_thirds(g->b_ih, g->hid); swap_first_two_thirds(g->b_hh, g->hid);
+    if (g->s_ih) swap_first_two_thirds(g->s_ih, g->hid);
+    if (g->s_hh) swap_first_two_thirds(g->s_hh, g->hid);
     return 0;
 }
 
@@ -267,13 +271,13 @@ int rd_model_parse(const void *blob, size_t len, rd_model *m)
     return 0;
 }
 
-static void lin_free(rd_linear *l) { free(l->w); free(l->b); l->w = l->b = NULL; }
+static void lin_free(rd_linear *l) { free(l->w); free(l->b); free(l->row_scale); l->w = l->b = l->row_scale = NULL; }
 void rd_model_free(rd_model *m)
 {
     lin_free(&m->enc_dense1); lin_free(&m->enc_zdense); lin_free(&m->dec_dense1); lin_free(&m->dec_output);
     for (int i = 0; i < 5; i++) {
-        free(m->enc_gru[i].w_ih); free(m->enc_gru[i].w_hh); free(m->enc_gru[i].b_ih); free(m->enc_gru[i].b_hh);
-        free(m->dec_gru[i].w_ih); free(m->dec_gru[i].w_hh); free(m->dec_gru[i].b_ih); free(m->dec_gru[i].b_hh);
+        free(m->enc_gru[i].w_ih); free(m->enc_gru[i].w_hh); free(m->enc_gru[i].b_ih); free(m->enc_gru[i].b_hh); free(m->enc_gru[i].s_ih); free(m->enc_gru[i].s_hh);
+        free(m->dec_gru[i].w_ih); free(m->dec_gru[i].w_hh); free(m->dec_gru[i].b_ih); free(m->dec_gru[i].b_hh); free(m->dec_gru[i].s_ih); free(m->dec_gru[i].s_hh);
         lin_free(&m->enc_conv[i]); lin_free(&m->dec_conv[i]); lin_free(&m->dec_glu[i]);
     }
     memset(m, 0, sizeof *m);
@@ -351,6 +355,51 @@ long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out)
                     o[0] = hi; o[64 * 8] = lo;
                 }
     return rd_packed16_size(N, K);
+}
+
+/* The receiver's in-kernel decoder (dq_gemm_tile) uses v_mfma_f32_16x16x32_f16 with the weights as the A operand: 16 output
+ * columns x 32 k per instruction, the same two planes of 2^10 w.  K must be a multiple of 32; N is padded to 16 with zeros.
+ * out[ks][ct][plane][lane][j] = plane(1024 W[16 ct + lane%16][32 ks + 8 (lane/16) + j]).  Returns the size or -1 on overflow. */
+long rd_packed16a_size(int N, int K) { return (long)(K / 32) * ((N + 15) / 16) * 2 * 64 * 8; }
+long rd_pack_weights_f16x2_a16(const float *W, int N, int K, unsigned short *out)
+{
+    const int nks = K / 32, nct = (N + 15) / 16;
+    for (int ks = 0; ks < nks; ks++)
+        for (int ct = 0; ct < nct; ct++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int nn = ct * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + j;
+                    const float w = nn < N ? 1024.0f * W[(size_t)nn * K + k] : 0.0f;
+                    if (!(fabsf(w) < 65504.0f)) return -1;
+                    const unsigned short hi = f32_to_f16(w), lo = f32_to_f16(w - f16_to_f32(hi));
+                    unsigned short *o = out + ((((size_t)ks * nct + ct) * 2) * 64 + lane) * 8 + j;
+                    o[0] = hi; o[64 * 8] = lo;
+                }
+    return rd_packed16a_size(N, K);
+}
+
+long rd_pack_weights_q16_a16(const float *W, const float *row_scale, int N, int K, unsigned short *out, float *scale_out)
+{
+    const int nks = K / 32, nct = (N + 15) / 16;
+    if (!row_scale) return -1;
+    for (int n = 0; n < nct * 16; n++) scale_out[n] = n < N ? row_scale[n] : 0.0f;
+    for (int ks = 0; ks < nks; ks++)
+        for (int ct = 0; ct < nct; ct++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int nn = ct * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4) + j;
+                    float q = 0.0f;
+                    if (nn < N) {
+                        const float w = W[(size_t)nn * K + k];
+                        if (w != 0.0f) {
+                            if (row_scale[nn] == 0.0f) return -1;
+                            q = rintf(w / row_scale[nn]);
+                            if (!(fabsf(q) <= 127.0f) || q * row_scale[nn] != w) return -1;      /* not an int8-exact layer after all */
+                        }
+                    }
+                    out[(((size_t)ks * nct + ct) * 64 + lane) * 8 + j] = f32_to_f16(q);
+                }
+    return (long)nks * nct * 64 * 8;
 }
 
 /* check_pilots rows on the f16 matrix cores: the realified pilot table Pm[n = 2f + c', k = 2m + c] = {pr, pi; pi, -pr}[c'][c]

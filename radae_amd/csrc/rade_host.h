@@ -10,8 +10,8 @@
 extern "C" {
 #endif
 
-typedef struct { int n_in, n_out; float *w, *b; } rd_linear;                 /* w[out][in] row-major */
-typedef struct { int n_in, hid; float *w_ih, *w_hh, *b_ih, *b_hh; } rd_gru; /* torch gate order r,z,n */
+typedef struct { int n_in, n_out; float *w, *b; float *row_scale; } rd_linear;   /* w[out][in] row-major; row_scale[out] != NULL: the layer is int8 in the blob, w[o][i] = q * row_scale[o] with integer |q| <= 127 */
+typedef struct { int n_in, hid; float *w_ih, *w_hh, *b_ih, *b_hh; float *s_ih, *s_hh; } rd_gru; /* torch gate order r,z,n; s_*: row scales of the int8 weights */
 
 typedef struct {
     rd_linear enc_dense1, enc_zdense, dec_dense1, dec_output;
@@ -31,6 +31,11 @@ void rd_fft_tables_fill(const rd_tables *T, float *G, float *tw);
 long rd_packed16_size(int N, int K);
 void rd_corr16_table_fill(const rd_tables *T, unsigned short *out);
 long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out);
+long rd_packed16a_size(int N, int K);
+/* int8-exact layers: ONE binary16 plane holding the integers q (exact), out[K/32][ceil(N/16)][64][8]; scale_out[16 ceil(N/16)] = row scale (0 past N).
+ * Returns the plane's size in halfs, or -1 when W is not q * row_scale with integer |q| <= 127. */
+long rd_pack_weights_q16_a16(const float *W, const float *row_scale, int N, int K, unsigned short *out, float *scale_out);
+long rd_pack_weights_f16x2_a16(const float *W, int N, int K, unsigned short *out);
 #ifdef __cplusplus
 }
 #endif

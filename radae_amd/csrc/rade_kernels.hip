@@ -115,10 +115,10 @@ __device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __bui
 __device__ __forceinline__ float2 ld2(const float (*p)[2], int i) { return make_float2(p[i][0], p[i][1]); }
 
 #ifdef RD_PHASE_TIMING   // developer aid: per-phase shader-clock totals of workgroup 0 (make EXTRA=-DRD_PHASE_TIMING)
-__device__ long long g_phase_cycles[24];
+__device__ long long g_phase_cycles[32];
 #define PH_T0() long long ph_t_ = clock64()
 #define PH(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); atomicAdd((unsigned long long *)&g_phase_cycles[i], (unsigned long long)(n_ - ph_t_)); ph_t_ = n_; } } while (0)
-extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 24); long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
+extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), sizeof(long long) * 32); long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z); }
 #else
 #define PH_T0() do { } while (0)
 #define PH(i) do { } while (0)
@@ -506,216 +506,233 @@ extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
 
 // =====================================================================================================
 // Per-stream decoder stage of the receiver kernel: the whole DenseNet stack for one stream's pending rows, run by the
-// stream's own workgroup of eight wavefronts.  GEMMs split K over the waves (k-blocks interleaved, partials reduced
-// in wave order through LDS), the recurrences run as in k_gru_scan<96>.
+// stream's own workgroup of eight wavefronts with every activation RESIDENT IN LDS.  Only the weights stream in (from L2);
+// nothing the stage produces goes through HBM except the 84-float output rows and the one conv-history row.
+//
+//  * rows are processed in chunks of DQ_ROWS = 24 (the eight modem frames between two unique-word checks);
+//  * the DenseNet rows x[t][0..735] live as two binary16 planes (x * 2^8 = hi + lo, 22 bits), written once by each layer's
+//    epilogue, so the matrix-core operands are read from LDS ready-made (no conversion in the product loops).  A row is 96
+//    blocks of 8 halfs (92 used, 1536 B = a multiple of the 256-byte bank width) and block c of logical row t sits at
+//    c ^ (t & 15): the 16-byte operand reads of v_mfma_f32_16x16x32_f16 (lane = row t, k-slice c) are bank-conflict free;
+//  * products run as v_mfma_f32_16x16x32_f16 with the WEIGHTS as the A operand (16 output columns) and the rows as the B
+//    operand (two 16-row tiles share every weight fragment), three products per k-step (lo*hi + hi*lo + hi*hi).  One
+//    wavefront owns a column tile over the whole K: no split-K, no reduction scratch, no barrier inside a product;
+//  * narrow layers would leave wavefronts idle (conv: 32 columns = 2 tiles), so each conv runs in the same phase as the
+//    part of the NEXT layer's input projection that does not need its output (K = the columns already final); a one-k-step
+//    fix-up product then adds the 32 new columns.  The 84-float output layer is treated the same way behind the last conv.
 // =====================================================================================================
-#define DS_NT 3
+#define NT_RX 512                // threads of the receiver workgroup (k_rx_sync)
+#define DQ_ROWS 24
+#define DQ_XB 96                 // 8-half blocks per x row
+#define DQ_HB 16                 // blocks per GRU-output row (12 used)
+#define DQ_PEND_MAX 64           // pending rows a stream can hold (engine: dec_rows <= 63)
 struct DecShared {
-    float red[SK_WAVES][DS_NT][16][64];      // 96 KB split-K partials
+    __attribute__((aligned(16))) _Float16 xh[DQ_ROWS + 2][DQ_XB * 8];    // physical row 0: conv history (the row before this chunk), 1..24: the chunk, 25: zeros
+    __attribute__((aligned(16))) _Float16 xl[DQ_ROWS + 2][DQ_XB * 8];
+    __attribute__((aligned(16))) float gi[DQ_ROWS][288];                 // GRU input projections of the layer being scanned; staging of the output layer
+    __attribute__((aligned(16))) _Float16 hbh[DQ_ROWS][DQ_HB * 8], hbl[DQ_ROWS][DQ_HB * 8];   // clamp(h_t) of the layer just scanned
     __attribute__((aligned(16))) float hs[2][96];
-    int rst[RD_DEC_ROWS_MAX];
-    int err[RD_DEC_ROWS_MAX];                // receiver: aux-bit (UW) decisions of the decoded rows
+    int rst[DQ_PEND_MAX];
+    int err[DQ_PEND_MAX];                    // receiver: aux-bit (UW) decisions of the decoded rows
+};
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// half index of x[logical row t][col] inside a plane; the history row is logical -1 (swizzle key 15), the zero row needs no key
+__device__ __forceinline__ int dq_xoff(int t, int col) { return (t + 1) * (DQ_XB * 8) + ((((col >> 3) ^ (t & 15)) << 3) | (col & 7)); }
+__device__ __forceinline__ int dq_hoff(int t, int col) { return t * (DQ_HB * 8) + ((((col >> 3) ^ (t & 15)) << 3) | (col & 7)); }
+// v in [-1, 1] -> the two planes of 2^8 v
+__device__ __forceinline__ void dq_split(float v, _Float16 &hi, _Float16 &lo) { const float x = 256.0f * v; hi = (_Float16)x; lo = (_Float16)(x - (float)hi); }
+
+enum { DQ_OUT_X = 0, DQ_OUT_GI = 1, DQ_OUT_GLOBAL = 2 };
+struct DqGemm {
+    const unsigned short *wa; int nct;     // rd_pack_weights_f16x2_a16: [K/32][nct][2 planes][64 lanes][8]
+    const float *bias; int N;              // bias may be null; N = valid output columns
+    const float *wscale;                   // non-null: int8-exact layer, ONE plane of integers, wscale[n] = the column's scale; null: two planes of 2^10 w
+    int from_hb;                           // B operand: 0 = the x planes, 1 = the GRU-output planes
+    int ktap;                              // k-steps [0, ktap) read the PREVIOUS row (conv tap 0), the rest the row itself
+    int ks0, nks;                          // k-steps of the weight's K axis this product covers
+    int init_gi;                           // accumulators start from gi[t][n] (fix-up products) instead of zero
+    int out, ocol, act;                    // DQ_OUT_*; first x column (DQ_OUT_X); act 0 none, 1 tanh+clamp, 2 GLU
+    float *gout; int gstride;              // DQ_OUT_GLOBAL
 };
 
-// Y[t, n] = act(sum_k [a0 | a1][t, k] W[n, k] + bias[n]) for t < Tb; a0 (K0 floats, may be 0) is the previous row's tap.
-// f16 matrix cores with both operands split in two binary16 planes (v = hi + lo, 22 bits):
-// acc += A_hi B_hi + A_hi B_lo + A_lo B_hi per 16-deep k-block (the dropped lo*lo term is 2^-22 relative; products
-// are exact, accumulation is f32 as before).  v_mfma_f32_32x32x16_f16 moves 16 k per 8 passes where the f32
-// instruction moves 2 per 16, so the three products cost a fifth of the f32 time.  The activations are split on the
-// fly (VALU, overlapped with the matrix pipe); the weights come pre-split from rd_pack_weights_f16x2.
+// one column tile (16 outputs) of a product for rows [0, Tb): see the notes above.  D k-steps of weights are in flight.
+// A real function (one copy, its own register allocation, five call sites): arguments arrive in vector registers and as
+// generic pointers, so everything wave-uniform is moved to scalar registers first and the pointers get their address spaces
+// back -- otherwise the weight loads become flat_load, which count on BOTH wait counters: every LDS wait would then also
+// wait for the weight prefetch it is supposed to run under.
+typedef __attribute__((address_space(3))) _Float16 lds_half;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(1))) const unsigned short glb_u16;
+typedef __attribute__((address_space(1))) const float glb_cf32;
+typedef __attribute__((address_space(1))) float glb_f32;
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+}
+#ifndef DQ_TILE_INLINE
+#define DQ_TILE_INLINE __forceinline__
+#endif
+// NT adjacent column tiles (16 outputs each) of a product for rows [0, Tb), one wavefront, the whole K: every row fragment read
+// from LDS feeds NT weight fragments, D k-steps of weights (NT KB per plane each) are in flight, and the pipeline fills once per
+// call -- with one tile per call the first round trip to L2 of every tile was most of its time.
 template <int NT>
-__device__ void ds_gemm16(DecShared *sh, int tid, const float *a1, int a1_st, int K1, const float *a0, int a0_st, int K0, const int *rst,
-                          const rd_lin w, float *y, int y_st, int act, int Tb, int nt_begin = 0, int nt_end = 1 << 20)
+__device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh_, const DqGemm g_, int ct_, int Tb_, unsigned rstmask_)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
-    const int ntt = (w.N + 31) >> 5;
-    const int nkb0 = K0 >> 4, nkb = nkb0 + (K1 >> 4);
-    const size_t wstep = (size_t)ntt * 2 * 64 * 8;                 // halfs per k-block
-    for (int r0 = 0; r0 < Tb; r0 += 32) {
-        const int t = min(r0 + (lane & 31), Tb - 1);
-        const float *p1 = a1 + (size_t)t * a1_st + 8 * half;
-        const float *p0 = nullptr;
-        if (K0) p0 = ((rst && rst[t]) ? g_zero_row : a0 + (size_t)t * a0_st) + 8 * half;
-        for (int nt0 = nt_begin; nt0 < min(ntt, nt_end); nt0 += NT) {
-            f32x16 acc[NT];
+    constexpr int D = NT == 1 ? 8 : 4;                                 // k-steps of weights in flight
+    const int ct = uni(ct_), Tb = uni(Tb_); const unsigned rstmask = (unsigned)uni((int)rstmask_);
+    const int nct = uni(g_.nct), N = uni(g_.N), from_hb = uni(g_.from_hb), ktap = uni(g_.ktap), ks0 = uni(g_.ks0), nks = uni(g_.nks), init_gi = uni(g_.init_gi),
+              outk = uni(g_.out), ocol = uni(g_.ocol), act = uni(g_.act), gstride = uni(g_.gstride);
+    DecShared *sh = uni_ptr(sh_);
+    glb_u16 *wbase = (glb_u16 *)uni_ptr(g_.wa); glb_cf32 *biasp = (glb_cf32 *)uni_ptr(g_.bias); glb_f32 *gout = (glb_f32 *)uni_ptr(g_.gout);
+    glb_cf32 *wscale = (glb_cf32 *)uni_ptr(g_.wscale);
+    const bool single = wscale != nullptr;                             // int8-exact layer: one plane of integers
+    const int lane = threadIdx.x & 63, t = lane & 15, gq = lane >> 4;
+    const bool two = Tb > 16;
+    const int r0 = min(t, Tb - 1), r1 = min(16 + t, Tb - 1);          // rows beyond Tb repeat the last one (results dropped)
+    const lds_half *bh = (const lds_half *)(from_hb ? &sh->hbh[0][0] : &sh->xh[0][0]), *bl = (const lds_half *)(from_hb ? &sh->hbl[0][0] : &sh->xl[0][0]);
+    const int stride = from_hb ? DQ_HB * 8 : DQ_XB * 8;
+    // tap 1: physical row 1 + r (x) / r (hb), key r & 15;  tap 0: physical row r = logical r - 1, key (r - 1) & 15, or the zero row
+    const int p1a = (from_hb ? r0 : r0 + 1) * stride, p1b = (from_hb ? r1 : r1 + 1) * stride, k1a = r0 & 15, k1b = r1 & 15;
+    const int p0a = ((rstmask >> r0) & 1u) ? (DQ_ROWS + 1) * stride : r0 * stride, p0b = ((rstmask >> r1) & 1u) ? (DQ_ROWS + 1) * stride : r1 * stride;
+    const int k0a = (r0 - 1) & 15, k0b = (r1 - 1) & 15;
+    const int planes = single ? 1 : 2;
+    glb_u16 *wa = wbase + (((size_t)ks0 * nct + ct) * planes * 64 + lane) * 8;
+    const size_t wstep = (size_t)nct * planes * 64 * 8, tstep = (size_t)planes * 64 * 8;
+    lds_f32 *gi = (lds_f32 *)&sh->gi[0][0];
+    f32x4 acc0[NT], acc1[NT];
 #pragma unroll
-            for (int i = 0; i < NT; i++)
+    for (int i = 0; i < NT; i++) { acc0[i] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; acc1[i] = acc0[i]; }
+    const int n0 = 16 * ct + 4 * gq;                                   // this lane's four output columns of tile 0 (tile i: + 16 i)
+    // bias and column scales: fetched now, used after the k loop (a load issued in the epilogue is one more exposed round trip per call)
+    f32x4 bias[NT], scl[NT];
 #pragma unroll
-                for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
-            const unsigned short *wbase = w.wp16 + ((size_t)nt0 * 2 * 64 + lane) * 8;
-            float biasv[NT];                                           // fetched now, used after the k loop and the reduction
+    for (int i = 0; i < NT; i++) {
+        bias[i] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; scl[i] = (f32x4){ 0x1p-18f, 0x1p-18f, 0x1p-18f, 0x1p-18f };      // two planes: 2^8 (rows) x 2^10 (weights)
+        if (biasp && !init_gi) {
 #pragma unroll
-            for (int i = 0; i < NT; i++) { const int col = (nt0 + i) * 32 + (lane & 31); biasv[i] = (w.bias && nt0 + i < ntt && col < w.N) ? w.bias[col] : 0.0f; }
-            f32x4 a_lo4 = { 0.0f, 0.0f, 0.0f, 0.0f }, a_hi4 = a_lo4;   // this block's 8 activations (f32)
-            f16x8 bh[NT], bl[NT];
-            auto fetch = [&](int kb) {
-                const float *p = kb < nkb0 ? p0 + kb * 16 : p1 + (kb - nkb0) * 16;
-                a_lo4 = *(const f32x4 *)p; a_hi4 = *(const f32x4 *)(p + 4);
+            for (int r = 0; r < 4; r++) bias[i][r] = n0 + 16 * i + r < N ? biasp[n0 + 16 * i + r] : 0.0f;
+        }
+        if (single) scl[i] = *(const __attribute__((address_space(1))) f32x4 *)(wscale + n0 + 16 * i) * 0x1p-8f;    // integers x column scale, rows carry 2^8
+    }
+    typedef const __attribute__((address_space(1))) f16x8 glb_f16x8;
+    typedef const __attribute__((address_space(3))) f16x8 lds_f16x8;
+    f16x8 wh[D][NT], wl[D][NT];
+    auto fetch = [&](int d, int ks) {                                  // k-steps past the end re-read the last one; their products are skipped
+        const int kq = min(ks, nks - 1);
 #pragma unroll
-                for (int i = 0; i < NT; i++) {
-                    if (nt0 + i < ntt) { bh[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8); bl[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8 + 64 * 8); }
-                    else { bh[i] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; bl[i] = bh[i]; }
-                }
-            };
-            if (wave < nkb) fetch(wave);
+        for (int i = 0; i < NT; i++) {
+            wh[d][i] = *(glb_f16x8 *)(wa + kq * wstep + i * tstep);
+            if (!single) wl[d][i] = *(glb_f16x8 *)(wa + kq * wstep + i * tstep + 64 * 8);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; d++) fetch(d, d);
 #pragma unroll 1
-            for (int kb = wave; kb < nkb; kb += SK_WAVES) {
-                f16x8 ah, al;
+    for (int ks = 0; ks < nks; ks += D) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float x = 256.0f * (j < 4 ? a_lo4[j] : a_hi4[j - 4]);   // 2^8 x 2^10 (packed W), undone in the epilogue
-                    const _Float16 hi = (_Float16)x;
-                    ah[j] = hi; al[j] = (_Float16)(x - (float)hi);
-                }
-                f16x8 ch[NT], cl[NT];
-#pragma unroll
-                for (int i = 0; i < NT; i++) { ch[i] = bh[i]; cl[i] = bl[i]; }
-                if (kb + SK_WAVES < nkb) fetch(kb + SK_WAVES);                 // next block's loads fly during the matrix instructions
-                __builtin_amdgcn_sched_barrier(0);
+        for (int d = 0; d < D; d++) {
+            if (ks + d < nks) {                                        // uniform
+                const int kk = ks0 + ks + d;
+                const bool tap0 = kk < ktap;
+                const int cb = 4 * (tap0 ? kk : kk - ktap) + gq;
+                const int oa = (tap0 ? p0a : p1a) + ((cb ^ (tap0 ? k0a : k1a)) << 3), ob = (tap0 ? p0b : p1b) + ((cb ^ (tap0 ? k0b : k1b)) << 3);
+                const f16x8 xha = *(lds_f16x8 *)(bh + oa), xla = *(lds_f16x8 *)(bl + oa);
+                f16x8 xhb = xha, xlb = xla;
+                if (two) { xhb = *(lds_f16x8 *)(bh + ob); xlb = *(lds_f16x8 *)(bl + ob); }
 #pragma unroll
                 for (int i = 0; i < NT; i++) {
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ch[i], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cl[i], acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ch[i], acc[i], 0, 0, 0);
+                    if (!single) {
+                        acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][i], xha, acc0[i], 0, 0, 0);
+                        if (two) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][i], xhb, acc1[i], 0, 0, 0);
+                    }
+                    acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xla, acc0[i], 0, 0, 0);
+                    if (two) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xlb, acc1[i], 0, 0, 0);
+                    acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xha, acc0[i], 0, 0, 0);
+                    if (two) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xhb, acc1[i], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                fetch(d, ks + d + D);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    }
+    // C layout: column = lane & 15 (row t), registers r = outputs n0 + r
+    lds_half *xh = (lds_half *)&sh->xh[0][0], *xl = (lds_half *)&sh->xl[0][0];
+    const lds_half *hbh = (const lds_half *)&sh->hbh[0][0], *hbl = (const lds_half *)&sh->hbl[0][0];
+    typedef __attribute__((address_space(3))) f16x4 lds_f16x4;
 #pragma unroll
-            for (int i = 0; i < NT; i++)
+    for (int i = 0; i < NT; i++) {
+        const int n = n0 + 16 * i;
 #pragma unroll
-                for (int j = 0; j < 16; j++) sh->red[wave][i][j][lane] = acc[i][j];
-            __syncthreads();
+        for (int rt = 0; rt < 2; rt++) {
+            const int tt = 16 * rt + t;
+            if (tt >= Tb || (rt && !two)) continue;
+            f32x4 v = (rt ? acc1[i] : acc0[i]) * scl[i] + bias[i];
+            if (init_gi) v += *(const __attribute__((address_space(3))) f32x4 *)(gi + tt * 288 + n);          // fix-up product: onto the staged sums
+            if (outk == DQ_OUT_GI) { *(__attribute__((address_space(3))) f32x4 *)(gi + tt * 288 + n) = v; continue; }
+            if (outk == DQ_OUT_GLOBAL) {
 #pragma unroll
-            for (int i = 0; i < NT; i++) {
-                const int col = (nt0 + i) * 32 + (lane & 31);
-                if (nt0 + i >= ntt || col >= w.N) continue;
-                const float bias = biasv[i];
-#pragma unroll
-                for (int jj = 0; jj < 2; jj++) {
-                    const int j = wave * 2 + jj;
-                    float v = 0.0f;
-#pragma unroll
-                    for (int ww = 0; ww < SK_WAVES; ww++) v += sh->red[ww][i][j][lane];
-                    const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
-                    if (tt >= Tb) continue;
-                    v = v * 0x1p-18f + bias;
-                    if (act == 1) v = clamp1(gate_tanh(v));               // libm tanhf / expf here cost a third of the decoder GEMM time
-                    else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * gate_sigmoid(v));
-                    y[(size_t)tt * y_st + col] = v;
-                }
+                for (int r = 0; r < 4; r++) if (n + r < N) gout[(size_t)tt * gstride + n + r] = v[r];
+                continue;
             }
-            __syncthreads();
+            if (act == 2) {                                             // GLU: x * sigmoid(W x), x = the GRU output of the same row / column
+                const f16x4 hh = *(const lds_f16x4 *)(hbh + dq_hoff(tt, n)), hl = *(const lds_f16x4 *)(hbl + dq_hoff(tt, n));
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = clamp1(((float)hh[r] + (float)hl[r]) * 0x1p-8f * gate_sigmoid(v[r]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = clamp1(gate_tanh(v[r]));
+            }
+            f16x4 oh, ol;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { _Float16 a, b; dq_split(v[r], a, b); oh[r] = a; ol[r] = b; }
+            *(lds_f16x4 *)(xh + dq_xoff(tt, ocol + n)) = oh; *(lds_f16x4 *)(xl + dq_xoff(tt, ocol + n)) = ol;
         }
     }
 }
 
-// Wide outputs (the GRU input projection, N = 288 = 9 column tiles): wave w owns column tile w with the whole K, so nothing is
-// reduced through LDS and no barrier falls inside the product; with a single 32x32 accumulator the wave can keep D k-blocks
-// of operands in flight, which is what the L2-latency-bound loop needs.  Tiles beyond the eighth go through ds_gemm16.
-template <int D>
-__device__ void ds_gemm16_cols(const float *a1, int a1_st, int K1, const rd_lin w, float *y, int y_st, int act, int Tb)
+// dense1 (K = 80 -> 96 columns) on the f32 matrix cores (v_mfma_f32_32x32x2_f32, weights from rd_pack_weights): its input
+// z_hat = symbol / pilot magnitude is the one operand of the stack that is not bounded -- a deep fade or a false sync can push
+// it past the +-255.9 the 2^8-scaled binary16 planes hold, an overflow there turns into inf - inf = NaN in the accumulators
+// and poisons the GRU state until the next reset, where the reference computes a finite value that tanh squashes.
+__device__ void dq_dense1(DecShared *sh, const float *z, const rd_lin w, int Tb)
 {
+    constexpr int NKB = RD_LATENT / 8;
     const int lane = threadIdx.x & 63, nt = threadIdx.x >> 6, half = lane >> 5;
-    const int ntt = (w.N + 31) >> 5, nkb = K1 >> 4;
-    if (nt >= ntt) return;
-    const size_t wstep = (size_t)ntt * 2 * 64 * 8;
-    const unsigned short *wbase = w.wp16 + ((size_t)nt * 2 * 64 + lane) * 8;
-    const int col = nt * 32 + (lane & 31);
-    const float bias = (w.bias && col < w.N) ? w.bias[col] : 0.0f;
-    for (int r0 = 0; r0 < Tb; r0 += 32) {
-        const int t = min(r0 + (lane & 31), Tb - 1);
-        const float *p1 = a1 + (size_t)t * a1_st + 8 * half;
-        f32x16 acc;
-#pragma unroll
-        for (int j = 0; j < 16; j++) acc[j] = 0.0f;
-        f32x4 av[D][2]; f16x8 bh[D], bl[D];
-        auto fetch = [&](int d, int kb) {
-            if (kb < nkb) {
-                av[d][0] = *(const f32x4 *)(p1 + kb * 16); av[d][1] = *(const f32x4 *)(p1 + kb * 16 + 4);
-                bh[d] = *(const f16x8 *)(wbase + kb * wstep); bl[d] = *(const f16x8 *)(wbase + kb * wstep + 64 * 8);
-            } else { bh[d] = (f16x8){0, 0, 0, 0, 0, 0, 0, 0}; bl[d] = bh[d]; av[d][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; av[d][1] = av[d][0]; }
-        };
-#pragma unroll
-        for (int d = 0; d < D; d++) fetch(d, d);
-#pragma unroll 1
-        for (int kb = 0; kb < nkb; kb += D) {          // k-blocks past the end contribute zeros
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                f16x8 ah, al;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float x = 256.0f * av[d][j >> 2][j & 3];
-                    const _Float16 hi = (_Float16)x;
-                    ah[j] = hi; al[j] = (_Float16)(x - (float)hi);
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[d], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[d], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[d], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(d, kb + d + D);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (col < w.N) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
-                if (tt >= Tb) continue;
-                float v = acc[j] * 0x1p-18f + bias;
-                if (act == 1) v = clamp1(gate_tanh(v));
-                else if (act == 2) v = clamp1(a1[(size_t)tt * a1_st + col] * gate_sigmoid(v));
-                y[(size_t)tt * y_st + col] = v;
-            }
-        }
-    }
-}
-
-// The same product on the f32 matrix cores (v_mfma_f32_32x32x2_f32, weights from rd_pack_weights) for the one layer whose
-// input is not bounded: dense1 reads z_hat = symbol / pilot magnitude, which a deep fade or a false sync can push past the
-// +-255.9 the 2^8-scaled binary16 planes hold (an overflow there turns into inf - inf = NaN in the accumulators and poisons
-// the GRU state until the next reset; the reference computes a finite value that tanh squashes).  K = 80, N = 96: the f32
-// instruction's 16/3 lower rate costs ~2 k cycles per decoder batch.  NKB = K / 8 k-blocks, all loads issued up front.
-template <int NKB>
-__device__ void ds_gemm32_cols(const float *a1, int a1_st, const rd_lin w, float *y, int y_st, int act, int Tb)
-{
-    const int lane = threadIdx.x & 63, nt = threadIdx.x >> 6, half = lane >> 5;
-    const int ntt = (w.N + 31) >> 5;
-    if (nt >= ntt) return;
+    if (nt >= 3) return;
     const float *wp = w.wp + ((size_t)nt * 64 + lane) * 4;
-    const size_t wstep = (size_t)ntt * 256;
+    const size_t wstep = (size_t)3 * 256;
     const int col = nt * 32 + (lane & 31);
-    const float bias = (w.bias && col < w.N) ? w.bias[col] : 0.0f;
-    for (int r0 = 0; r0 < Tb; r0 += 32) {
-        const int t = min(r0 + (lane & 31), Tb - 1);
-        const float *p1 = a1 + (size_t)t * a1_st + 4 * half;
-        f32x4 av[NKB], bv[NKB];
+    const float bias = w.bias[col];
+    const int t = min(lane & 31, Tb - 1);
+    const float *p1 = z + (size_t)t * RD_LATENT + 4 * half;
+    f32x4 av[NKB], bv[NKB];
 #pragma unroll
-        for (int kb = 0; kb < NKB; kb++) { av[kb] = *(const f32x4 *)(p1 + kb * 8); bv[kb] = *(const f32x4 *)(wp + kb * wstep); }
-        f32x16 acc;
+    for (int kb = 0; kb < NKB; kb++) { av[kb] = *(const f32x4 *)(p1 + kb * 8); bv[kb] = *(const f32x4 *)(wp + kb * wstep); }
+    f32x16 acc;
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[j] = 0.0f;
+    for (int j = 0; j < 16; j++) acc[j] = 0.0f;
 #pragma unroll
-        for (int kb = 0; kb < NKB; kb++)
+    for (int kb = 0; kb < NKB; kb++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb][s], bv[kb][s], acc, 0, 0, 0);
-        if (col < w.N) {
+        for (int s = 0; s < 4; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kb][s], bv[kb][s], acc, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int tt = r0 + (j & 3) + 8 * (j >> 2) + 4 * half;
-                if (tt >= Tb) continue;
-                float v = acc[j] + bias;
-                if (act == 1) v = clamp1(gate_tanh(v));
-                y[(size_t)tt * y_st + col] = v;
-            }
-        }
+    for (int j = 0; j < 16; j++) {
+        const int tt = (j & 3) + 8 * (j >> 2) + 4 * half;
+        if (tt >= Tb) continue;
+        _Float16 a, b; dq_split(clamp1(gate_tanh(acc[j] + bias)), a, b);
+        sh->xh[0][dq_xoff(tt, col)] = a; sh->xl[0][dq_xoff(tt, col)] = b;
     }
 }
 
-// GRU recurrence over Tb steps (k_gru_scan<96> inside a 512-thread workgroup: threads >= 384 only keep the barriers)
-__device__ void ds_scan(DecShared *sh, int tid, const float *gi_, int gi_st, const float *Whh, const float *bhh, float *hstate, float *out, int out_st, bool use_rst, int Tb)
+// GRU recurrence over Tb steps: four lanes per hidden unit (threads >= 384 only keep the barriers), gi and the outputs in LDS
+__device__ void dq_scan(DecShared *sh, const float *Whh, const float *bhh, float *hstate, int Tb, unsigned rstmask)
 {
     constexpr int H = 96, KP = H / 4;
-    tid = rx_tid();
+    const int tid = rx_tid();
     const bool on = tid < 4 * H;
     const int j = on ? tid >> 2 : 0, p = tid & 3;
     float wr[KP], wz[KP], wn[KP];
@@ -731,29 +748,32 @@ __device__ void ds_scan(DecShared *sh, int tid, const float *gi_, int gi_st, con
     const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
     float hj = hstate[j];
     if (on && p == 0) sh->hs[0][j] = hj;
-    const float *gi = gi_ + (p < 3 ? p * H + j : j);
-    float g0 = 0.0f, g1 = 0.0f;
-    if (Tb > 0) g0 = gi[0];
-    if (Tb > 1) g1 = gi[gi_st];
+    const float *gi = &sh->gi[0][0] + (p < 3 ? p * H + j : j);
+    float g0 = gi[0];
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < Tb; t++) {
-        if (use_rst && sh->rst[t]) {                   // uniform over the workgroup
+        if ((rstmask >> t) & 1u) {                     // uniform over the workgroup
             hj = 0.0f;
             __syncthreads();
             if (on && p == 0) sh->hs[cur][j] = 0.0f;
             __syncthreads();
         }
-        float g2 = 0.0f;
-        if (t + 2 < Tb) g2 = gi[(size_t)(t + 2) * gi_st];
-        float sr = 0.0f, sz = 0.0f, sn = 0.0f;
+        const float g1 = gi[(size_t)min(t + 1, Tb - 1) * 288];           // next step's input: its LDS latency hides under this step
+        // six independent accumulation chains (two per gate): the step is a chain of dependent instructions on a wavefront
+        // that shares its SIMD with at most one other, so the length of the longest chain is the step's time
+        float sr = 0.0f, sz = 0.0f, sn = 0.0f, sr2 = 0.0f, sz2 = 0.0f, sn2 = 0.0f;
         const float *hp = sh->hs[cur] + p * KP;
 #pragma unroll
-        for (int k = 0; k < KP; k += 4) {
-            const f32x4 hv = *(const f32x4 *)(hp + k);
+        for (int k = 0; k < KP; k += 8) {
+            const f32x4 hv = *(const f32x4 *)(hp + k), hw = *(const f32x4 *)(hp + k + 4);
 #pragma unroll
-            for (int u = 0; u < 4; u++) { sr += wr[k + u] * hv[u]; sz += wz[k + u] * hv[u]; sn += wn[k + u] * hv[u]; }
+            for (int u = 0; u < 4; u++) {
+                sr += wr[k + u] * hv[u]; sz += wz[k + u] * hv[u]; sn += wn[k + u] * hv[u];
+                sr2 += wr[k + 4 + u] * hw[u]; sz2 += wz[k + 4 + u] * hw[u]; sn2 += wn[k + 4 + u] * hw[u];
+            }
         }
+        sr += sr2; sz += sz2; sn += sn2;
         sr += quad_dpp<QUAD_XOR1>(sr); sz += quad_dpp<QUAD_XOR1>(sz); sn += quad_dpp<QUAD_XOR1>(sn);
         sr += quad_dpp<QUAD_XOR2>(sr); sz += quad_dpp<QUAD_XOR2>(sz); sn += quad_dpp<QUAD_XOR2>(sn);
         const float gr = quad_dpp<QUAD_BC0>(g0), gz = quad_dpp<QUAD_BC1>(g0), gn = quad_dpp<QUAD_BC2>(g0);
@@ -763,40 +783,74 @@ __device__ void ds_scan(DecShared *sh, int tid, const float *gi_, int gi_st, con
         hj = (hj - n) * z + n;
         if (on && p == 0) {
             sh->hs[cur ^ 1][j] = hj;
-            out[(size_t)t * out_st + j] = clamp1(hj);
+            _Float16 a, b; dq_split(clamp1(hj), a, b);
+            sh->hbh[0][dq_hoff(t, j)] = a; sh->hbl[0][dq_hoff(t, j)] = b;
         }
-        g0 = g1; g1 = g2;
+        g0 = g1;
         cur ^= 1;
         __syncthreads();
     }
     if (on && p == 0) hstate[j] = hj;
 }
 
-// all decoder layers for rows [0, Tb) of stream b; sh->rst[] holds the per-row reset flags
-__device__ void ds_layers(DecShared *sh, const rd_decs_args &a, int b, int Tb, int tid)
+// all decoder layers for rows [0, Tb) (Tb <= DQ_ROWS) of stream b: z rows in, 84-float rows out; rstmask bit t = state reset before row t
+__device__ void dq_layers(DecShared *sh, const rd_decs_args &a, int b, const float *z, float *out, int Tb, unsigned rstmask)
 {
-    const int W = RD_DEC_W;
+    const int tid = rx_tid(), wave = tid >> 6;
     PH_T0();
-    float *x = a.x + (size_t)b * a.x_sb;
-    float *gi = a.gi + (size_t)b * a.gi_sb, *hb = a.hbuf + (size_t)b * a.hb_sb;
-    // short-K, few-column products (dense1: K = 80, GLU gates: K = 96): one column tile per wave, no split-K reduction;
-    // dense1 on the f32 matrix cores: its input z_hat is the only unbounded operand of the stack
-    ds_gemm32_cols<RD_LATENT / 8>(a.z + (size_t)b * a.z_sb, RD_LATENT, a.dense1, x, W, 1, Tb);
+    {   // conv history (the row before this chunk) from HBM into physical row 0 (key 15); the zero row
+        // (the slot holds the two planes as they were, one dword per column: a value re-split from their float sum could round to a
+        // different (hi, lo) pair, and the dropped lo x lo term would then depend on how the rows were cut into chunks)
+        const unsigned *hist = (const unsigned *)(a.x + (size_t)b * a.x_sb - RD_DEC_W);
+        for (int c = tid; c < RD_DEC_W; c += NT_RX) {
+            const unsigned u = hist[c];
+            sh->xh[0][dq_xoff(-1, c)] = __builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); sh->xl[0][dq_xoff(-1, c)] = __builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+        }
+        for (int c = tid; c < DQ_XB * 8; c += NT_RX) { sh->xh[DQ_ROWS + 1][c] = (_Float16)0.0f; sh->xl[DQ_ROWS + 1][c] = (_Float16)0.0f; }
+    }
+    dq_dense1(sh, z, a.dense1, Tb);
     __syncthreads();
+    DqGemm g;
+    // layer 0's input projection: K = 96
+    g = (DqGemm){ a.gin[0].wa16, 18, a.gin[0].bias, 288, a.gin[0].wscale, 0, 0, 0, 3, 0, DQ_OUT_GI, 0, 0, nullptr, 0 };
+    if (wave >= 2) dq_gemm_tiles<3>(sh, g, 3 * (wave - 2), Tb, rstmask);          // 18 column tiles = six wavefronts x three
+    __syncthreads();
+    PH(24);
 #pragma unroll 1
     for (int l = 0; l < 5; l++) {
         const int in = 96 + 128 * l, cin = in + 96;      // radae_base.py:378-386
-        ds_gemm16_cols<4>(x, W, in, a.gin[l], gi, 288, 0, Tb);                                 // column tiles 0..7, one per wave
-        ds_gemm16<1>(sh, tid, x, W, in, nullptr, 0, 0, nullptr, a.gin[l], gi, 288, 0, Tb, 8, 9);   // tile 8: K over the 8 waves
-        PH(21);
-        ds_scan(sh, tid, gi, 288, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, hb, 96, true, Tb);
+        dq_scan(sh, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, Tb, rstmask);
         PH(23);
-        ds_gemm16_cols<4>(hb, 96, 96, a.glu[l], x + in, W, 2, Tb);
+        // GLU gates: K = 96 from the GRU-output planes, 6 column tiles
+        g = (DqGemm){ a.glu[l].wa16, 6, nullptr, 96, a.glu[l].wscale, 1, 0, 0, 3, 0, DQ_OUT_X, in, 2, nullptr, 0 };
+        if (wave < 6) dq_gemm_tiles<1>(sh, g, wave, Tb, rstmask);
         __syncthreads();
-        ds_gemm16<1>(sh, tid, x, W, cin, x - W, W, cin, sh->rst, a.conv[l], x + cin, W, 1, Tb);
+        PH(25);
+        // conv (2 tiles, K = 2 cin, both taps) beside the next product's columns that are already final (K = cin):
+        // the next layer's input projection (18 tiles) or, behind the last conv, the output layer (6 tiles, staged in gi)
+        const DqGemm gc = (DqGemm){ a.conv[l].wa16, 2, a.conv[l].bias, 32, a.conv[l].wscale, 0, cin / 32, 0, 2 * cin / 32, 0, DQ_OUT_X, cin, 1, nullptr, 0 };
+        const bool last = l == 4;
+        const rd_lin &nx = last ? a.output : a.gin[l + 1];
+        const int nct = last ? 6 : 18;
+        const DqGemm gm = (DqGemm){ nx.wa16, nct, nx.bias, last ? a.out_w : 288, nx.wscale, 0, 0, 0, cin / 32, 0, DQ_OUT_GI, 0, 0, nullptr, 0 };
+        // wavefronts 0 and 1 take the two conv tiles (twice the K), the other six three projection tiles each (or one output tile)
+        if (wave < 2) dq_gemm_tiles<1>(sh, gc, wave, Tb, rstmask);
+        else if (last) dq_gemm_tiles<1>(sh, gm, wave - 2, Tb, rstmask);
+        else dq_gemm_tiles<3>(sh, gm, 3 * (wave - 2), Tb, rstmask);
+        __syncthreads();
+        PH(26);
+        // fix-up: the conv's 32 new columns (one k-step) added onto the staged sums
+        const DqGemm gf = (DqGemm){ nx.wa16, nct, nullptr, last ? a.out_w : 288, nx.wscale, 0, 0, cin / 32, 1, 1, last ? DQ_OUT_GLOBAL : DQ_OUT_GI, 0, 0, out, a.out_w };
+        if (wave >= 2) { if (last) dq_gemm_tiles<1>(sh, gf, wave - 2, Tb, rstmask); else dq_gemm_tiles<3>(sh, gf, 3 * (wave - 2), Tb, rstmask); }
+        __syncthreads();
+        PH(27);
     }
-    ds_gemm16<DS_NT>(sh, tid, x, W, 736, nullptr, 0, 0, nullptr, a.output, a.out + (size_t)b * a.out_sb, a.out_w, 0, Tb);
-    PH(21);
+    {   // conv history of the next chunk = this chunk's last row, back to HBM as float32
+        unsigned *hist = (unsigned *)(a.x + (size_t)b * a.x_sb - RD_DEC_W);
+        for (int c = tid; c < RD_DEC_W; c += NT_RX)
+            hist[c] = (unsigned)__builtin_bit_cast(unsigned short, sh->xh[0][dq_xoff(Tb - 1, c)]) | ((unsigned)__builtin_bit_cast(unsigned short, sh->xl[0][dq_xoff(Tb - 1, c)]) << 16);
+    }
+    __syncthreads();
 }
 
 // =====================================================================================================
@@ -1159,7 +1213,6 @@ enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
 
 
 
-#define NT_RX 512
 #define FFT_N 2048
 #define FFT_SCR (32 * 66)               // floats per wave of the FFT transpose scratch: [q][l + (l >> 5)], row stride 66: both
                                         // halves of the wave hit 32 distinct banks on the write (fixed q) and on the read (fixed l)
@@ -1179,11 +1232,13 @@ struct RxShared {
     float2 bmem[102];                     // BPF memory (dsp.py:55,96)
     double2 pd[RD_M], pendd[RD_M];        // pilot / end-of-over replicas as doubles (refine, check_pilots)
     float2 rxb[RD_RXBUF];                 // rx_buf (radae_rxe.py:141)
-    __attribute__((aligned(16))) float2 xm[1408];   // BPF [mem | mixed-down new] (1224); refine(): rx window as doubles (11264 B); rx1[1152] for the demod
     float2 sym[6][RD_NC];
     float2 rp[2][RD_NC];
     __attribute__((aligned(16))) float bpf_h[RD_NTAP + 3];
     union {
+      struct {
+        __attribute__((aligned(16))) float2 xm[1408];   // BPF [mem | mixed-down new] (1224); refine(): rx window as doubles (11264 B); rx1[1152] for the demod
+        union {
         struct {                          // synchronised state (S.lds_sync != 0)
             float2 wfwd[RD_M][RD_NC];     // forward DFT matrix (dsp.py:501)
             union {
@@ -1192,11 +1247,13 @@ struct RxShared {
                 struct { char rpart_pad[8192]; double rpart[6][64][4]; };   // refine(), in-sync grid (dtr uses 5 KB): second-half partial tiles
             };
         };
-        unsigned char dec_raw[sizeof(DecShared)];   // decoder stage scratch (rx_decode_pending)
         struct {                          // search / candidate state: FFT pilot correlator
             float2 fftX[FFT_N];           // spectrum of the rx_buf window being correlated
             float fftscr[NT_RX / 64][FFT_SCR];
         };
+        };
+      };
+      __attribute__((aligned(16))) unsigned char dec_raw[sizeof(DecShared)];   // decoder stage (rx_decode_pending): runs between calls, when xm and the tables are dead
     };
     double2 rtw[80], rrot[80], rt80[80];  // refine(): e^{-jw_f}, e^{-jw_f Nmf}, e^{-jw_f 80} per candidate frequency
     float rowsum1[RD_NMF], rowsum2[RD_NMF]; // sum_f |Dt1[t,f]|, |Dt2[t,f]|
@@ -1339,7 +1396,7 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
             const int t0 = q2 + 32 * h;                                       // this lane's outputs: t = t0 + 64 p < Nmf
             float d1[15];                                                     // |Dt1| of the same (f, t): fetched now, used after the transform
 #pragma unroll
-            for (int p = 0; p < 15; p++) d1[p] = (pass && fi >= 0) ? prev[(size_t)f * RD_NMF + t0 + 64 * p] : 0.0f;
+            for (int p = 0; p < 15; p++) d1[p] = (pass && fi >= 0) ? __builtin_nontemporal_load(&prev[(size_t)f * RD_NMF + t0 + 64 * p]) : 0.0f;   // streamed once: keep it out of the L2 the decoder weights live in
             __builtin_amdgcn_sched_barrier(0);
             fft2048_wave(v, scr, tw, lane);
             if (fi < 0) {
@@ -1351,7 +1408,7 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
                 for (int p = 0; p < 15; p++) {
                     const float2 c = v[brev5(p)];
                     const float d = __builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y));
-                    dst[(size_t)f * RD_NMF + t0 + 64 * p] = d;
+                    __builtin_nontemporal_store(d, &dst[(size_t)f * RD_NMF + t0 + 64 * p]);
                     rs[p] += d;
                     if (pass) { const float s12 = d1[p] + d; if (s12 > mx[p]) { mx[p] = s12; argw = (argw & ~(15ull << (4 * p))) | ((unsigned long long)fi << (4 * p)); } }
                 }
@@ -1627,7 +1684,12 @@ __device__ __forceinline__ void rx_decode_pending(RxShared *sh, const rd_sync_ar
     for (int i = tid; i < Tb; i += NT_RX) ds->rst[i] = rnd->row_reset[i];
     if (tid == 0) S->lds_sync = 0;
     __syncthreads();
-    ds_layers(ds, a.dec, b, Tb, tid);
+    for (int c0 = 0; c0 < Tb; c0 += DQ_ROWS) {                       // chunks of 24 rows: GRU state and conv history carry across
+        const int n = min(DQ_ROWS, Tb - c0);
+        unsigned rstmask = 0u;
+        for (int t = 0; t < n; t++) rstmask |= ds->rst[c0 + t] ? (1u << t) : 0u;
+        dq_layers(ds, a.dec, b, a.dec.z + (size_t)b * a.dec.z_sb + (size_t)c0 * RD_LATENT, a.dec.out + (size_t)b * a.dec.out_sb + (size_t)c0 * a.dec.out_w, n, rstmask);
+    }
     const float *f84 = a.dec.out + (size_t)b * a.dec.out_sb;
     for (int r = tid; r < Tb; r += NT_RX) ds->err[r] = f84[r * 84 + 20] > 0.0f ? 1 : 0;      // first aux symbol of each group of 4
     // valid frame v (3 rows) -> 12 feature frames x 36 floats, 20 used + 16 zeros
@@ -1636,10 +1698,6 @@ __device__ __forceinline__ void rx_decode_pending(RxShared *sh, const rd_sync_ar
         const int fr = i / 36, j = i - fr * 36;          // fr = 10 ms frame index within this batch
         const int row = fr >> 2, sub = fr & 3;
         out[i] = j < 20 ? f84[row * 84 + sub * 21 + j] : 0.0f;
-    }
-    {   // conv history of the next batch = the last row
-        float *x = a.dec.x + (size_t)b * a.dec.x_sb;
-        for (int i = tid; i < RD_DEC_W; i += NT_RX) x[i - RD_DEC_W] = x[(size_t)(Tb - 1) * RD_DEC_W + i];
     }
     __syncthreads();
     if (a.trace) {

@@ -148,11 +148,12 @@ def test_host_tables_match_reference_constants(lib, golden):
 
 
 class Lin(C.Structure):
-    _fields_ = [("n_in", C.c_int), ("n_out", C.c_int), ("w", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float))]
+    _fields_ = [("n_in", C.c_int), ("n_out", C.c_int), ("w", C.POINTER(C.c_float)), ("b", C.POINTER(C.c_float)), ("row_scale", C.POINTER(C.c_float))]
 
 
 class Gru(C.Structure):
-    _fields_ = [("n_in", C.c_int), ("hid", C.c_int), ("w_ih", C.POINTER(C.c_float)), ("w_hh", C.POINTER(C.c_float)), ("b_ih", C.POINTER(C.c_float)), ("b_hh", C.POINTER(C.c_float))]
+    _fields_ = [("n_in", C.c_int), ("hid", C.c_int), ("w_ih", C.POINTER(C.c_float)), ("w_hh", C.POINTER(C.c_float)), ("b_ih", C.POINTER(C.c_float)), ("b_hh", C.POINTER(C.c_float)),
+                ("s_ih", C.POINTER(C.c_float)), ("s_hh", C.POINTER(C.c_float))]
 
 
 class Model(C.Structure):
@@ -185,6 +186,21 @@ def test_host_blob_reader_and_packing(lib, golden):
     # truncated / corrupt blobs are rejected, not mis-parsed
     assert lib.rd_model_parse(blob[:100000], 100000, C.byref(Model())) != 0
     assert lib.rd_model_parse(b"XXXX" + blob[4:], len(blob), C.byref(Model())) != 0
+    # int8-exact layers: one binary16 plane of integers + row scales reproduces the de-quantised weights bit for bit
+    lib.rd_pack_weights_q16_a16.restype = C.c_long
+    lib.rd_pack_weights_q16_a16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    for lin, N, K in ((m.dec_conv[3], 32, 1152), (m.dec_glu[0], 96, 96)):
+        assert bool(lin.row_scale)
+        plane = np.zeros((K // 32) * ((N + 15) // 16) * 64 * 8, np.float16); sc = np.zeros(((N + 15) // 16) * 16, np.float32)
+        assert lib.rd_pack_weights_q16_a16(lin.w, lin.row_scale, N, K, plane.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)) == plane.size
+        W = arr(lin.w, N * K).reshape(N, K)
+        q = plane.reshape(K // 32, (N + 15) // 16, 4, 16, 8)                     # [ks][ct][k-slice][n][j]
+        Wr = (q.transpose(1, 3, 0, 2, 4).reshape(-1, K).astype(np.float32) * sc[:, None])[:N]
+        assert np.array_equal(Wr, W) and np.abs(plane).max() <= 127 and np.array_equal(plane, np.round(plane))
+    g = m.dec_gru[2]
+    assert bool(g.s_ih) and not bool(m.dec_output.row_scale)                     # float layers keep two planes
+    bad = arr(m.dec_glu[0].w, 96 * 96).copy(); bad[5] *= 1.0000001
+    assert lib.rd_pack_weights_q16_a16(bad.ctypes.data_as(C.c_void_p), m.dec_glu[0].row_scale, 96, 96, plane.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p)) < 0
     # packing: every weight lands exactly once where k_gemm's lane expects it
     lib.rd_packed_size.restype = C.c_long; lib.rd_packed_size.argtypes = [C.c_int, C.c_int]
     lib.rd_pack_weights.restype = C.c_long; lib.rd_pack_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]

@@ -13,12 +13,12 @@ for b in range(B):
     G[b] = torch.from_numpy(multipath_g("mpp", 8000, n_mf * 960, 5000 + b)).to(dev)
 rx = eng.channel(iq, sigma_from_EbNodB(3.0), -11.0, n_pre=8000, n_post=1152, with_eoo=True, G=G, seed=1)
 lib = load_library(); lib.rd_debug_phase_cycles.argtypes = [C.c_void_p]
-buf = (C.c_longlong * 24)(); lib.rd_debug_phase_cycles(buf)
+buf = (C.c_longlong * 32)(); lib.rd_debug_phase_cycles(buf)
 eng.profile(True)
 fo, st, _ = eng.rx(rx); torch.cuda.synchronize()
 eng.profile(False); pr = eng.profile_get()['rx_sync']
 lib.rd_debug_phase_cycles(buf)
-names = ["load", "bpf+shift", "detect corr", "detect reduce", "refine", "check rows", "sigma+corr+slip", "freqcorr", "demod dft", "eq", "statemachine", "store", " refine:tables", " refine:mfma", " refine:scan", " refine:argmax", " detect:pre", " detect:fft", " bpf:mix+load", " bpf:fir", "decode+post", " dec:gemm", "loop top", " dec:scan"]
+names = ["load", "bpf+shift", "detect corr", "detect reduce", "refine", "check rows", "sigma+corr+slip", "freqcorr", "demod dft", "eq", "statemachine", "store", " refine:tables", " refine:mfma", " refine:scan", " refine:argmax", " detect:pre", " detect:fft", " bpf:mix+load", " bpf:fir", "decode+post", " dec:gemm", "loop top", " dec:scan", " dec:hist+dense1+gin0", " dec:glu", " dec:conv+next", " dec:fixup", "", "", "", ""]
 tot = sum(buf[:12])
 print("stream0 calls", st[0].n_calls, "valid", st[0].n_valid, "rx_sync kernel ms", pr["ms"], "launches", pr["launches"])
 for i, n in enumerate(names): print(f"{n:18s} {buf[i]:12d} cyc  {100*buf[i]/tot:5.1f}%  {buf[i]/100e6*1e3:8.3f} ms (100MHz clk?)")
