@@ -182,6 +182,7 @@ typedef struct {
     float *eoo_out;                                      /* [B][180] or NULL */
     rd_rx_trace *trace; float *trace_z; int trace_cap;   /* optional */
     int *progress;                                       /* [4]: calls made by this launch, unused x3 */
+    long long *wg_cycles;                                /* [B] shader-clock cycles each stream's workgroup spent in the launch (or NULL) */
     int B;
 } rd_sync_args;
 int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);

@@ -49,6 +49,7 @@ struct rade_batch {
     int *rx_avail, *rx_acc, *rx_progress, *rx_status;
     float *zrows, *dec_x, *dec_gi, *dec_hbuf, *dec_h[5], *feat84, *dtcache;
     rd_rx_trace *trace; float *trace_z;
+    long long *wg_cycles;            /* [B] per-stream cycles of the last receiver launch */
     int *h_small;                    /* pinned host scratch */
     unsigned *lcg_seeds;             /* host copy for resets */
     unsigned *d_lcg_seeds;
@@ -227,6 +228,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->rx_round = dev_zeros(sizeof(rd_rx_round) * B);
     h->rx_avail = dev_zeros(sizeof(int) * B); h->rx_acc = dev_zeros(sizeof(int) * B * 4); h->rx_progress = dev_zeros(sizeof(int) * 4);
     h->rx_status = dev_zeros(sizeof(int) * B * 4);
+    h->wg_cycles = dev_zeros(sizeof(long long) * B);
     h->zrows = dev_zeros(sizeof(float) * B * DR * RD_LATENT);
     h->dec_x = dev_zeros(sizeof(float) * B * (1 + DR) * RD_DEC_W);
     h->dec_gi = dev_zeros(sizeof(float) * B * DR * 288);
@@ -283,7 +285,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16 };
+                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -522,7 +524,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
     sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
-    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.B = B;
+    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
     sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only
@@ -552,6 +554,15 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     return 0;
 fail:
     return -1;
+}
+
+/* shader-clock cycles every stream's workgroup spent in the most recent receiver launch (measurement aid: the launch lasts as
+ * long as its slowest stream) */
+int rade_batch_rx_stream_cycles(rade_batch *h, long long *out_host)
+{
+    if (!h || !out_host || !h->wg_cycles) return -1;
+    ON_DEV(h);
+    return hipMemcpy(out_host, h->wg_cycles, sizeof(long long) * h->B, hipMemcpyDeviceToHost) == hipSuccess ? h->B : -1;
 }
 
 int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls)

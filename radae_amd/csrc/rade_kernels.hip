@@ -1222,6 +1222,7 @@ struct RxScalars {
     uint32_t lcg;
     unsigned rxmax_cur, rxmax_h0, rxmax_h1;   // float bits of max |re|,|im| of the filtered samples of this call / the two calls before (check_pilots operand scale)
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
+    int entry;                // this candidate call enters sync (decided by thread 0 before a barrier: see do_entry)
     int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
     float snr_est, mag; float2 bpf_phase;
     double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
@@ -1396,7 +1397,7 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
             const int t0 = q2 + 32 * h;                                       // this lane's outputs: t = t0 + 64 p < Nmf
             float d1[15];                                                     // |Dt1| of the same (f, t): fetched now, used after the transform
 #pragma unroll
-            for (int p = 0; p < 15; p++) d1[p] = (pass && fi >= 0) ? __builtin_nontemporal_load(&prev[(size_t)f * RD_NMF + t0 + 64 * p]) : 0.0f;   // streamed once: keep it out of the L2 the decoder weights live in
+            for (int p = 0; p < 15; p++) d1[p] = (pass && fi >= 0) ? prev[(size_t)f * RD_NMF + t0 + 64 * p] : 0.0f;
             __builtin_amdgcn_sched_barrier(0);
             fft2048_wave(v, scr, tw, lane);
             if (fi < 0) {
@@ -1408,7 +1409,7 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
                 for (int p = 0; p < 15; p++) {
                     const float2 c = v[brev5(p)];
                     const float d = __builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y));
-                    __builtin_nontemporal_store(d, &dst[(size_t)f * RD_NMF + t0 + 64 * p]);
+                    dst[(size_t)f * RD_NMF + t0 + 64 * p] = d;      // (plain accesses on purpose: with nt stores + nt loads a stream now and then read back a stale surface)
                     rs[p] += d;
                     if (pass) { const float s12 = d1[p] + d; if (s12 > mx[p]) { mx[p] = s12; argw = (argw & ~(15ull << (4 * p))) | ((unsigned long long)fi << (4 * p)); } }
                 }
@@ -1748,6 +1749,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0;
     }
     const int avail = a.avail[b];
+    const long long wg_t0 = clock64();                 // per-stream duration of this launch (tail analysis: the launch lasts as long as its slowest stream)
     __syncthreads();
     PH_T0(); PH(0);
 
@@ -1818,7 +1820,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // ---- complex_bpf.bpf (dsp.py:63-102)
         const float2 *xin = rxin + S->consumed_inv;
         for (int i = tid; i < ml; i += NT_RX) sh->xm[i] = sh->bmem[i];
-        for (int i = tid; i < nin; i += NT_RX) sh->xm[ml + i] = cmul(xin[i], cmul(bpf_phase, ld2(tab->bpf_E, i)));
+        for (int i = tid; i < nin; i += NT_RX) { sh->xm[ml + i] = cmul(xin[i], cmul(bpf_phase, ld2(tab->bpf_E, i))); }
         __syncthreads();
         PH(18);
         // 101-tap FIR, three consecutive outputs per thread over a sliding register window (one LDS read per tap and
@@ -1873,6 +1875,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             // largest component of the new samples: sets the power-of-two scale of check_pilots' binary16 operand planes, so
             // that no input level (int16-scaled samples, a strong interferer) can overflow them
+           
             float mloc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 3; j++) mloc = fmaxf(mloc, fmaxf(fabsf(filt[j].x), fabsf(filt[j].y)));
@@ -1925,6 +1928,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             PH(2);
             block_argmax(sh, best, bt, bfi);
             const float Dmax = sh->redf[0]; const int tbest = sh->redi[0], fbest = sh->redj[0];
+           
             __syncthreads();
             const float sr = sigma_r_from_rowsums(sh);
             if (tid == 0) {
@@ -1932,6 +1936,10 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 if (Dmax > 0.0f) { S->tmax = tbest; S->f_ind_max = fbest; S->fmax = -50.0 + 2.5 * fbest;   /* = tab->fcoarse[fbest] (dsp.py:163), without the dependent global load in the serial section */ S->Dtmax12 = (double)Dmax; }
                 else { S->tmax = 0; S->f_ind_max = 0; S->fmax = 0.0; S->Dtmax12 = 0.0; }
                 S->candidate = S->Dtmax12 > S->Dthresh;
+                // radae_rxe.py:256-260, decided HERE, by the one thread that also runs the state machine: evaluated by every thread after
+                // the barrier it raced with thread 0's state update (valid_count++ a few lines further down), and a wavefront that read
+                // the incremented count walked into refine() alone, one call early -- its barriers then paired with the wrong ones
+                S->entry = S->candidate && (abs(S->tmax - S->tmax_candidate) < RD_NCP) && (S->valid_count + 1 > 3);
             }
             __syncthreads();
             PH(3);
@@ -2200,7 +2208,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 
         PH(9);
         // ---- state machine (radae_rxe.py:248-297).  Sync entry needs the whole workgroup for refine().
-        const int do_entry = (state == ST_CANDIDATE) && S->candidate && (abs(S->tmax - S->tmax_candidate) < RD_NCP) && (S->valid_count + 1 > 3);
+        const int do_entry = (state == ST_CANDIDATE) && S->entry;      // S->entry is final since the barrier that ended the detect stage
         if (do_entry) {
             const int tm = S->tmax; const double fm = S->fmax;
             const int t0 = max(0, tm - 1);
@@ -2241,6 +2249,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         rnd->out_base = S->out_base;
         a.acc[b * 4 + 0] = S->consumed_inv; a.acc[b * 4 + 1] = S->calls_inv; a.acc[b * 4 + 2] = S->valid_inv; a.acc[b * 4 + 3] = S->eoo_inv;
         a.status[b * 4 + 0] = S->nin; a.status[b * 4 + 1] = S->state == ST_SYNC; a.status[b * 4 + 2] = (int)S->snr_est; a.status[b * 4 + 3] = S->state;
+        if (a.wg_cycles) a.wg_cycles[b] = clock64() - wg_t0;
         if (S->n_calls) atomicAdd(&a.progress[0], S->n_calls);
         if (S->calls_inv < a.max_calls && S->valid_inv < a.feat_cap && S->consumed_inv + S->nin <= avail) atomicAdd(&a.progress[1], 1);   // stopped at the per-launch limit
     }

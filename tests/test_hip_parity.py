@@ -401,6 +401,33 @@ def test_many_identical_streams_agree(Engine, torch_dev, golden, name, B):
     eng.close()
 
 
+def test_replicas_agree_over_many_fresh_launches(Engine, torch_dev):
+    """Barrier-phase race guard.  256 streams = 32 replicas of 8 utterances, a fresh engine per repetition, no trace (the timing of
+    the untraced kernel is what exposed it): every replica must come out bit-identical.  Round 2 found a latent race here -- every
+    thread evaluated the sync-entry condition from LDS scalars while thread 0 was already incrementing valid_count in its state
+    update; a wavefront that read the new count entered refine() alone one call early, its barriers paired with the wrong ones,
+    and it read the next call's samples (about 1 launch in 20 had such a stream; tools/first_launch_check.py is the long form)."""
+    import torch
+    from radae_amd.channel_tools import synth_features
+    from radae_amd.engine import sigma_from_EbNodB
+    B, T = 256, 1008
+    n_mf = T // 12
+    base = [synth_features(3000 + u, T) for u in range(8)]
+    feats = torch.tensor(np.stack([base[b % 8] for b in range(B)]), device=torch_dev)
+    rng = np.random.default_rng(9)
+    n_tot = 4000 + n_mf * 960 + 1152 + 1152
+    nz = ((rng.standard_normal((8, n_tot)) + 1j * rng.standard_normal((8, n_tot))) / np.sqrt(2)).astype(np.complex64)
+    noise = torch.tensor(np.concatenate([nz] * 32), device=torch_dev)
+    for rep in range(40):
+        eng = Engine(B, max_tx_mf=n_mf)
+        rx = eng.channel(eng.tx(feats), sigma_from_EbNodB(10.0), 11.0, n_pre=4000, n_post=1152, with_eoo=True, noise=noise)
+        fo, st, _ = eng.rx(rx)
+        nv = np.array([s.n_valid for s in st])
+        assert nv.min() == nv.max() == 81, (rep, nv.min(), nv.max())
+        assert torch.equal(fo.view(32, 8, -1)[1:], fo.view(32, 8, -1)[:1].expand(31, -1, -1)), rep
+        eng.close()
+
+
 def test_single_stream_c_abi(golden):
     """rade_api.h entry points (what radae_tx.c / radae_rx.c / freedv-gui call), via radae_amd.api."""
     from radae_amd import api
@@ -627,7 +654,7 @@ def test_core_level_boundary_config2(golden, tmp_path):
     assert rms(z, e["z"][0]) < 1e-4 and np.abs(z - e["z"][0]).max() < 2e-6 * np.abs(e["z"]).max() + 1e-5     # latents are O(100)
     enc2 = core.CoreEncoder()                                          # second state, same blob: bottleneck 1, untouched by the first
     z1 = np.stack([enc2.step(r, bottleneck=1) for r in rows])
-    assert np.abs(z1 - np.tanh(e["z"][0])).max() < 1e-5
+    assert np.abs(z1 - np.tanh(e["z"][0])).max() < 1e-4
     enc.reset()
     assert np.array_equal(np.stack([enc.step(r) for r in rows[:5]]), z[:5])          # rade_init_encoder == fresh state
     with pytest.raises(ValueError):

@@ -1,14 +1,26 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats + three separate PMC passes of the bench command.
-# Outputs land in gpurun_out/prof_r01/ and are summarised into profiles/ by tools/make_profile_summary.py.
+# Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats of the bench command + separate PMC passes (never combined with
+# trace domains other than --kernel-trace).  Outputs land in gpurun_out/prof_$TAG/ and are summarised into profiles/ by
+# tools/make_profile_summary.py (run it afterwards in the repo).  Usage: bash tools/collect_profiles.sh [tag]
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_r01; rm -rf $O; mkdir -p $O
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
+# 1. the plain bench line (un-profiled) that the roofline block is quoted from
+python $R/bench.py --steps 100 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
+# 2. rocprofv3 --kernel-trace --stats of the same command (shorter: the trace of 100 steps is large)
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $CMD > $O/bench_under_rocprof.json 2> $O/stats.err
-CMD1="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $O/pmc_mfma -o pmc -- $CMD1 > /dev/null 2> $O/pmc_mfma.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- $CMD1 > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o pmc -- $CMD1 > /dev/null 2> $O/pmc_write.err
-find $O -name "*.csv" | head -20
-tail -1 $O/bench_under_rocprof.json | cut -c1-300
+# 3. counters, one pass each
+CMD1="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-parity"
+pass() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -o pmc -- $CMD1 > /dev/null 2> $O/pmc_$n.err; }
+pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F16
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
+pass sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA
+pass l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# 4. per-stream duration of the receiver launch (tail analysis) and the receiver's traffic by source
+python $R/tools/stream_cycles.py > $O/stream_cycles.json 2> $O/stream_cycles.err
+find $O -name "*.csv" | head -30
+tail -c 400 $O/bench_line.json

@@ -1,30 +1,38 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/prof_r01/ (tools/collect_profiles.sh) into the tracked summaries under profiles/:
-r01_bench_kernel_stats.csv, r01_bench_under_rocprof.json, r01_pmc_per_kernel.txt, r01_pmc_summary.json."""
-import csv, json, os, shutil, sys, collections
+"""Turn gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into the tracked summaries under profiles/:
+<tag>_bench_kernel_stats.csv, <tag>_bench_line.json, <tag>_bench_under_rocprof.json, <tag>_pmc_per_kernel.txt, <tag>_pmc_summary.json,
+<tag>_stream_cycles.json.  Usage: python tools/make_profile_summary.py [tag]"""
+import csv, glob, json, os, shutil, subprocess, sys, collections
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(R, "gpurun_out", "prof_r01"); dst = os.path.join(R, "profiles")
-shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, "r01_bench_kernel_stats.csv"))
-line = [l for l in open(os.path.join(src, "bench_under_rocprof.json")) if l.startswith("{")][-1]
-json.dump(json.loads(line), open(os.path.join(dst, "r01_bench_under_rocprof.json"), "w"), indent=1)
+src = os.path.join(R, "gpurun_out", "prof_" + tag); dst = os.path.join(R, "profiles")
+shutil.copy(glob.glob(os.path.join(src, "stats", "**", "bench_kernel_stats.csv"), recursive=True)[0], os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+for name in ("bench_under_rocprof", "bench_line", "stream_cycles"):
+    line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
+    json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
 
 def load(name):
-    rows = list(csv.DictReader(open(os.path.join(src, name, "pmc_counter_collection.csv"))))
+    fs = glob.glob(os.path.join(src, name, "**", "pmc_counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
-    for r in rows:
+    for r in (csv.DictReader(open(fs[0])) if fs else []):
         k = r["Kernel_Name"].split("(")[0]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k].add(r["Dispatch_Id"])
     return agg, {k: len(v) for k, v in cnt.items()}
-out = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline (three separate passes: SQ/GRBM set, FETCH_SIZE, WRITE_SIZE; tools/collect_profiles.sh)",
-       "note": "FETCH_SIZE/WRITE_SIZE are the raw counters x 1024 (KB units, MI355X_MICROARCH.md); the gfx950 wide-load halving correction is NOT applied (the dominant kernel mixes 4/8/16-byte per-lane loads: uncalibrated width). GRBM_GUI_ACTIVE is summed over the 8 XCDs, so cycles = GRBM/8; MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs) / (cycles x 1024 SIMDs).",
-       "kernels": {}}
-mf, n1 = load("pmc_mfma"); fe, n2 = load("pmc_fetch"); wr, n3 = load("pmc_write")
+try:
+    commit = subprocess.check_output(["git", "-C", R, "rev-parse", "--short", "HEAD"]).decode().strip()
+except Exception:
+    commit = "?"
+out = {"commit": commit,
+       "command": "rocprofv3 --kernel-trace --pmc <set> -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-parity (separate passes: MFMA/GRBM set, FETCH_SIZE, WRITE_SIZE, two SQ sets, TCC hit/miss; tools/collect_profiles.sh)",
+       "note": "FETCH_SIZE/WRITE_SIZE are the raw counters x 1024 (KB units, MI355X_MICROARCH.md); the gfx950 wide-load halving correction is NOT applied here (bench.py reports raw and corrected). GRBM_GUI_ACTIVE is summed over the 8 XCDs, so cycles = GRBM/8; MFMA busy % = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over SIMDs) / (cycles x 1024 SIMDs). SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles.",
+       "kernels": {}, "sq_breakdown": {}}
+mf, n1 = load("pmc_mfma"); fe, n2 = load("pmc_fetch"); wr, n3 = load("pmc_write"); s1, n4 = load("pmc_sq1"); s2, n5 = load("pmc_sq2"); l2, n6 = load("pmc_l2")
 txt = []
-for name, (agg, n) in (("pmc_mfma", (mf, n1)), ("pmc_fetch", (fe, n2)), ("pmc_write", (wr, n3))):
-    txt.append(f"# gpurun_out/prof_r01/{name}/pmc_counter_collection.csv")
+for name, (agg, n) in (("pmc_mfma", (mf, n1)), ("pmc_fetch", (fe, n2)), ("pmc_write", (wr, n3)), ("pmc_sq1", (s1, n4)), ("pmc_sq2", (s2, n5)), ("pmc_l2", (l2, n6))):
+    txt.append(f"# gpurun_out/prof_{tag}/{name}/pmc_counter_collection.csv")
     for k in sorted(agg, key=lambda k: -n[k]):
         txt.append(f"{k[:42]:42s} dispatches {n[k]:5d} " + " ".join(f"{c}={v / n[k]:.4g}/disp" for c, v in sorted(agg[k].items())))
-open(os.path.join(dst, "r01_pmc_per_kernel.txt"), "w").write("\n".join(txt) + "\n")
+open(os.path.join(dst, tag + "_pmc_per_kernel.txt"), "w").write("\n".join(txt) + "\n")
 for k in mf:
     n = n1[k]; a = mf[k]
     out["kernels"][k] = {
@@ -34,6 +42,16 @@ for k in mf:
         "mfma_mops_f16_per_dispatch": a.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) / n,
         "fetch_bytes_per_dispatch": 1024.0 * fe.get(k, {}).get("FETCH_SIZE", 0.0) / max(n2.get(k, 1), 1),
         "write_bytes_per_dispatch": 1024.0 * wr.get(k, {}).get("WRITE_SIZE", 0.0) / max(n3.get(k, 1), 1)}
-json.dump(out, open(os.path.join(dst, "r01_pmc_summary.json"), "w"), indent=1)
+    if k in l2 and l2[k].get("TCC_HIT_sum", 0) + l2[k].get("TCC_MISS_sum", 0) > 0:
+        out["kernels"][k]["l2_hit_rate"] = l2[k]["TCC_HIT_sum"] / (l2[k]["TCC_HIT_sum"] + l2[k]["TCC_MISS_sum"])
+    if k in s1 and s1[k].get("SQ_WAVE_CYCLES", 0) > 0:
+        w = s1[k]["SQ_WAVE_CYCLES"]; a1 = s1[k]; a2 = s2.get(k, {})
+        sh = {"parked_s_waitcnt_s_barrier": a1.get("SQ_WAIT_ANY", 0) / w, "issue_stalled": a1.get("SQ_WAIT_INST_ANY", 0) / w, "issuing": a1.get("SQ_ACTIVE_INST_ANY", 0) / w,
+              "issuing_valu": a1.get("SQ_ACTIVE_INST_VALU", 0) / w, "issuing_lds": a1.get("SQ_ACTIVE_INST_LDS", 0) / w,
+              "lds_bank_conflict_share_of_lds_cycles": (a2.get("SQ_LDS_BANK_CONFLICT", 0) / a2["SQ_LDS_IDX_ACTIVE"]) if a2.get("SQ_LDS_IDX_ACTIVE") else None}
+        sh = {kk: (round(v, 4) if v is not None else None) for kk, v in sh.items()}
+        sh["bound"] = ("latency (s_waitcnt/s_barrier)" if sh["parked_s_waitcnt_s_barrier"] > 0.4 else "issue") + (" + valu-issue" if sh["issuing_valu"] > 0.15 else "")
+        out["sq_breakdown"][k] = sh
+json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
 for k, v in out["kernels"].items():
-    if v["gpu_cycles_per_dispatch"] > 1e5: print(f"{k[:40]:40s} n={v['dispatches']:4d} cyc={v['gpu_cycles_per_dispatch']:.3g} mfma_busy={v['mfma_busy_pct']:.1f}% fetch={v['fetch_bytes_per_dispatch']/1e6:.1f}MB write={v['write_bytes_per_dispatch']/1e6:.1f}MB")
+    if v["gpu_cycles_per_dispatch"] > 1e5: print(f"{k[:40]:40s} n={v['dispatches']:4d} cyc={v['gpu_cycles_per_dispatch']:.3g} mfma_busy={v['mfma_busy_pct']:.1f}% fetch={v['fetch_bytes_per_dispatch']/1e6:.1f}MB write={v['write_bytes_per_dispatch']/1e6:.1f}MB l2hit={v.get('l2_hit_rate')} sq={out['sq_breakdown'].get(k)}")
