@@ -104,6 +104,7 @@ typedef struct {
     const int *n_rows;                 /* optional [B]: rows t >= n_rows[b] are skipped */
     const float *Wp; const float *bias;
     const unsigned short *Wp16;        /* optional rd_pack_weights_f16x2 copy: used for large row counts when K0, K1 are multiples of 16 */
+    const float *Wscale;               /* non-NULL: Wp16 is ONE plane of integers (rd_pack_weights_q16, int8-exact layer) and Wscale[n] the column's scale */
     float *y; long y_sb, y_st; int N;  /* N valid outputs (<= 32*NT) */
     int B, T, act;
 } rd_gemm_args;

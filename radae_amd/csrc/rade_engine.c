@@ -23,7 +23,7 @@
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rade: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); goto fail; } } while (0)
 
-typedef struct { float *wp, *bias; unsigned short *wp16, *wa16; float *wscale; int N, K; } dev_lin;
+typedef struct { float *wp, *bias; unsigned short *wp16, *wa16; float *wscale, *wscale16; int N, K; } dev_lin;   /* wscale16: column scales when wp16 is one plane of integers */
 
 /* every public entry point runs on its engine's device, whatever device the calling thread had current (one host thread may
  * drive several engines, and an engine may be called from a thread other than the one that opened it) */
@@ -92,16 +92,24 @@ static int upload_lin(dev_lin *d, const float *w, const float *b, const float *r
     rd_pack_weights(wsrc, N, Kpad, packed);
     d->wp = dev_upload(packed, sizeof(float) * n);
     d->bias = b ? dev_upload(b, sizeof(float) * N) : NULL;
-    d->N = N; d->K = Kpad; d->wp16 = NULL;
-    if (Kpad % 16 == 0) {                  /* two-plane f16 copy for the receiver's in-kernel decoder (f16 matrix cores) */
+    d->N = N; d->K = Kpad; d->wp16 = NULL; d->wscale16 = NULL;
+    if (Kpad % 16 == 0) {                  /* binary16 copy for the f16 matrix cores (k_gemm16): int8-exact layers as ONE plane of integers + column scales, others as two planes */
         const long n16 = rd_packed16_size(N, Kpad);
         unsigned short *p16 = malloc(sizeof(unsigned short) * n16);
-        if (!p16 || rd_pack_weights_f16x2(wsrc, N, Kpad, p16) < 0) {
-            fprintf(stderr, "rade: a weight exceeds the range of the split-binary16 operand planes (|w| < 63.9)\n");
-            free(p16); free(packed); free(tmp); return -1;
+        float *sc = calloc((size_t)((N + 31) / 32) * 32, sizeof(float));
+        long nq = -1;
+        if (p16 && sc && row_scale && !getenv("RADE_NO_INT8_EXACT")) nq = rd_pack_weights_q16(wsrc, row_scale, N, Kpad, p16, sc);
+        if (nq > 0) {
+            d->wp16 = dev_upload(p16, sizeof(unsigned short) * nq);
+            d->wscale16 = dev_upload(sc, sizeof(float) * (size_t)((N + 31) / 32) * 32);
+        } else {
+            if (!p16 || rd_pack_weights_f16x2(wsrc, N, Kpad, p16) < 0) {
+                fprintf(stderr, "rade: a weight exceeds the range of the split-binary16 operand planes (|w| < 63.9)\n");
+                free(p16); free(sc); free(packed); free(tmp); return -1;
+            }
+            d->wp16 = dev_upload(p16, sizeof(unsigned short) * n16);
         }
-        d->wp16 = dev_upload(p16, sizeof(unsigned short) * n16);
-        free(p16);
+        free(p16); free(sc);
     }
     d->wa16 = NULL; d->wscale = NULL;
     if (Kpad % 32 == 0) {                  /* A-operand layout of the in-kernel decoder's 16x16x32 products */
@@ -279,7 +287,7 @@ rade_batch *rade_batch_open(const char *blob_path, const rade_batch_config *cfg)
     return h;
 }
 
-static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFree(d->bias); if (d->wp16) hipFree(d->wp16); if (d->wa16) hipFree(d->wa16); if (d->wscale) hipFree(d->wscale); }
+static void free_lin(dev_lin *d) { if (d->wp) hipFree(d->wp); if (d->bias) hipFree(d->bias); if (d->wp16) hipFree(d->wp16); if (d->wa16) hipFree(d->wa16); if (d->wscale) hipFree(d->wscale); if (d->wscale16) hipFree(d->wscale16); }
 void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
@@ -341,7 +349,7 @@ static int gemm(rade_batch *hh, const dev_lin *w, const float *a1, long a1_sb, l
     rd_gemm_args g;
     memset(&g, 0, sizeof g);
     g.a1 = a1; g.a1_sb = a1_sb; g.a1_st = a1_st; g.K1 = K1; g.a0 = a0; g.a0_sb = a0_sb; g.a0_st = a0_st; g.K0 = K0;
-    g.reset = reset; g.reset_sb = hh->dec_rows; g.n_rows = n_rows; g.Wp = w->wp; g.Wp16 = w->wp16; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
+    g.reset = reset; g.reset_sb = hh->dec_rows; g.n_rows = n_rows; g.Wp = w->wp; g.Wp16 = w->wp16; g.Wscale = w->wp16 ? w->wscale16 : NULL; g.bias = w->bias; g.y = y; g.y_sb = y_sb; g.y_st = y_st; g.N = w->N; g.B = B; g.T = T; g.act = act;
     if (K0 + K1 != w->K) { fprintf(stderr, "rade: internal GEMM shape error (%d+%d != %d)\n", K0, K1, w->K); return -1; }
     PROF_BEGIN(hh, stream);
     const int rc = rd_launch_gemm(&g, stream);
@@ -358,7 +366,7 @@ static int encode_core(rade_batch *h, int T, float *z, void *stream)
     int e = 0;
     /* dense1 reads raw features: the one encoder operand that is not tanh-bounded, so it stays on the f32 matrix cores
      * (the 2^8-scaled binary16 planes of the split-f16 kernels overflow beyond +-255.9) */
-    dev_lin d1 = h->enc_dense1; d1.wp16 = NULL;
+    dev_lin d1 = h->enc_dense1; d1.wp16 = NULL; d1.wscale16 = NULL;
     e |= gemm(h, &d1, h->enc_xin, (long)T * h->enc_kpad, h->enc_kpad, h->enc_kpad, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = ENC_IN[l];
@@ -457,7 +465,7 @@ static int decoder_layers(rade_batch *h, const float *z, int T, int Tio, int Tca
     const long xsb = (long)(1 + Tcap) * W;
     float *x = xbuf + W;
     int e = 0;
-    dev_lin d1 = h->dec_dense1; d1.wp16 = NULL;       /* z_hat is unbounded: f32 matrix cores (see encode_core) */
+    dev_lin d1 = h->dec_dense1; d1.wp16 = NULL; d1.wscale16 = NULL;       /* z_hat is unbounded: f32 matrix cores (see encode_core) */
     e |= gemm(h, &d1, z, (long)Tio * RD_LATENT, RD_LATENT, RD_LATENT, NULL, 0, 0, 0, NULL, nr, x, xsb, W, B, T, 1, stream);
     for (int l = 0; l < 5 && !e; l++) {
         const int in = DEC_IN[l];

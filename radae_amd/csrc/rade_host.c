@@ -378,6 +378,30 @@ long rd_pack_weights_f16x2_a16(const float *W, int N, int K, unsigned short *out
     return rd_packed16a_size(N, K);
 }
 
+static int q_of(float w, float sc, float *q)
+{   /* w = q * sc with integer |q| <= 127, exactly? */
+    *q = 0.0f;
+    if (w == 0.0f) return 0;
+    if (sc == 0.0f) return -1;
+    *q = rintf(w / sc);
+    return (fabsf(*q) <= 127.0f && *q * sc == w) ? 0 : -1;
+}
+long rd_pack_weights_q16(const float *W, const float *row_scale, int N, int K, unsigned short *out, float *scale_out)
+{
+    const int nkb = K / 16, ntt = (N + 31) / 32;
+    if (!row_scale) return -1;
+    for (int n = 0; n < ntt * 32; n++) scale_out[n] = n < N ? row_scale[n] : 0.0f;
+    for (int kb = 0; kb < nkb; kb++)
+        for (int nt = 0; nt < ntt; nt++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int nn = nt * 32 + (lane & 31), k = kb * 16 + 8 * (lane >> 5) + j;
+                    float q = 0.0f;
+                    if (nn < N && q_of(W[(size_t)nn * K + k], row_scale[nn], &q)) return -1;
+                    out[(((size_t)kb * ntt + nt) * 64 + lane) * 8 + j] = f32_to_f16(q);
+                }
+    return (long)nkb * ntt * 64 * 8;
+}
 long rd_pack_weights_q16_a16(const float *W, const float *row_scale, int N, int K, unsigned short *out, float *scale_out)
 {
     const int nks = K / 32, nct = (N + 15) / 16;

@@ -242,8 +242,10 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
 #pragma unroll
             for (int j = 0; j < 16; j++) acc[q][i][j] = 0.0f;
     const int nkb0 = a.K0 >> 4, nkb = nkb0 + (a.K1 >> 4);
-    const unsigned short *wbase = a.Wp16 + ((size_t)nt0 * 2 * 64 + lane) * 8;
-    const size_t wstep = (size_t)ntt * 2 * 64 * 8;
+    const bool single = a.Wscale != nullptr;          // int8-exact layer: the weights are ONE plane of integers (exact in binary16), two products per k-block
+    const int planes = single ? 1 : 2;
+    const unsigned short *wbase = a.Wp16 + ((size_t)nt0 * planes * 64 + lane) * 8;
+    const size_t wstep = (size_t)ntt * planes * 64 * 8;
     f32x4 a4[RT][2]; f16x8 bh[NT], bl[NT];
     auto fetch = [&](int kb) {
 #pragma unroll
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
             a4[q][0] = *(const f32x4 *)p; a4[q][1] = *(const f32x4 *)(p + 4);
         }
 #pragma unroll
-        for (int i = 0; i < NT; i++) { bh[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8); bl[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8 + 64 * 8); }
+        for (int i = 0; i < NT; i++) { bh[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * planes * 64 * 8); if (!single) bl[i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8 + 64 * 8); }
     };
     fetch(0);
 #pragma unroll 1
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
 #pragma unroll
             for (int i = 0; i < NT; i++) {
                 acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q], ch[i], acc[q][i], 0, 0, 0);
-                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], cl[i], acc[q][i], 0, 0, 0);
+                if (!single) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], cl[i], acc[q][i], 0, 0, 0);
                 acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], ch[i], acc[q][i], 0, 0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
@@ -287,13 +289,14 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
             const int col = (nt0 + i) * 32 + (lane & 31);
             if (col >= a.N) continue;
             const float bias = a.bias ? a.bias[col] : 0.0f;
+            const float scl = single ? a.Wscale[col] * 0x1p-8f : 0x1p-18f;       // integers x column scale (rows carry 2^8), or two planes of 2^10 w
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int rr = r0 + 32 * q + (j & 3) + 8 * (j >> 2) + 4 * half;
                 if (rr >= rows) continue;
                 const int bb = rr / a.T, tt = rr - bb * a.T;
                 if (a.n_rows && tt >= a.n_rows[bb]) continue;
-                float v = acc[q][i][j] * 0x1p-18f + bias;
+                float v = acc[q][i][j] * scl + bias;
                 if (a.act == 1) v = clamp1(gate_tanh(v));                 // hardware exp2 / rcp, as in the recurrences
                 else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * gate_sigmoid(v));
                 a.y[bb * a.y_sb + tt * a.y_st + col] = v;
