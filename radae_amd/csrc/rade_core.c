@@ -109,7 +109,9 @@ int init_radedec(RADEDec *model, const WeightArray *arrays, int output_dim)
 }
 
 /* device side of one state: a single-stream engine and its staging buffers */
-typedef struct { rade_batch *eng; float *d_in, *d_out; int dim; } core_dev;
+/* One step is ~20 short dependent launches for a single stream (launch-bound), so after the first call the sequence
+ * [input H2D, encoder / decoder kernels, output D2H] is captured once and replayed as a hipGraph, as rade_tx() does. */
+typedef struct { rade_batch *eng; float *d_in, *d_out; int dim; hipStream_t gs; hipGraphExec_t graph; int calls, graph_off; float *h_in, *h_out; } core_dev;
 
 static core_dev *dev_open(const void *blob, int len, int dim)
 {
@@ -126,11 +128,17 @@ static core_dev *dev_open(const void *blob, int len, int dim)
         free(d);
         return NULL;
     }
+    if (getenv("RADE_NO_GRAPH") || hipStreamCreate(&d->gs) != hipSuccess || hipHostMalloc((void **)&d->h_in, sizeof(float) * 96, 0) != hipSuccess ||
+        hipHostMalloc((void **)&d->h_out, sizeof(float) * 96, 0) != hipSuccess) { d->graph_off = 1; (void)hipGetLastError(); }
     return d;
 }
 static void dev_close(core_dev *d)
 {
     if (!d) return;
+    if (d->graph) hipGraphExecDestroy(d->graph);
+    if (d->h_in) hipHostFree(d->h_in);
+    if (d->h_out) hipHostFree(d->h_out);
+    if (d->gs) hipStreamDestroy(d->gs);
     rade_batch_close(d->eng); hipFree(d->d_in); hipFree(d->d_out); free(d);
 }
 
@@ -138,6 +146,36 @@ void rade_init_encoder(RADEEncState *s) { memset(s, 0, sizeof *s); }     /* rade
 void rade_init_decoder(RADEDecState *s) { memset(s, 0, sizeof *s); }
 void rade_free_encoder(RADEEncState *s) { if (s && s->initialized) dev_close(s->dev); if (s) memset(s, 0, sizeof *s); }
 void rade_free_decoder(RADEDecState *s) { if (s && s->initialized) dev_close(s->dev); if (s) memset(s, 0, sizeof *s); }
+
+/* one step through the engine: in[n_in] (host) -> out[n_out] (host); enc selects rade_batch_encode / rade_batch_decode */
+static int core_step(core_dev *d, int enc, const float *in, int n_in, float *out, int n_out)
+{
+    int ok = 0;
+    if (d->calls > 0 && !d->graph_off) {
+        if (!d->graph) {                                       /* second call: record the sequence (nothing runs during capture) */
+            hipGraph_t g = NULL;
+            int c = hipStreamBeginCapture(d->gs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (c) {
+                c = hipMemcpyAsync(d->d_in, d->h_in, sizeof(float) * n_in, hipMemcpyHostToDevice, d->gs) == hipSuccess &&
+                    (enc ? rade_batch_encode(d->eng, d->d_in, 1, d->d_out, d->gs) : rade_batch_decode(d->eng, d->d_in, 1, d->d_out, 0, d->gs)) == 1 &&
+                    hipMemcpyAsync(d->h_out, d->d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost, d->gs) == hipSuccess;
+                if (hipStreamEndCapture(d->gs, &g) != hipSuccess) c = 0;
+            }
+            if (c && hipGraphInstantiate(&d->graph, g, NULL, NULL, 0) != hipSuccess) { c = 0; d->graph = NULL; }
+            if (g) hipGraphDestroy(g);
+            if (!c) { d->graph_off = 1; (void)hipGetLastError(); }
+        }
+        if (d->graph) {
+            memcpy(d->h_in, in, sizeof(float) * n_in);
+            if (hipGraphLaunch(d->graph, d->gs) == hipSuccess && hipStreamSynchronize(d->gs) == hipSuccess) { memcpy(out, d->h_out, sizeof(float) * n_out); ok = 1; }
+        }
+    }
+    if (!ok) ok = hipMemcpy(d->d_in, in, sizeof(float) * n_in, hipMemcpyHostToDevice) == hipSuccess &&
+                  (enc ? rade_batch_encode(d->eng, d->d_in, 1, d->d_out, NULL) : rade_batch_decode(d->eng, d->d_in, 1, d->d_out, 0, NULL)) == 1 &&
+                  hipMemcpy(out, d->d_out, sizeof(float) * n_out, hipMemcpyDeviceToHost) == hipSuccess;
+    d->calls++;
+    return ok ? 0 : -1;
+}
 
 static void die(const char *what) { fprintf(stderr, "%s: device error (this library has no CPU fallback)\n", what); exit(1); }
 
@@ -150,9 +188,7 @@ void rade_core_encoder(RADEEncState *s, const RADEEnc *model, float *z, const fl
         s->initialized = 1;
     }
     core_dev *d = s->dev;
-    if (hipMemcpy(d->d_in, features, sizeof(float) * d->dim, hipMemcpyHostToDevice) != hipSuccess ||
-        rade_batch_encode(d->eng, d->d_in, 1, d->d_out, NULL) != 1 ||
-        hipMemcpy(z, d->d_out, sizeof(float) * RADE_LATENT_DIM, hipMemcpyDeviceToHost) != hipSuccess) die("rade_core_encoder");
+    if (core_step(d, 1, features, d->dim, z, RADE_LATENT_DIM)) die("rade_core_encoder");
     if (bottleneck == 1) for (int i = 0; i < RADE_LATENT_DIM; i++) z[i] = tanhf(z[i]);      /* rade_enc.c:113 / radae_base.py:281-284 */
 }
 
@@ -165,7 +201,5 @@ void rade_core_decoder(RADEDecState *s, const RADEDec *model, float *features, c
         s->initialized = 1;
     }
     core_dev *d = s->dev;
-    if (hipMemcpy(d->d_in, z_hat, sizeof(float) * RADE_LATENT_DIM, hipMemcpyHostToDevice) != hipSuccess ||
-        rade_batch_decode(d->eng, d->d_in, 1, d->d_out, 0, NULL) != 1 ||
-        hipMemcpy(features, d->d_out, sizeof(float) * d->dim, hipMemcpyDeviceToHost) != hipSuccess) die("rade_core_decoder");
+    if (core_step(d, 0, z_hat, RADE_LATENT_DIM, features, d->dim)) die("rade_core_decoder");
 }

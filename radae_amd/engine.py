@@ -74,6 +74,7 @@ def load_library() -> C.CDLL:
     L.rade_batch_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.rade_batch_rx_set_lcg.argtypes = [vp, C.POINTER(C.c_uint)]
     L.rade_batch_rx_get_trace.argtypes = [vp, C.c_int, C.POINTER(RxTrace), vp, C.c_int]
+    L.rade_batch_rx_stream_cycles.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -88,6 +89,7 @@ EXPORTED_SYMBOLS = [
     "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
+    "rade_batch_rx_stream_cycles",
     "rade_multi_open", "rade_multi_close", "rade_multi_n_devices", "rade_multi_transport", "rade_multi_engine", "rade_multi_shard", "rade_multi_foreach",
     "rade_multi_allreduce_sum",
 ]
@@ -296,6 +298,13 @@ class BatchEngine:
         if r:
             raise RuntimeError("rade_batch_rx failed")
         return features_out, list(status), eoo
+
+    def rx_stream_cycles(self) -> np.ndarray:
+        """Shader-clock cycles each stream's workgroup spent in the most recent receiver launch."""
+        out = np.zeros(self.B, np.int64)
+        if self.lib.rade_batch_rx_stream_cycles(self.h, out.ctypes.data_as(C.c_void_p)) != self.B:
+            raise RuntimeError("rade_batch_rx_stream_cycles failed")
+        return out
 
     def rx_trace(self, b: int = 0):
         """Per-call trace of stream b in the layout of tests/golden/rxtrace_*.npz."""

@@ -24,8 +24,6 @@ for rep in range(int(os.environ.get("REPS", "3"))):
     iq_bad = [b for b in range(8, B) if not torch.equal(iq[b], iq[b % 8])]; rx_bad = [b for b in range(8, B) if not torch.equal(rx[b], rx[b % 8])]
     if iq_bad or rx_bad: print(f"rep {rep}: tx replicas differ {iq_bad[:8]}, channel replicas differ {rx_bad[:8]}")
     nv = np.array([s.n_valid for s in st])
-    hunt = eng.rx_stream_cycles()
-    if os.environ.get('HUNT'): print('hunt codes:', sorted(set(int(x) for x in hunt if x < 999999999))[:10], [int(b) for b in np.nonzero(hunt < 999999999)[0][:10]])
     bad = 0
     if TR == 0:
         odd = [b for b in range(8, B) if nv[b] != nv[b % 8] or not torch.equal(fo[b], fo[b % 8])]

@@ -52,6 +52,23 @@ for k in mf:
         sh = {kk: (round(v, 4) if v is not None else None) for kk, v in sh.items()}
         sh["bound"] = ("latency (s_waitcnt/s_barrier)" if sh["parked_s_waitcnt_s_barrier"] > 0.4 else "issue") + (" + valu-issue" if sh["issuing_valu"] > 0.15 else "")
         out["sq_breakdown"][k] = sh
+# where k_rx_sync's counter bytes go (per launch): what can be computed from the call counts of the un-profiled bench line, the rest by difference
+try:
+    bl = json.load(open(os.path.join(dst, tag + "_bench_line.json")))
+    c = bl["roofline"]["per_launch_counts"]; k = out["kernels"]["k_rx_sync"]; B = bl["config"]["streams_per_gpu"]
+    surf = 960 * 40 * 4
+    rd = {"rx samples in (algorithmic)": 640.0 * c["offered_frames"], "|Dt| surface of the previous search call (dtcache)": c["search_calls"] * surf,
+          "per-stream state at launch start": B * 33e3, "decoder latents / history (zrows, hist)": c["decoded_modem_frames"] * 960 + c["decoded_modem_frames"] / 8 * 2944 * 1.0}
+    wr = {"features out (algorithmic)": 144.0 * 12 * c["decoded_modem_frames"], "|Dt| surface written by every search call (dtcache)": c["search_calls"] * surf,
+          "per-stream state at launch end": B * 33e3, "decoder latents, 84-float rows, history": c["decoded_modem_frames"] * (960 + 1008) + c["decoded_modem_frames"] / 8 * 2944}
+    rd["remainder: L2 misses on weights / FFT tables / pilot planes + scratch reloads"] = k["fetch_bytes_per_dispatch"] - sum(rd.values())
+    wr["remainder: scratch spills (about 2.5 M wave-stores of 256 B)"] = k["write_bytes_per_dispatch"] - sum(wr.values())
+    out["rx_sync_traffic_breakdown_bytes_per_launch"] = {"fetch_raw": k["fetch_bytes_per_dispatch"], "write_raw": k["write_bytes_per_dispatch"], "fetch": rd, "write": wr,
+        "algorithmic_io_bytes": 784.0 * c["offered_frames"], "ratio_raw_over_io": (k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]) / (784.0 * c["offered_frames"]),
+        "ratio_raw_over_io_plus_search_state": (k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]) / (784.0 * c["offered_frames"] + 2 * c["search_calls"] * surf),
+        "note": "the |Dt| surface (960 x 40 float32 = 153.6 KB) a search call leaves for the next one is state the reference's algorithm defines (dsp.py keeps Dt1/Dt2 between calls); it does not fit beside the FFT work area in LDS and must stay float32 for the arg-max to stay bit-exact"}
+except Exception as e:
+    print("traffic breakdown skipped:", e)
 json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
 for k, v in out["kernels"].items():
     if v["gpu_cycles_per_dispatch"] > 1e5: print(f"{k[:40]:40s} n={v['dispatches']:4d} cyc={v['gpu_cycles_per_dispatch']:.3g} mfma_busy={v['mfma_busy_pct']:.1f}% fetch={v['fetch_bytes_per_dispatch']/1e6:.1f}MB write={v['write_bytes_per_dispatch']/1e6:.1f}MB l2hit={v.get('l2_hit_rate')} sq={out['sq_breakdown'].get(k)}")
