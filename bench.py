@@ -216,6 +216,12 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         if dom == "rx_sync":
             r["traffic_ratio"] = raw / (RX_ALGO_BYTES_PER_FRAME * B * T)
             r["traffic_ratio_wide_corrected"] = r["traffic_fetch_wide_corrected"] / (RX_ALGO_BYTES_PER_FRAME * B * T)
+        tb = pm.get("rx_sync_traffic_breakdown_bytes_per_launch")
+        if tb and dom == "rx_sync":
+            r["traffic_ratio_incl_search_state"] = tb["ratio_raw_over_io_plus_search_state"]      # |Dt| surfaces kept between search calls counted as algorithmic state
+            r["traffic_breakdown"] = f"profiles/{PROFILE_TAG}_pmc_summary.json:rx_sync_traffic_breakdown_bytes_per_launch"
+        if "l2_hit_rate" in k:
+            r["l2_hit_rate_pmc"] = k["l2_hit_rate"]
         r["mfma_busy_pct_pmc"] = k["mfma_busy_pct"]
         r["counters_from"] = f"profiles/{PROFILE_TAG}_pmc_summary.json (commit {pm.get('commit', '?')})"
         sq = pm.get("sq_breakdown", {}).get("k_rx_sync")
