@@ -9,8 +9,12 @@ O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 # 1. the plain bench line (un-profiled) that the roofline block is quoted from
 python $R/bench.py --steps 100 --warmup 5 > $O/bench_line.json 2> $O/bench_line.err
 # 2. rocprofv3 --kernel-trace --stats of the same command (shorter: the trace of 100 steps is large)
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity"
+#    --pipeline 1: kernel durations with one batch in flight, which is how bench.py's roofline leg times them (HIP events); the
+#    second pass is the default command (two batches in flight: a launch's duration then includes CUs shared with the other batch)
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --pipeline 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- $CMD > $O/bench_under_rocprof.json 2> $O/stats.err
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-parity --no-roofline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_pipe -o bench -- $CMD > $O/bench_pipelined_under_rocprof.json 2> $O/stats_pipe.err
 # 3. counters, one pass each
 CMD1="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-parity"
 pass() { n=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc_$n -o pmc -- $CMD1 > /dev/null 2> $O/pmc_$n.err; }

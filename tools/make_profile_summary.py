@@ -7,7 +7,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(R, "gpurun_out", "prof_" + tag); dst = os.path.join(R, "profiles")
 shutil.copy(glob.glob(os.path.join(src, "stats", "**", "bench_kernel_stats.csv"), recursive=True)[0], os.path.join(dst, tag + "_bench_kernel_stats.csv"))
-for name in ("bench_under_rocprof", "bench_line", "stream_cycles"):
+pp = glob.glob(os.path.join(src, "stats_pipe", "**", "bench_kernel_stats.csv"), recursive=True)
+if pp: shutil.copy(pp[0], os.path.join(dst, tag + "_bench_pipelined_kernel_stats.csv"))      # the default command (two batches in flight)
+for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles"):
+    if not os.path.exists(os.path.join(src, name + ".json")): continue
     line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
 
