@@ -27,6 +27,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two IEEE fused multiply-adds per lane in one instruction (v_pk_fma_f32: the full-rate f32 path of the vector ALU)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #define PI_D 3.14159265358979323846
@@ -738,14 +741,16 @@ __device__ void dq_scan(DecShared *sh, const float *Whh, const float *bhh, float
     const int tid = rx_tid();
     const bool on = tid < 4 * H;
     const int j = on ? tid >> 2 : 0, p = tid & 3;
-    float wr[KP], wz[KP], wn[KP];
+    f32x2 wr[KP / 2], wz[KP / 2], wn[KP / 2];            // weight pairs (k, k+1): the products run as v_pk_fma_f32, two per lane and instruction
     {
         const float *w0 = Whh + (size_t)j * H + p * KP;
 #pragma unroll
         for (int k = 0; k < KP; k += 4) {
             const f32x4 v0 = *(const f32x4 *)(w0 + k), v1 = *(const f32x4 *)(w0 + (size_t)H * H + k), v2 = *(const f32x4 *)(w0 + (size_t)2 * H * H + k);
 #pragma unroll
-            for (int u = 0; u < 4; u++) { wr[k + u] = v0[u]; wz[k + u] = v1[u]; wn[k + u] = v2[u]; }
+            for (int u = 0; u < 2; u++) {
+                wr[k / 2 + u] = (f32x2){ v0[2 * u], v0[2 * u + 1] }; wz[k / 2 + u] = (f32x2){ v1[2 * u], v1[2 * u + 1] }; wn[k / 2 + u] = (f32x2){ v2[2 * u], v2[2 * u + 1] };
+            }
         }
     }
     const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
@@ -765,18 +770,19 @@ __device__ void dq_scan(DecShared *sh, const float *Whh, const float *bhh, float
         const float g1 = gi[(size_t)min(t + 1, Tb - 1) * 288];           // next step's input: its LDS latency hides under this step
         // six independent accumulation chains (two per gate): the step is a chain of dependent instructions on a wavefront
         // that shares its SIMD with at most one other, so the length of the longest chain is the step's time
-        float sr = 0.0f, sz = 0.0f, sn = 0.0f, sr2 = 0.0f, sz2 = 0.0f, sn2 = 0.0f;
+        f32x2 ar = { 0.0f, 0.0f }, az = { 0.0f, 0.0f }, an = { 0.0f, 0.0f }, ar2 = { 0.0f, 0.0f }, az2 = { 0.0f, 0.0f }, an2 = { 0.0f, 0.0f };
         const float *hp = sh->hs[cur] + p * KP;
 #pragma unroll
         for (int k = 0; k < KP; k += 8) {
             const f32x4 hv = *(const f32x4 *)(hp + k), hw = *(const f32x4 *)(hp + k + 4);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                sr += wr[k + u] * hv[u]; sz += wz[k + u] * hv[u]; sn += wn[k + u] * hv[u];
-                sr2 += wr[k + 4 + u] * hw[u]; sz2 += wz[k + 4 + u] * hw[u]; sn2 += wn[k + 4 + u] * hw[u];
-            }
+            const f32x2 h0 = { hv[0], hv[1] }, h1 = { hv[2], hv[3] }, h2 = { hw[0], hw[1] }, h3 = { hw[2], hw[3] };
+            ar = pk_fma(wr[k / 2], h0, ar); az = pk_fma(wz[k / 2], h0, az); an = pk_fma(wn[k / 2], h0, an);
+            ar2 = pk_fma(wr[k / 2 + 1], h1, ar2); az2 = pk_fma(wz[k / 2 + 1], h1, az2); an2 = pk_fma(wn[k / 2 + 1], h1, an2);
+            ar = pk_fma(wr[k / 2 + 2], h2, ar); az = pk_fma(wz[k / 2 + 2], h2, az); an = pk_fma(wn[k / 2 + 2], h2, an);
+            ar2 = pk_fma(wr[k / 2 + 3], h3, ar2); az2 = pk_fma(wz[k / 2 + 3], h3, az2); an2 = pk_fma(wn[k / 2 + 3], h3, an2);
         }
-        sr += sr2; sz += sz2; sn += sn2;
+        ar += ar2; az += az2; an += an2;
+        float sr = ar[0] + ar[1], sz = az[0] + az[1], sn = an[0] + an[1];
         sr += quad_dpp<QUAD_XOR1>(sr); sz += quad_dpp<QUAD_XOR1>(sz); sn += quad_dpp<QUAD_XOR1>(sn);
         sr += quad_dpp<QUAD_XOR2>(sr); sz += quad_dpp<QUAD_XOR2>(sz); sn += quad_dpp<QUAD_XOR2>(sn);
         const float gr = quad_dpp<QUAD_BC0>(g0), gz = quad_dpp<QUAD_BC1>(g0), gn = quad_dpp<QUAD_BC2>(g0);
@@ -1225,6 +1231,7 @@ struct RxScalars {
     uint32_t lcg;
     unsigned rxmax_cur, rxmax_h0, rxmax_h1;   // float bits of max |re|,|im| of the filtered samples of this call / the two calls before (check_pilots operand scale)
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
+    int pf_n;                 // samples of the NEXT call already mixed down into xm[102..] by the end of this (synchronised) call; 0 = none
     int entry;                // this candidate call enters sync (decided by thread 0 before a barrier: see do_entry)
     int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
     float snr_est, mag; float2 bpf_phase;
@@ -1749,7 +1756,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
         S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0;
+        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0; S->pf_n = 0;
     }
     const int avail = a.avail[b];
     const long long wg_t0 = clock64();                 // per-stream duration of this launch (tail analysis: the launch lasts as long as its slowest stream)
@@ -1770,6 +1777,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             // ... or when this launch ends for the stream (out of samples, call limit)
             S->need_decode = S->n_rows > 0 && (!go || (S->state == ST_SYNC && ((S->synced_count + 1) % 8) == 0) || S->n_rows + 3 > a.dec_rows);
             S->go = go;
+            if (!go || S->need_decode) S->pf_n = 0;              // the decoder stage overlays xm
             if (go) { S->rxmax_h1 = S->rxmax_h0; S->rxmax_h0 = S->rxmax_cur; S->rxmax_cur = 0u; }   // rx_buf holds this call's samples and (parts of) the two calls' before
             S->state_before = S->state; S->nin_before = S->nin;
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
@@ -1821,9 +1829,11 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         }
 
         // ---- complex_bpf.bpf (dsp.py:63-102)
-        const float2 *xin = rxin + S->consumed_inv;
+        const int cons0 = S->consumed_inv;
+        const float2 *xin = rxin + cons0;
+        const bool staged = S->pf_n == nin && ml == 102;      // the previous call fetched and mixed these samples while its equaliser ran
         for (int i = tid; i < ml; i += NT_RX) sh->xm[i] = sh->bmem[i];
-        for (int i = tid; i < nin; i += NT_RX) { sh->xm[ml + i] = cmul(xin[i], cmul(bpf_phase, ld2(tab->bpf_E, i))); }
+        if (!staged) for (int i = tid; i < nin; i += NT_RX) { sh->xm[ml + i] = cmul(xin[i], cmul(bpf_phase, ld2(tab->bpf_E, i))); }
         __syncthreads();
         PH(18);
         // 101-tap FIR, three consecutive outputs per thread over a sliding register window (one LDS read per tap and
@@ -1838,38 +1848,58 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             sh->rows48[k] = (int)((x >> 8) % RD_NMF);
             if (k == 47) sh->redi[15] = (int)x;                                        // the new LCG state, committed after the barrier below
         }
+        if (tid >= NT_RX - 128 && tid < NT_RX - 64) {
+            // the call after this one reads the next 800..1120 samples of the stream: their first touch costs an HBM access and,
+            // with 256 streams spread over as many separate regions, an address translation (about 5,000 cycles together).  This
+            // wavefront has nothing else to do during the FIR, so it takes that miss now (one load per 128-byte line, values
+            // dropped); the real fetch -- under the equaliser of a synchronised call, at the start of the next call otherwise --
+            // then finds the lines in the L2.
+            const int l = tid - (NT_RX - 128), rem = min(avail - cons0 - nin, RD_NINMAX);
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 2; q++) { const int i = (l + 64 * q) * 16; if (i < rem) t += xin[nin + i].x; }
+            asm volatile("" :: "v"(t));
+        }
         float2 filt[3];
         {
             const int i0 = 3 * tid;
             float2 eup[3];                                  // mix-up phasors of this thread's outputs: fetched ahead of the FIR
 #pragma unroll
             for (int j = 0; j < 3; j++) eup[j] = ld2(tab->bpf_E, min(i0 + j, RD_NINMAX - 1));
-            float ar[3] = { 0.0f, 0.0f, 0.0f }, ai[3] = { 0.0f, 0.0f, 0.0f };
+            f32x2 acc[3] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };      // (re, im) of three outputs: one v_pk_fma_f32 per tap and output
             if (i0 < nin) {
+                const f32x2 *xm2 = (const f32x2 *)sh->xm;
 #pragma unroll 2
                 for (int kb = 0; kb < 96; kb += 8) {
-                    float2 x[10]; float h[8];
+                    f32x2 x[10]; float h[8];
 #pragma unroll
-                    for (int u = 0; u < 10; u++) x[u] = sh->xm[i0 + kb + u];
+                    for (int u = 0; u < 10; u++) x[u] = xm2[i0 + kb + u];
 #pragma unroll
                     for (int u = 0; u < 8; u++) h[u] = sh->bpf_h[kb + u];
 #pragma unroll
-                    for (int u = 0; u < 8; u++)
+                    for (int u = 0; u < 8; u++) {
+                        const f32x2 hh = { h[u], h[u] };
 #pragma unroll
-                        for (int j = 0; j < 3; j++) { ar[j] = fmaf(x[u + j].x, h[u], ar[j]); ai[j] = fmaf(x[u + j].y, h[u], ai[j]); }
+                        for (int j = 0; j < 3; j++) acc[j] = pk_fma(x[u + j], hh, acc[j]);
+                    }
                 }
                 {
-                    float2 x[7]; float h[5];
+                    f32x2 x[7]; float h[5];
 #pragma unroll
-                    for (int u = 0; u < 7; u++) x[u] = sh->xm[i0 + 96 + u];
+                    for (int u = 0; u < 7; u++) x[u] = xm2[i0 + 96 + u];
 #pragma unroll
                     for (int u = 0; u < 5; u++) h[u] = sh->bpf_h[96 + u];
 #pragma unroll
-                    for (int u = 0; u < 5; u++)
+                    for (int u = 0; u < 5; u++) {
+                        const f32x2 hh = { h[u], h[u] };
 #pragma unroll
-                        for (int j = 0; j < 3; j++) { ar[j] = fmaf(x[u + j].x, h[u], ar[j]); ai[j] = fmaf(x[u + j].y, h[u], ai[j]); }
+                        for (int j = 0; j < 3; j++) acc[j] = pk_fma(x[u + j], hh, acc[j]);
+                    }
                 }
             }
+            float ar[3], ai[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) { ar[j] = acc[j][0]; ai[j] = acc[j][1]; }
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 const int i = i0 + j;
@@ -1899,7 +1929,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         for (int j = 0; j < 3; j++) { const int i = 3 * tid + j; if (i < nin) sh->rxb[RD_RXBUF - nin + i] = filt[j]; }
         if (tid < 102) sh->bmem[tid] = memv;
         if (tid == 0) {
-            S->bpf_phase = cmul(bpf_phase, e_last);
+            S->bpf_phase = cmul(bpf_phase, e_last); S->pf_n = 0;
             if (state == ST_SYNC) S->lcg = (uint32_t)sh->redi[15];
             S->bpf_mem_len = 102; S->consumed_inv += nin; S->consumed_round += nin;
         }
@@ -2108,6 +2138,22 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             if (tid == NT_RX - 64) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
             if (tid == NT_RX - 128) state_update(0, !endofover, endofover);   // valid_output of a synchronised call = !endofover (set by the EQ below)
             PH(7);
+            // The NEXT call's input, fetched under the demodulator and the equaliser (an HBM / L2 round trip of several thousand
+            // cycles that would otherwise open the next call): up to nin_max samples and their mix-down phasors -- the next size
+            // and whether there is a next call are settled by the state update running beside the DFT, so the decision what to
+            // keep comes at the end of this call, where the samples are stored mixed down into xm (free from the DFT on).  Same
+            // products as the BPF stage computes, so the result does not depend on which of the two ran.
+            float2 pfx[3], pfe[3];
+            {
+                const int lim = min(avail - S->consumed_inv, RD_NINMAX);
+                const float2 *xn = rxin + S->consumed_inv;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const int i = tid + q * NT_RX;
+                    pfx[q] = pfe[q] = make_float2(0.0f, 0.0f);
+                    if (i < lim) { pfx[q] = xn[i]; pfe[q] = ld2(tab->bpf_E, i); }
+                }
+            }
             // receiver_one (dsp.py:487-526): window [16:176] of each 192-sample symbol, 160->30 DFT
             // two lanes per (symbol, carrier), 80 samples each in four independent chains; the halves meet through a lane swap
             if (tid < 2 * 6 * RD_NC) {
@@ -2126,6 +2172,13 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             __syncthreads();
             PH(8);
+            int pf_n = 0;                                        // settled now (state update above): is there a next call, does the decoder stage run first
+            {
+                const int nn = S->nin;
+                const bool go_n = !(S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls || S->valid_inv >= a.feat_cap) && S->consumed_inv + nn <= avail;
+                const bool dec_n = S->n_rows > 0 && ((S->state == ST_SYNC && ((S->synced_count + 1) % 8) == 0) || S->n_rows + 3 > a.dec_rows);
+                if (go_n && !dec_n) pf_n = nn;
+            }
             float *zrow = a.zrows + ((size_t)b * a.dec_rows + n_rows) * RD_LATENT;   // 3 rows = 240 contiguous floats
             float *eoo_dst = a.eoo_out ? a.eoo_out + (size_t)b * RD_NEOOBITS : nullptr;
             const int call_idx0 = mf0 - 1;
@@ -2205,6 +2258,12 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     if (eoo_dst) { eoo_dst[2 * tid] = v.x; eoo_dst[2 * tid + 1] = v.y; }
                     if (a.trace_z && call_idx0 < a.trace_cap) { float *tz = a.trace_z + ((size_t)b * a.trace_cap + call_idx0) * RD_ZMF; tz[2 * tid] = v.x; tz[2 * tid + 1] = v.y; }
                 }
+            }
+            if (pf_n) {
+                const float2 ph = S->bpf_phase;                  // already advanced to the next call's start by this call's BPF stage
+#pragma unroll
+                for (int q = 0; q < 3; q++) { const int i = tid + q * NT_RX; if (i < pf_n) sh->xm[102 + i] = cmul(pfx[q], cmul(ph, pfe[q])); }
+                if (tid == 0) S->pf_n = pf_n;
             }
             __syncthreads();
         }
