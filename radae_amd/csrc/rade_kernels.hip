@@ -1246,6 +1246,8 @@ struct RxShared {
     float2 sym[6][RD_NC];
     float2 rp[2][RD_NC];
     __attribute__((aligned(16))) float bpf_h[RD_NTAP + 3];
+    float eqP[RD_NC]; float2 eqPmat[RD_NC][2][3], eqrot[RD_NC];   // est_pilots' constants (dsp.py:400-433): an L2 round trip per call if read from the table in HBM
+    float eq_pg, eq_snrc1, eq_snrc2;                                // pilot_gain and the SNR estimator's constants
     union {
       struct {
         __attribute__((aligned(16))) float2 xm[1408];   // BPF [mem | mixed-down new] (1224); refine(): rx window as doubles (11264 B); rx1[1152] for the demod
@@ -1454,8 +1456,11 @@ __device__ RD_DETECT_INLINE void rx_detect_fft(RxShared *sh, const float *G_, co
     }
 }
 
-// max reduction with lexicographic tie-break (smaller k0, then smaller k1 wins); result in sh->redf[0], redi[0], redj[0]
-__device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
+// max reduction with lexicographic tie-break (smaller k0, then smaller k1 wins); every thread returns with the winner in (v, k0, k1).
+// One barrier: the per-wave winners go to LDS and EVERY thread combines the eight of them (no single-thread pass, no second and
+// third barrier).  The caller guarantees a workgroup barrier between the previous reduction's reads and this call (both call sites
+// come straight after one), which is what keeps the partial slots safe to overwrite.
+__device__ void block_argmax(RxShared *sh, float &v, int &k0, int &k1)
 {
     const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
     // max under a total order: any combination order gives the same winner; quad / row steps on DPP, rows through readlane
@@ -1472,42 +1477,38 @@ __device__ void block_argmax(RxShared *sh, float v, int k0, int k1)
         }
         v = bv; k0 = b0; k1 = b1;
     }
-    __syncthreads();                                   // previous readers of slot 0 are done
     if (lane == 0) { sh->redf[1 + wave] = v; sh->redi[1 + wave] = k0; sh->redj[1 + wave] = k1; }
     __syncthreads();
-    if (tid == 0) {
-        float bv = sh->redf[1]; int b0 = sh->redi[1], b1 = sh->redj[1];
-        for (int w = 1; w < NT_RX / 64; w++) {
-            const float ov = sh->redf[1 + w]; const int o0 = sh->redi[1 + w], o1 = sh->redj[1 + w];
-            if (ov > bv || (ov == bv && (o0 < b0 || (o0 == b0 && o1 < b1)))) { bv = ov; b0 = o0; b1 = o1; }
-        }
-        sh->redf[0] = bv; sh->redi[0] = b0; sh->redj[0] = b1;
+    float bv = sh->redf[1]; int b0 = sh->redi[1], b1 = sh->redj[1];
+#pragma unroll
+    for (int w = 1; w < NT_RX / 64; w++) {
+        const float ov = sh->redf[1 + w]; const int o0 = sh->redi[1 + w], o1 = sh->redj[1 + w];
+        if (ov > bv || (ov == bv && (o0 < b0 || (o0 == b0 && o1 < b1)))) { bv = ov; b0 = o0; b1 = o1; }
     }
-    __syncthreads();
+    v = bv; k0 = b0; k1 = b1;
 }
 
-// sum NV doubles per thread over the workgroup: wave shuffles, then one LDS pass; result in sh->redd[0..NV)
-// Entries k >= KALL are non-zero only in the first NW wavefronts (the caller's contract): the others skip their f64 reductions.
-// redd is private to this routine and every call ends with a barrier, so none is needed before the partials are stored.
-template <int NV, int KALL = NV, int NW = NT_RX / 64>
+// sum NV doubles per thread over the workgroup: wave shuffles, the per-wave sums to LDS, one barrier, then every thread adds the
+// eight partials in wave order (same order, hence same rounding, in every thread).  Same contract as block_argmax: a workgroup
+// barrier lies between the previous call's reads of redd and this call.
+template <int NV>
 __device__ void block_sum_multi(RxShared *sh, double (&v)[NV])
 {
     const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        if (k < KALL || wave < NW) v[k] = wave_sum_f64(v[k]);
-        else v[k] = 0.0;
-    }
+    for (int k = 0; k < NV; k++) v[k] = wave_sum_f64(v[k]);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < NV; k++) sh->redd[wave * NV + k] = v[k];
     }
     __syncthreads();
-    if (tid < NV) { double t = 0.0; for (int w = 0; w < NT_RX / 64; w++) t += sh->redd[w * NV + tid]; sh->redd[(NT_RX / 64) * NV + tid] = t; }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = sh->redd[(NT_RX / 64) * NV + k];
-    __syncthreads();
+    for (int k = 0; k < NV; k++) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT_RX / 64; w++) t += sh->redd[w * NV + k];
+        v[k] = t;
+    }
 }
 
 __device__ __forceinline__ float sigma_r_from_sums(double t1, double t2)
@@ -1657,9 +1658,8 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
         if (v > best || (v == best && (fi < bf || (fi == bf && ti < bt)))) { best = v; bf = fi; bt = ti; }
     }
     PH(14);
-    block_argmax(sh, best, bf, bt);
-    if (sh->redf[0] > 0.0f) { *tmax = t0 + sh->redj[0]; *fmax = fstart + sh->redi[0] * delta; }
-    __syncthreads();
+    block_argmax(sh, best, bf, bt);                                       // dtr and the window are free from its barrier on
+    if (best > 0.0f) { *tmax = t0 + bt; *fmax = fstart + bf * delta; }
     PH(15);
 }
 
@@ -1743,6 +1743,9 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
     // ---- load the stream's working set into LDS
     for (int i = tid; i < RD_RXBUF; i += NT_RX) sh->rxb[i] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]);
     for (int i = tid; i < RD_NTAP; i += NT_RX) sh->bpf_h[i] = tab->bpf_h[i];
+    if (tid == 0) { sh->eq_pg = tab->pilot_gain; sh->eq_snrc1 = tab->snr_c1; sh->eq_snrc2 = tab->snr_c2; }
+    if (tid < RD_NC) { sh->eqP[tid] = tab->P[tid]; sh->eqrot[tid] = make_float2(tab->eq_rot[tid][0], tab->eq_rot[tid][1]); }
+    if (tid < RD_NC * 6) { const int c = tid / 6, r = tid - 6 * c; sh->eqPmat[c][r / 3][r % 3] = make_float2(tab->Pmat[c][r / 3][r % 3][0], tab->Pmat[c][r / 3][r % 3][1]); }
     for (int i = tid; i < RD_M; i += NT_RX) { sh->pd[i] = make_double2(tab->p[i][0], tab->p[i][1]); sh->pendd[i] = make_double2(tab->pend[i][0], tab->pend[i][1]); }
     for (int i = tid; i < RD_NMF; i += NT_RX) { sh->rowsum1[i] = st->rowsum1[i]; sh->rowsum2[i] = st->rowsum2[i]; }
     for (int i = tid; i < 102; i += NT_RX) sh->bmem[i] = make_float2(st->bpf_mem[i][0], st->bpf_mem[i][1]);
@@ -1767,22 +1770,29 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         // opaque per-iteration copy: keeps the compiler from hoisting every thread-index address computation of the
         // loop body into registers that stay live across the whole call (they starve the FFT correlator of registers)
         int tid = threadIdx.x; asm volatile("" : "+v"(tid));
-        // ---- can this stream make another call right now?  (decided once, by thread 0)
-        if (tid == 0) {
-            int go = 1;
-            if (S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls || S->valid_inv >= a.feat_cap) go = 0;   // feat_cap: room in features_out
-            else if (S->consumed_inv + S->nin > avail) go = 0;
+        // ---- can this stream make another call right now?  Decided once, by thread 0: for the first call here, for every later
+        // one at the end of the call before it (same thread, just ahead of that call's closing barrier: no barrier of its own).
+        // Every operand is read up front and combined without branches -- a short-circuit chain is a chain of LDS round trips.
+        auto prepare_next = [&]() {
+            const int calls_inv = S->calls_inv, n_calls = S->n_calls, valid_inv = S->valid_inv, consumed = S->consumed_inv, nin_n = S->nin;
+            const int n_rows = S->n_rows, st_n = S->state, sc = S->synced_count;
+            const unsigned m0 = S->rxmax_h0, m1 = S->rxmax_cur, m2 = S->rxmax_h1;
+            const int go = (int)(calls_inv < a.max_calls) & (int)(n_calls < a.round_calls) & (int)(valid_inv < a.feat_cap) & (int)(consumed + nin_n <= avail);   // feat_cap: room in features_out
             // the decoder runs right here, in this workgroup, when its output is needed: before a unique-word check
             // (radae_rxe.py:220-224 looks at the aux bits of the 8 frames before this one) or when the row buffer is full
             // ... or when this launch ends for the stream (out of samples, call limit)
-            S->need_decode = S->n_rows > 0 && (!go || (S->state == ST_SYNC && ((S->synced_count + 1) % 8) == 0) || S->n_rows + 3 > a.dec_rows);
-            S->go = go;
-            if (!go || S->need_decode) S->pf_n = 0;              // the decoder stage overlays xm
-            if (go) { S->rxmax_h1 = S->rxmax_h0; S->rxmax_h0 = S->rxmax_cur; S->rxmax_cur = 0u; }   // rx_buf holds this call's samples and (parts of) the two calls' before
-            S->state_before = S->state; S->nin_before = S->nin;
+            const int need = (int)(n_rows > 0) & ((go ^ 1) | ((int)(st_n == ST_SYNC) & (int)(((sc + 1) % 8) == 0)) | (int)(n_rows + 3 > a.dec_rows));
+            S->need_decode = need; S->go = go;
+            if ((go ^ 1) | need) S->pf_n = 0;                    // the decoder stage overlays xm
+            S->rxmax_h1 = go ? m0 : m2; S->rxmax_h0 = go ? m1 : m0; S->rxmax_cur = go ? 0u : m1;   // rx_buf holds this call's samples and (parts of) the two calls' before
+            S->state_before = st_n; S->nin_before = nin_n;
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
+        };
+        if (it == 0) {
+            if (tid == 0) prepare_next();
+            __syncthreads();
         }
-        __syncthreads();
+        PH(28);
         if (S->need_decode) { PH(22); rx_decode_pending(sh, a, b); PH(20); }
         if (!S->go) break;
         const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
@@ -1960,9 +1970,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             PH(17);
             PH(2);
             block_argmax(sh, best, bt, bfi);
-            const float Dmax = sh->redf[0]; const int tbest = sh->redi[0], fbest = sh->redj[0];
-           
-            __syncthreads();
+            const float Dmax = best; const int tbest = bt, fbest = bfi;
             const float sr = sigma_r_from_rowsums(sh);
             if (tid == 0) {
                 S->Dthresh = (double)(2.0f * sr) * sqrt(-log(0.00001 / 5.0));
@@ -2109,6 +2117,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 block_sum_multi<2>(sh, rs2);
                 red[0] = rs2[0]; red[1] = rs2[1];
             }
+            PH(29);
 #pragma unroll
             for (int q = 0; q < 8; q++) red[2 + q] = sh->corrp[0][q] + sh->corrp[1][q];     // prepared during the matrix phase above
             const float sr = sigma_r_from_sums(red[0], red[1]);
@@ -2191,14 +2200,15 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     float2 g0 = make_float2(0.0f, 0.0f), g1 = g0;
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
-                        const float pp = tab->P[cm - 1 + k];
+                        const float pp = sh->eqP[cm - 1 + k];
                         const float2 h = make_float2(row[cm - 1 + k].x / pp, row[cm - 1 + k].y / pp);
-                        g0 = cadd(g0, cmul(make_float2(tab->Pmat[c][0][k][0], tab->Pmat[c][0][k][1]), h));
-                        g1 = cadd(g1, cmul(make_float2(tab->Pmat[c][1][k][0], tab->Pmat[c][1][k][1]), h));
+                        g0 = cadd(g0, cmul(sh->eqPmat[c][0][k], h));
+                        g1 = cadd(g1, cmul(sh->eqPmat[c][1][k], h));
                     }
-                    sh->rp[i][c] = cadd(g0, cmul(g1, make_float2(tab->eq_rot[c][0], tab->eq_rot[c][1])));
+                    sh->rp[i][c] = cadd(g0, cmul(g1, sh->eqrot[c]));
                 }
                 __syncthreads();
+                PH(30);
                 // update_snr_est (dsp.py:438-456) + coarse magnitude (:477-482): per-carrier terms reduced by wave shuffles
                 // two independent chains on two wavefronts: 0 = coarse magnitude (the EQ below waits for it), 1 = SNR estimate
                 if (tid < 128) {
@@ -2212,7 +2222,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                         pm = wave_sum_f32(pm);                                                   // lanes >= Nc hold zeros
                         if (c == 0) {
                             float mag = powf(pm / 60.0f, 0.5f) + 1e-6f;
-                            S->mag = (mag * fabsf(tab->P[0])) / tab->pilot_gain;
+                            S->mag = (mag * fabsf(sh->eqP[0])) / sh->eq_pg;
                             S->valid_output = 1;
                         }
                     } else {
@@ -2229,12 +2239,13 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                             if (snr <= 0.0f) snr = 0.1f;
                             float snrdB = 10.0f * log10f(snr);
                             snrdB = (snrdB - 2.513f) / 0.8070f;
-                            const float snr3k = snrdB + tab->snr_c1 + tab->snr_c2;
+                            const float snr3k = snrdB + sh->eq_snrc1 + sh->eq_snrc2;
                             S->snr_est = 0.9f * S->snr_est + 0.1f * snr3k;
                         }
                     }
                 }
                 __syncthreads();
+                PH(31);
                 const float mag = S->mag;
                 // linear-interpolated phase EQ of the 4 data symbols (:468-474), demap to z_hat
                 if (tid < RD_NS * RD_NC) {
@@ -2289,6 +2300,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 tr->snr_int = (int)S->snr_est; tr->fmax = S->fmax; tr->Dthresh = S->Dthresh; tr->Dtmax12 = S->Dtmax12; tr->Dtmax12_eoo = S->Dtmax12_eoo; tr->snrdB_3k_est = S->snr_est;
             }
         }
+        if (tid == 0) prepare_next();                      // the next call's go / decode decision (see the loop top)
         __syncthreads();
         PH(10);
     }
