@@ -28,6 +28,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // two IEEE fused multiply-adds per lane in one instruction (v_pk_fma_f32: the full-rate f32 path of the vector ALU)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -1259,6 +1260,7 @@ struct RxShared {
                 float2 dtr[2 * 80 * 16];      // refine(): complex64 Dt1 / Dt2 at [(frame * nf + f) * 16 + t]; does not overlap the FFT area
                 struct { char rpart_pad[8192]; double rpart[6][64][4]; };   // refine(), in-sync grid (dtr uses 5 KB): second-half partial tiles
             };
+            unsigned rxh[RD_RXBUF], rxl[RD_RXBUF];   // check_pilots: rx_buf x 2^(7-E) split in two binary16 planes, one dword = (re, im) of a sample
         };
         struct {                          // search / candidate state: FFT pilot correlator
             float2 fftX[FFT_N];           // spectrum of the rx_buf window being correlated
@@ -1729,6 +1731,70 @@ __device__ __forceinline__ void rx_decode_pending(RxShared *sh, const rd_sync_ar
     __syncthreads();
 }
 
+// check_pilots' row refresh for one (modem frame, group of NTN frequency tiles): three row tiles x NTN f-tiles of 16x16 outputs,
+// K = 160 samples x (re, im) in ten k-steps of three binary16-plane products each.  Row operands: the pre-split rx_buf planes in LDS
+// (4-byte aligned windows: dword reads); pilot operands: a.corr16 fragments from L2 in two register sets, each refilled for k-step
+// s + 2 as soon as the products of k-step s have issued, so an L2 round trip has two k-steps to complete.
+template <int NTN>
+__device__ __forceinline__ void check_rows_tiles(RxShared *sh, const unsigned short *corr16, int frame, int nt_base, int lane, float rx_unsc)
+{
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned *xh[3], *xl[3];
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++) { const int o = sh->rows48[rt * 16 + i] + frame * RD_NMF + 4 * g; xh[rt] = sh->rxh + o; xl[rt] = sh->rxl + o; }
+    const unsigned short *pt = corr16 + ((size_t)nt_base * 10 * 2 * 64 + lane) * 8;
+    f32x4 acc[3][NTN];
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+        for (int q = 0; q < NTN; q++) acc[rt][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    f16x8 p0h[NTN], p0l[NTN], p1h[NTN], p1l[NTN];
+    auto fetch = [&](f16x8 (&ph)[NTN], f16x8 (&pl)[NTN], int sidx) {
+#pragma unroll
+        for (int q = 0; q < NTN; q++) {
+            ph[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2) * 64 * 8);
+            pl[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2 + 1) * 64 * 8);
+        }
+    };
+    auto kstep = [&](const f16x8 (&ch)[NTN], const f16x8 (&cl)[NTN], int sidx) {
+        f16x8 ah[3], al[3];
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++) {
+            u32x4 vh, vl;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { vh[j] = xh[rt][16 * sidx + j]; vl[j] = xl[rt][16 * sidx + j]; }
+            ah[rt] = __builtin_bit_cast(f16x8, vh); al[rt] = __builtin_bit_cast(f16x8, vl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NTN; q++) {
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q], ah[rt], acc[rt][q], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], al[rt], acc[rt][q], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], ah[rt], acc[rt][q], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(p0h, p0l, 0); fetch(p1h, p1l, 1);
+#pragma unroll
+    for (int sidx = 0; sidx < 10; sidx += 2) {
+        kstep(p0h, p0l, sidx);
+        if (sidx + 2 < 10) fetch(p0h, p0l, sidx + 2);
+        kstep(p1h, p1l, sidx + 1);
+        if (sidx + 3 < 10) fetch(p1h, p1l, sidx + 3);
+    }
+    // C layout: column = lane & 15 (row draw), rows 4 (lane >> 4) + r = (re, im) of f = 8 nt + 2 g and f + 1
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+        for (int q = 0; q < NTN; q++) {
+            const int f = 8 * (nt_base + q) + 2 * g, r2 = 2 * (rt * 16 + i) + frame;
+            sh->absd[r2][f] = rx_unsc * hypotf(acc[rt][q][0], acc[rt][q][1]); sh->absd[r2][f + 1] = rx_unsc * hypotf(acc[rt][q][2], acc[rt][q][3]);
+        }
+}
+
 __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1792,7 +1858,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             if (tid == 0) prepare_next();
             __syncthreads();
         }
-        PH(28);
         if (S->need_decode) { PH(22); rx_decode_pending(sh, a, b); PH(20); }
         if (!S->go) break;
         const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
@@ -1991,6 +2056,21 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 const int tm = S->tmax; const double fm = S->fmax;
                 const int t0 = max(0, tm - 8);
                 int tnew = tm; double fhat = fm;
+                {   // check_pilots' operand planes of the whole rx_buf (read after refine(), whose barriers order these stores):
+                    // operand scale 2^(7 - E), E = exponent of the largest component in rx_buf: samples x scale stay below 256 (the
+                    // pilot planes carry 2^12); undone exactly in the |Dt| epilogue
+                    const unsigned mb = max(max(S->rxmax_cur, S->rxmax_h0), S->rxmax_h1);
+                    const int eb = min(max((int)((mb >> 23) & 0xffu), 32), 222);              // biased exponent, clamped so both factors stay normal
+                    const float rx_sc = __uint_as_float((unsigned)(127 + 7 - (eb - 127)) << 23);
+                    if (tid == 0) sh->redf[12] = __uint_as_float((unsigned)(127 - 12 - 7 + (eb - 127)) << 23);
+                    for (int i = tid; i < RD_RXBUF; i += NT_RX) {
+                        float2 v = sh->rxb[i]; v.x *= rx_sc; v.y *= rx_sc;
+                        const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y;
+                        const _Float16 l0 = (_Float16)(v.x - (float)h0), l1 = (_Float16)(v.y - (float)h1);
+                        sh->rxh[i] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                        sh->rxl[i] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                    }
+                }
                 rx_refine(sh, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true);      // tables: see the BPF stage
                 tm_ref = tnew; fm_ref = 0.9 * fm + 0.1 * fhat;
                 if (tid == 0) { S->tmax = tm_ref; S->fmax = fm_ref; }
@@ -1999,105 +2079,68 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             // check_pilots (dsp.py:273-320): refresh 48 pseudo-random rows
             // x_{i+1} = 1664525 x_i + 1013904223 (mod 2^32), 48 draws: thread i jumps straight to draw i (x_i = A^i x_0 + C_i)
             // (the draws were made during the BPF stage by an idle wavefront: rows48)
-            // 96 rows (48 draws x {Dt1, Dt2}) x 40 frequencies on the f16 matrix cores, operands split in two binary16
-            // planes: six tasks = 3 row tiles x {f-tiles 0-2, f-tiles 3-4}; the rx window of a row tile is converted
-            // once per k-step and reused by the task's f-tiles; the pilot planes stream from L2 (a.corr16)
+            // 96 rows (48 draws x {Dt1, Dt2}) x 40 frequencies on the f16 matrix cores, operands split in two binary16 planes.
+            // The rx_buf planes were split ONCE for this call (rxh / rxl, before refine()): every sample is an operand of up to
+            // 48 x 2 windows, and converting it inside the k loop (as this block did) was ~200 vector instructions per k-step
+            // and wavefront -- the pace of the whole phase.  Four wavefronts, one per SIMD: (frame, f-tile group) x all three row
+            // tiles, so each pilot plane fragment (L2, a.corr16) is applied to three row tiles.  The other four wavefronts do the
+            // scalar-ish f64 work that only depends on refine()'s result (below).
             {
                 const int wave = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
-                // operand scale 2^(7 - E), E = exponent of the largest component in rx_buf: samples x scale stay below 256 (the
-                // pilot planes carry 2^12); undone exactly in the |Dt| epilogue
-                const unsigned mb = max(max(S->rxmax_cur, S->rxmax_h0), S->rxmax_h1);
-                const int eb = min(max((int)((mb >> 23) & 0xffu), 32), 222);              // biased exponent, clamped so both factors stay normal
-                const float rx_sc = __uint_as_float((unsigned)(127 + 7 - (eb - 127)) << 23), rx_unsc = __uint_as_float((unsigned)(127 - 12 - 7 + (eb - 127)) << 23);
-                if (wave < 6) {
-                    const int rt = wave >> 1, nt_base = (wave & 1) ? 3 : 0, ntn = (wave & 1) ? 2 : 3;
-                    const int row = rt * 16 + i;
-                    const float *rxf = (const float *)&sh->rxb[0];
-                    const float *xa = rxf + 2 * sh->rows48[row] + 8 * g, *xb = xa + 2 * RD_NMF;
-                    const unsigned short *pt = a.corr16 + ((size_t)nt_base * 10 * 2 * 64 + lane) * 8;
-                    f32x4 accA[3], accB[3];
-#pragma unroll
-                    for (int q = 0; q < 3; q++) { accA[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; accB[q] = accA[q]; }
-                    f16x8 ph[3], pl[3];
-                    auto fetch = [&](int sidx) {
-#pragma unroll
-                        for (int q = 0; q < 3; q++) if (q < ntn) {
-                            ph[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2) * 64 * 8);
-                            pl[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2 + 1) * 64 * 8);
-                        }
-                    };
-                    fetch(0);
-#pragma unroll 1
-                    for (int sidx = 0; sidx < 10; sidx++) {
-                        f16x8 ah, al, bh, bl, ch[3], cl[3];
-#pragma unroll
-                        for (int j = 0; j < 8; j += 2) {
-                            float2 va = *(const float2 *)(xa + 32 * sidx + j), vb = *(const float2 *)(xb + 32 * sidx + j);
-                            va.x *= rx_sc; va.y *= rx_sc; vb.x *= rx_sc; vb.y *= rx_sc;           // 2^(7-E) (samples) x 2^12 (pilot planes)
-                            const _Float16 a0 = (_Float16)va.x, a1 = (_Float16)va.y, b0 = (_Float16)vb.x, b1 = (_Float16)vb.y;
-                            ah[j] = a0; ah[j + 1] = a1; al[j] = (_Float16)(va.x - (float)a0); al[j + 1] = (_Float16)(va.y - (float)a1);
-                            bh[j] = b0; bh[j + 1] = b1; bl[j] = (_Float16)(vb.x - (float)b0); bl[j + 1] = (_Float16)(vb.y - (float)b1);
-                        }
-#pragma unroll
-                        for (int q = 0; q < 3; q++) { ch[q] = ph[q]; cl[q] = pl[q]; }
-                        if (sidx + 1 < 10) fetch(sidx + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int q = 0; q < 3; q++) if (q < ntn) {
-                            accA[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q], ah, accA[q], 0, 0, 0);
-                            accB[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q], bh, accB[q], 0, 0, 0);
-                            accA[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], al, accA[q], 0, 0, 0);
-                            accB[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], bl, accB[q], 0, 0, 0);
-                            accA[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], ah, accA[q], 0, 0, 0);
-                            accB[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], bh, accB[q], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    // C layout: column = lane & 15 (row draw), rows 4 (lane >> 4) + r = (re, im) of f = 8 nt + 2 g and f + 1
-#pragma unroll
-                    for (int q = 0; q < 3; q++) if (q < ntn) {
-                        const int f = 8 * (nt_base + q) + 2 * g;
-                        sh->absd[2 * row][f] = rx_unsc * hypotf(accA[q][0], accA[q][1]); sh->absd[2 * row][f + 1] = rx_unsc * hypotf(accA[q][2], accA[q][3]);
-                        sh->absd[2 * row + 1][f] = rx_unsc * hypotf(accB[q][0], accB[q][1]); sh->absd[2 * row + 1][f + 1] = rx_unsc * hypotf(accB[q][2], accB[q][3]);
-                    }
+                const float rx_unsc = sh->redf[12];              // 2^(E - 19): undoes the operand scales exactly (set with the planes)
+#ifdef RD_PHASE_TIMING
+                const long long cr_t0 = clock64();
+#endif
+                if (wave < 4) {
+                    // straight-line code per tile count (a tile count known only at run time puts the fragment loads behind
+                    // branches, and the compiler then waits for ALL outstanding loads at the first use)
+                    if (wave < 2) check_rows_tiles<3>(sh, a.corr16, wave & 1, 0, lane, rx_unsc);
+                    else check_rows_tiles<2>(sh, a.corr16, wave & 1, 3, lane, rx_unsc);
                 } else {
-                    // ---- wavefronts 6 and 7 have no matrix work here.  refine() has fixed (tmax, fmax), so they prepare what the
+                    // ---- wavefronts 4..7 have no matrix work here.  refine() has fixed (tmax, fmax), so they prepare what the
                     // phases after this one used to compute with everybody waiting: the four correlations of check_pilots
-                    // (dsp.py:307-313) and the frequency-corrected window the demodulator reads (radae_rxe.py:209-218, :227-233)
-                    const int k = tid - 6 * 64;
+                    // (dsp.py:307-313; wavefronts 4 and 5, two samples per lane) and the frequency-corrected window the
+                    // demodulator reads (radae_rxe.py:209-218, :227-233; samples [0, 704) on wavefronts 6 and 7, the rest on 4 and 5)
+                    const int k = tid & 127, hi = wave >= 6;
                     const int tm = tm_ref; const double w = 2.0 * PI_D * fm_ref / 8000.0;
-                    double cr[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
-                    for (int n = k; n < RD_M; n += 128) {
-                        const float2 cf = cis_reduced(-w * n);
-                        const double sn = cf.y, cs = cf.x;
-                        const double2 rp = sh->pd[n], re = sh->pendd[n];
-                        const int t0s[4] = { tm, tm + RD_NMF, tm + RD_M + RD_NCP, tm + RD_NMF };
+                    if (!hi) {
+                        double cr[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
+                        for (int n = k; n < RD_M; n += 128) {
+                            const float2 cf = cis_reduced(-w * n);
+                            const double sn = cf.y, cs = cf.x;
+                            const double2 rp = sh->pd[n], re = sh->pendd[n];
+                            const int t0s[4] = { tm, tm + RD_NMF, tm + RD_M + RD_NCP, tm + RD_NMF };
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const float2 x = sh->rxb[t0s[q] + n];
-                            const double qr = cs * x.x - sn * x.y, qi = -(cs * x.y + sn * x.x);    // conj(w_vec*rx)
-                            const double2 r = q < 2 ? rp : re;
-                            cr[2 * q] += qr * r.x - qi * r.y; cr[2 * q + 1] += qr * r.y + qi * r.x;
+                            for (int q = 0; q < 4; q++) {
+                                const float2 x = sh->rxb[t0s[q] + n];
+                                const double qr = cs * x.x - sn * x.y, qi = -(cs * x.y + sn * x.x);    // conj(w_vec*rx)
+                                const double2 r = q < 2 ? rp : re;
+                                cr[2 * q] += qr * r.x - qi * r.y; cr[2 * q + 1] += qr * r.y + qi * r.x;
+                            }
                         }
-                    }
 #pragma unroll
-                    for (int q = 0; q < 8; q++) cr[q] = wave_sum_f64(cr[q]);
-                    if (lane == 0) {
+                        for (int q = 0; q < 8; q++) cr[q] = wave_sum_f64(cr[q]);
+                        if (lane == 0) {
 #pragma unroll
-                        for (int q = 0; q < 8; q++) sh->corrp[wave - 6][q] = cr[q];
+                            for (int q = 0; q < 8; q++) sh->corrp[wave - 4][q] = cr[q];
+                        }
                     }
                     int t2 = tm;                                                  // timing slip, as the state update below applies it
                     if (t2 >= RD_NMF - RD_M) t2 -= RD_M;
                     if (t2 < RD_M) t2 += RD_M;
                     const double rph_r = S->rph_r, rph_i = S->rph_i;
                     float2 *rx1 = sh->xm;                                         // free between refine() and the next call's BPF
-                    for (int n = k; n < RD_NEOO; n += 128) {
+                    const int n_lo = hi ? 0 : 704, n_hi = hi ? 704 : RD_NEOO;
+                    for (int n = n_lo + k; n < n_hi; n += 128) {
                         const float2 cs = cis_reduced(-w * (double)(n + 1));
                         const double c = cs.x, s_ = cs.y;
                         const float pr = (float)(rph_r * c - rph_i * s_), pi = (float)(rph_r * s_ + rph_i * c);
                         rx1[n] = cmul(sh->rxb[t2 - RD_NCP + n], make_float2(pr, pi));
                     }
                 }
+#ifdef RD_PHASE_TIMING
+                if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 2 || wave == 4 || wave == 6)) atomicAdd((unsigned long long *)&g_phase_cycles[wave == 0 ? 21 : (wave == 2 ? 28 : (wave == 4 ? 29 : 30))], (unsigned long long)(clock64() - cr_t0));
+#endif
             }
             __syncthreads();
             // duplicates in rows48 are harmless: every copy writes the same value
@@ -2117,7 +2160,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                 block_sum_multi<2>(sh, rs2);
                 red[0] = rs2[0]; red[1] = rs2[1];
             }
-            PH(29);
 #pragma unroll
             for (int q = 0; q < 8; q++) red[2 + q] = sh->corrp[0][q] + sh->corrp[1][q];     // prepared during the matrix phase above
             const float sr = sigma_r_from_sums(red[0], red[1]);
@@ -2208,7 +2250,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     sh->rp[i][c] = cadd(g0, cmul(g1, sh->eqrot[c]));
                 }
                 __syncthreads();
-                PH(30);
                 // update_snr_est (dsp.py:438-456) + coarse magnitude (:477-482): per-carrier terms reduced by wave shuffles
                 // two independent chains on two wavefronts: 0 = coarse magnitude (the EQ below waits for it), 1 = SNR estimate
                 if (tid < 128) {
@@ -2245,7 +2286,6 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
                     }
                 }
                 __syncthreads();
-                PH(31);
                 const float mag = S->mag;
                 // linear-interpolated phase EQ of the 4 data symbols (:468-474), demap to z_hat
                 if (tid < RD_NS * RD_NC) {

@@ -18,7 +18,7 @@ eng.profile(True)
 fo, st, _ = eng.rx(rx); torch.cuda.synchronize()
 eng.profile(False); pr = eng.profile_get()['rx_sync']
 lib.rd_debug_phase_cycles(buf)
-names = ["load", "bpf+shift", "detect corr", "detect reduce", "refine", "check rows", "sigma+corr+slip", "freqcorr", "demod dft", "eq", "statemachine", "store", " refine:tables", " refine:mfma", " refine:scan", " refine:argmax", " detect:pre", " detect:fft", " bpf:mix+load", " bpf:fir", "decode+post", " dec:gemm", "loop top", " dec:scan", " dec:hist+dense1+gin0", " dec:glu", " dec:conv+next", " dec:fixup", " loop top (every call)", " sigma:rowsum reduce", " eq:est_pilots", " eq:snr+mag"]
+names = ["load", "bpf+shift", "detect corr", "detect reduce", "refine", "check rows", "sigma+corr+slip", "freqcorr", "demod dft", "eq", "statemachine", "store", " refine:tables", " refine:mfma", " refine:scan", " refine:argmax", " detect:pre", " detect:fft", " bpf:mix+load", " bpf:fir", "decode+post", " check: wave 0 (3 tiles)", "loop top", " dec:scan", " dec:hist+dense1+gin0", " dec:glu", " dec:conv+next", " dec:fixup", "", " check: wave 1 (2 tiles)", " check: wave 6 (side work)", ""]
 tot = sum(buf[:12])
 print("stream0 calls", st[0].n_calls, "valid", st[0].n_valid, "rx_sync kernel ms", pr["ms"], "launches", pr["launches"])
 for i, n in enumerate(names): print(f"{n:18s} {buf[i]:12d} cyc  {100*buf[i]/tot:5.1f}%  {buf[i]/100e6*1e3:8.3f} ms (100MHz clk?)")
