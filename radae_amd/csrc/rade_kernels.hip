@@ -588,7 +588,7 @@ template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
 template <int NT>
 __device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh_, const DqGemm g_, int ct_, int Tb_, unsigned rstmask_)
 {
-    constexpr int D = NT == 1 ? 8 : 4;                                 // k-steps of weights in flight
+    constexpr int D = NT == 1 ? 16 : 6;                                // k-steps of weights in flight
     const int ct = uni(ct_), Tb = uni(Tb_); const unsigned rstmask = (unsigned)uni((int)rstmask_);
     const int nct = uni(g_.nct), N = uni(g_.N), from_hb = uni(g_.from_hb), ktap = uni(g_.ktap), ks0 = uni(g_.ks0), nks = uni(g_.nks), init_gi = uni(g_.init_gi),
               outk = uni(g_.out), ocol = uni(g_.ocol), act = uni(g_.act), gstride = uni(g_.gstride);
