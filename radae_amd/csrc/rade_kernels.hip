@@ -585,9 +585,12 @@ template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
 // NT adjacent column tiles (16 outputs each) of a product for rows [0, Tb), one wavefront, the whole K: every row fragment read
 // from LDS feeds NT weight fragments, D k-steps of weights (NT KB per plane each) are in flight, and the pipeline fills once per
 // call -- with one tile per call the first round trip to L2 of every tile was most of its time.
-template <int NT>
-__device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh_, const DqGemm g_, int ct_, int Tb_, unsigned rstmask_)
-{
+template <int NT, bool SINGLE>
+__device__ DQ_TILE_INLINE void dq_gemm_tiles_(DecShared *sh_, const DqGemm g_, int ct_, int Tb_, unsigned rstmask_)
+{   // SINGLE (int8-exact layer: one plane of integers) is a template parameter and both 16-row tiles are always computed: with
+    // either as a run-time flag every matrix instruction of the k loop sat behind a (uniform) branch, and the compiler, unable to
+    // count outstanding loads across branches, waited for ALL weight fragments in flight before each k-step (vmcnt(0)): the
+    // weight pipeline was one k-step deep whatever D said (296 cycles per k-step for 64 cycles of matrix work, tools/ubench/dq_gemm_bench)
     constexpr int D = NT == 1 ? 16 : 6;                                // k-steps of weights in flight
     const int ct = uni(ct_), Tb = uni(Tb_); const unsigned rstmask = (unsigned)uni((int)rstmask_);
     const int nct = uni(g_.nct), N = uni(g_.N), from_hb = uni(g_.from_hb), ktap = uni(g_.ktap), ks0 = uni(g_.ks0), nks = uni(g_.nks), init_gi = uni(g_.init_gi),
@@ -595,9 +598,9 @@ __device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh_, const DqGemm g_, in
     DecShared *sh = uni_ptr(sh_);
     glb_u16 *wbase = (glb_u16 *)uni_ptr(g_.wa); glb_cf32 *biasp = (glb_cf32 *)uni_ptr(g_.bias); glb_f32 *gout = (glb_f32 *)uni_ptr(g_.gout);
     glb_cf32 *wscale = (glb_cf32 *)uni_ptr(g_.wscale);
-    const bool single = wscale != nullptr;                             // int8-exact layer: one plane of integers
+    constexpr bool single = SINGLE;
     const int lane = threadIdx.x & 63, t = lane & 15, gq = lane >> 4;
-    const bool two = Tb > 16;
+    constexpr bool two = true;                                         // Tb <= 16: the second tile repeats the last row, results dropped
     const int r0 = min(t, Tb - 1), r1 = min(16 + t, Tb - 1);          // rows beyond Tb repeat the last one (results dropped)
     const lds_half *bh = (const lds_half *)(from_hb ? &sh->hbh[0][0] : &sh->xh[0][0]), *bl = (const lds_half *)(from_hb ? &sh->hbl[0][0] : &sh->xl[0][0]);
     const int stride = from_hb ? DQ_HB * 8 : DQ_XB * 8;
@@ -637,35 +640,38 @@ __device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh_, const DqGemm g_, in
     };
 #pragma unroll
     for (int d = 0; d < D; d++) fetch(d, d);
-#pragma unroll 1
-    for (int ks = 0; ks < nks; ks += D) {
+    auto step = [&](int d, int kidx, bool refill) {
+        const int kk = ks0 + kidx;
+        const bool tap0 = kk < ktap;
+        const int cb = 4 * (tap0 ? kk : kk - ktap) + gq;
+        const int oa = (tap0 ? p0a : p1a) + ((cb ^ (tap0 ? k0a : k1a)) << 3), ob = (tap0 ? p0b : p1b) + ((cb ^ (tap0 ? k0b : k1b)) << 3);
+        const f16x8 xha = *(lds_f16x8 *)(bh + oa), xla = *(lds_f16x8 *)(bl + oa);
+        const f16x8 xhb = *(lds_f16x8 *)(bh + ob), xlb = *(lds_f16x8 *)(bl + ob);
+        __builtin_amdgcn_sched_barrier(0);          // all four row fragments in flight before the first product (left alone, the scheduler
+                                                    // reads them one at a time into the same registers: an LDS round trip in front of every product)
 #pragma unroll
-        for (int d = 0; d < D; d++) {
-            if (ks + d < nks) {                                        // uniform
-                const int kk = ks0 + ks + d;
-                const bool tap0 = kk < ktap;
-                const int cb = 4 * (tap0 ? kk : kk - ktap) + gq;
-                const int oa = (tap0 ? p0a : p1a) + ((cb ^ (tap0 ? k0a : k1a)) << 3), ob = (tap0 ? p0b : p1b) + ((cb ^ (tap0 ? k0b : k1b)) << 3);
-                const f16x8 xha = *(lds_f16x8 *)(bh + oa), xla = *(lds_f16x8 *)(bl + oa);
-                f16x8 xhb = xha, xlb = xla;
-                if (two) { xhb = *(lds_f16x8 *)(bh + ob); xlb = *(lds_f16x8 *)(bl + ob); }
-#pragma unroll
-                for (int i = 0; i < NT; i++) {
-                    if (!single) {
-                        acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][i], xha, acc0[i], 0, 0, 0);
-                        if (two) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][i], xhb, acc1[i], 0, 0, 0);
-                    }
-                    acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xla, acc0[i], 0, 0, 0);
-                    if (two) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xlb, acc1[i], 0, 0, 0);
-                    acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xha, acc0[i], 0, 0, 0);
-                    if (two) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xhb, acc1[i], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(d, ks + d + D);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < NT; i++) {
+            if (!single) {
+                acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][i], xha, acc0[i], 0, 0, 0);
+                acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[d][i], xhb, acc1[i], 0, 0, 0);
             }
+            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xla, acc0[i], 0, 0, 0);
+            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xlb, acc1[i], 0, 0, 0);
+            acc0[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xha, acc0[i], 0, 0, 0);
+            acc1[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[d][i], xhb, acc1[i], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (refill) fetch(d, kidx + D);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int ks = 0;
+#pragma unroll 1
+    for (; ks + D <= nks; ks += D) {                                   // whole groups: straight-line, every load counted
+#pragma unroll
+        for (int d = 0; d < D; d++) step(d, ks + d, true);
     }
+#pragma unroll
+    for (int d = 0; d < D; d++) if (ks + d < nks) step(d, ks + d, false);     // the last nks % D k-steps (their fragments are already here)
     // C layout: column = lane & 15 (row t), registers r = outputs n0 + r
     lds_half *xh = (lds_half *)&sh->xh[0][0], *xl = (lds_half *)&sh->xl[0][0];
     const lds_half *hbh = (const lds_half *)&sh->hbh[0][0], *hbl = (const lds_half *)&sh->hbl[0][0];
@@ -676,7 +682,7 @@ __device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh_, const DqGemm g_, in
 #pragma unroll
         for (int rt = 0; rt < 2; rt++) {
             const int tt = 16 * rt + t;
-            if (tt >= Tb || (rt && !two)) continue;
+            if (tt >= Tb) continue;
             f32x4 v = (rt ? acc1[i] : acc0[i]) * scl[i] + bias[i];
             if (init_gi) v += *(const __attribute__((address_space(3))) f32x4 *)(gi + tt * 288 + n);          // fix-up product: onto the staged sums
             if (outk == DQ_OUT_GI) { *(__attribute__((address_space(3))) f32x4 *)(gi + tt * 288 + n) = v; continue; }
@@ -699,6 +705,13 @@ __device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh_, const DqGemm g_, in
             *(lds_f16x4 *)(xh + dq_xoff(tt, ocol + n)) = oh; *(lds_f16x4 *)(xl + dq_xoff(tt, ocol + n)) = ol;
         }
     }
+}
+
+template <int NT>
+__device__ DQ_TILE_INLINE void dq_gemm_tiles(DecShared *sh, const DqGemm g, int ct, int Tb, unsigned rstmask)
+{
+    if (uni_ptr(g.wscale) != nullptr) dq_gemm_tiles_<NT, true>(sh, g, ct, Tb, rstmask);
+    else dq_gemm_tiles_<NT, false>(sh, g, ct, Tb, rstmask);
 }
 
 // dense1 (K = 80 -> 96 columns) on the f32 matrix cores (v_mfma_f32_32x32x2_f32, weights from rd_pack_weights): its input
