@@ -640,15 +640,22 @@ __device__ DQ_TILE_INLINE void dq_gemm_tiles_(DecShared *sh_, const DqGemm g_, i
     };
 #pragma unroll
     for (int d = 0; d < D; d++) fetch(d, d);
-    auto step = [&](int d, int kidx, bool refill) {
-        const int kk = ks0 + kidx;
+    // row fragments (LDS) one k-step ahead of their products
+    f16x8 nha, nla, nhb, nlb;
+    auto rows = [&](int kidx) {                                        // kidx past the end re-reads the last k-step
+        const int kk = ks0 + min(kidx, nks - 1);
         const bool tap0 = kk < ktap;
         const int cb = 4 * (tap0 ? kk : kk - ktap) + gq;
         const int oa = (tap0 ? p0a : p1a) + ((cb ^ (tap0 ? k0a : k1a)) << 3), ob = (tap0 ? p0b : p1b) + ((cb ^ (tap0 ? k0b : k1b)) << 3);
-        const f16x8 xha = *(lds_f16x8 *)(bh + oa), xla = *(lds_f16x8 *)(bl + oa);
-        const f16x8 xhb = *(lds_f16x8 *)(bh + ob), xlb = *(lds_f16x8 *)(bl + ob);
-        __builtin_amdgcn_sched_barrier(0);          // all four row fragments in flight before the first product (left alone, the scheduler
-                                                    // reads them one at a time into the same registers: an LDS round trip in front of every product)
+        nha = *(lds_f16x8 *)(bh + oa); nla = *(lds_f16x8 *)(bl + oa);
+        nhb = *(lds_f16x8 *)(bh + ob); nlb = *(lds_f16x8 *)(bl + ob);
+    };
+    rows(0);
+    auto step = [&](int d, int kidx, bool refill) {
+        const f16x8 xha = nha, xla = nla, xhb = nhb, xlb = nlb;
+        rows(kidx + 1);
+        __builtin_amdgcn_sched_barrier(0);          // the next k-step's four row fragments in flight before this one's first product (left
+                                                    // alone, the scheduler reads them one at a time into the same registers: an LDS round trip per product)
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             if (!single) {
