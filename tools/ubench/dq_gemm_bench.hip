@@ -36,7 +36,7 @@ int main()
     hipMemcpy(wc, h.data(), nwc * 2, hipMemcpyHostToDevice); hipMemcpy(wg, h.data(), nwg * 2, hipMemcpyHostToDevice);
     hipMemcpy(sc, f.data(), 512 * 4, hipMemcpyHostToDevice); hipMemcpy(bi, f.data(), 512 * 4, hipMemcpyHostToDevice);
     hipFuncSetAttribute((const void *)k_dq_bench, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(DecShared));
-    for (int cin : {320, 576, 704})
+    for (int cin : {32, 64, 128, 320, 576, 704})
         for (int mode : {0, 1, 2})
             for (int nb : {1, 256}) {
                 for (int rep = 0; rep < 2; rep++) { hipLaunchKernelGGL(k_dq_bench, dim3(nb), dim3(NT_RX), sizeof(DecShared), 0, wc, wg, sc, bi, cyc, iters, cin, mode); hipDeviceSynchronize(); }
