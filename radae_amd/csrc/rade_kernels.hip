@@ -308,6 +308,107 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
         }
 }
 
+// The same kernel with two k-blocks of operands in flight and no branch inside the k loop: "one or two weight planes" is a template
+// parameter and the k-blocks come in pairs (every layer of the model has an even number), the fetches past the end re-read the last
+// block.  With the plane count a run-time flag every matrix instruction sat behind a uniform branch and the loads of the next
+// k-block could only be waited for all at once; here the compiler counts them (partial vmcnt waits) and a fetch has two k-blocks of
+// matrix work to complete.
+template <int NT, int RT, bool SINGLE>
+__global__ __launch_bounds__(64) void k_gemm16p(rd_gemm_args a)
+{
+    const int lane = threadIdx.x;
+    const int rows = a.B * a.T;
+    const int r0 = blockIdx.x * 32 * RT;
+    const int ntt = (a.N + 31) >> 5;
+    const int nt0 = blockIdx.y * NT;
+    const int half = lane >> 5;
+    const float *p1[RT], *p0[RT];
+#pragma unroll
+    for (int q = 0; q < RT; q++) {
+        int r = r0 + 32 * q + (lane & 31);
+        if (r >= rows) r = rows - 1;
+        const int b = r / a.T, t = r - b * a.T;
+        p1[q] = a.a1 + b * a.a1_sb + t * a.a1_st + 8 * half;
+        p0[q] = p1[q];
+        if (a.K0) {
+            const bool rst = a.reset && a.reset[b * a.reset_sb + t];
+            p0[q] = (rst ? g_zero_row : a.a0 + b * a.a0_sb + t * a.a0_st) + 8 * half;
+        }
+    }
+    f32x16 acc[RT][NT];
+#pragma unroll
+    for (int q = 0; q < RT; q++)
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[q][i][j] = 0.0f;
+    const int nkb0 = a.K0 >> 4, nkb = nkb0 + (a.K1 >> 4);
+    constexpr int planes = SINGLE ? 1 : 2;
+    const unsigned short *wbase = a.Wp16 + ((size_t)nt0 * planes * 64 + lane) * 8;
+    const size_t wstep = (size_t)ntt * planes * 64 * 8;
+    f32x4 a4[2][RT][2]; f16x8 bh[2][NT], bl[2][NT];
+    auto fetch = [&](int st, int kb_) {
+        const int kb = min(kb_, nkb - 1);
+#pragma unroll
+        for (int q = 0; q < RT; q++) {
+            const float *p = kb < nkb0 ? p0[q] + kb * 16 : p1[q] + (kb - nkb0) * 16;
+            a4[st][q][0] = *(const f32x4 *)p; a4[st][q][1] = *(const f32x4 *)(p + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            bh[st][i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * planes * 64 * 8);
+            if (!SINGLE) bl[st][i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8 + 64 * 8);
+        }
+    };
+    auto block = [&](int st, int kb_next) {
+        f16x8 ah[RT], al[RT], ch[NT], cl[NT];
+#pragma unroll
+        for (int q = 0; q < RT; q++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float x = 256.0f * a4[st][q][j >> 2][j & 3];
+                const _Float16 hi = (_Float16)x;
+                ah[q][j] = hi; al[q][j] = (_Float16)(x - (float)hi);
+            }
+#pragma unroll
+        for (int i = 0; i < NT; i++) { ch[i] = bh[st][i]; cl[i] = bl[st][i]; }
+        fetch(st, kb_next);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < RT; q++)
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q], ch[i], acc[q][i], 0, 0, 0);
+                if (!SINGLE) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], cl[i], acc[q][i], 0, 0, 0);
+                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q], ch[i], acc[q][i], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    fetch(0, 0); fetch(1, 1);
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; kb += 2) { block(0, kb + 2); block(1, kb + 3); }
+#pragma unroll
+    for (int q = 0; q < RT; q++)
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int col = (nt0 + i) * 32 + (lane & 31);
+            if (col >= a.N) continue;
+            const float bias = a.bias ? a.bias[col] : 0.0f;
+            const float scl = SINGLE ? a.Wscale[col] * 0x1p-8f : 0x1p-18f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int rr = r0 + 32 * q + (j & 3) + 8 * (j >> 2) + 4 * half;
+                if (rr >= rows) continue;
+                const int bb = rr / a.T, tt = rr - bb * a.T;
+                if (a.n_rows && tt >= a.n_rows[bb]) continue;
+                float v = acc[q][i][j] * scl + bias;
+                if (a.act == 1) v = clamp1(gate_tanh(v));
+                else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * gate_sigmoid(v));
+                a.y[bb * a.y_sb + tt * a.y_st + col] = v;
+            }
+        }
+}
+
 // Small-M variant (decoder rounds, single-stream API): the K loop is the latency, so 8 wavefronts of one
 // workgroup split it (k-blocks interleaved), partial accumulators meet in LDS, and each wave finishes two of the
 // sixteen accumulator registers of every tile (bias / activation / store).
@@ -412,6 +513,13 @@ extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
     dim3 block(64);
     if (a->Wp16 && (a->K0 & 15) == 0 && (a->K1 & 15) == 0) {          // f16 matrix cores, two-plane operands
         const int gx2 = (rows + 63) / 64;
+        static int pair_ok = -1; if (pair_ok < 0) pair_ok = getenv("RADE_GEMM_NO_PAIRS") ? 0 : 1;
+        if (pair_ok && (((a->K0 + a->K1) >> 4) & 1) == 0 && ((a->K0 >> 4) & 1) == 0 && ntt % 3 == 0) {      // k-blocks in pairs (and the tap boundary on a pair)
+            dim3 grid(gx2, ntt / 3);
+            if (a->Wscale) hipLaunchKernelGGL((k_gemm16p<3, 2, true>), grid, block, 0, st, *a);
+            else hipLaunchKernelGGL((k_gemm16p<3, 2, false>), grid, block, 0, st, *a);
+            return (int)hipGetLastError();
+        }
         if (ntt % 3 == 0) { dim3 grid(gx2, ntt / 3); hipLaunchKernelGGL((k_gemm16<3, 2>), grid, block, 0, st, *a); }
         else if (ntt % 2 == 0) { dim3 grid(gx2, ntt / 2); hipLaunchKernelGGL((k_gemm16<2, 2>), grid, block, 0, st, *a); }
         else { dim3 grid(gx2, ntt); hipLaunchKernelGGL((k_gemm16<1, 2>), grid, block, 0, st, *a); }
