@@ -699,7 +699,7 @@ __device__ DQ_TILE_INLINE void dq_gemm_tiles_(DecShared *sh_, const DqGemm g_, i
     // either as a run-time flag every matrix instruction of the k loop sat behind a (uniform) branch, and the compiler, unable to
     // count outstanding loads across branches, waited for ALL weight fragments in flight before each k-step (vmcnt(0)): the
     // weight pipeline was one k-step deep whatever D said (296 cycles per k-step for 64 cycles of matrix work, tools/ubench/dq_gemm_bench)
-    constexpr int D = NT == 1 ? 16 : 6;                                // k-steps of weights in flight
+    constexpr int D = NT == 1 ? 12 : 4;                                // k-steps of weights in flight
     const int ct = uni(ct_), Tb = uni(Tb_); const unsigned rstmask = (unsigned)uni((int)rstmask_);
     const int nct = uni(g_.nct), N = uni(g_.N), from_hb = uni(g_.from_hb), ktap = uni(g_.ktap), ks0 = uni(g_.ks0), nks = uni(g_.nks), init_gi = uni(g_.init_gi),
               outk = uni(g_.out), ocol = uni(g_.ocol), act = uni(g_.act), gstride = uni(g_.gstride);
