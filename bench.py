@@ -230,7 +230,11 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         achieved = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
         r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS})
     # counters of the same command, collected in separate rocprofv3 --pmc passes (tools/collect_profiles.sh -> profiles/)
-    r["bound"] = "latency (s_waitcnt/s_barrier) + valu-issue"
+    # "bound" names the roofline the (achieved, peak) pair is priced against -- compute, at the f32 matrix-core peak; the byte side is
+    # hbm_frac_kernel / hbm_frac_whole_job.  Neither binds this kernel: "limiter" says what does (SQ wave-cycle shares of the same
+    # command, separate --pmc pass): waves parked on s_waitcnt / s_barrier on a per-stream serial chain, then VALU issue.
+    r["bound"] = "mfma"
+    r["limiter"] = "latency (s_waitcnt/s_barrier) + valu-issue"
     r["traffic"] = None
     try:
         pm = json.load(open(os.path.join(REPO, "profiles", f"{PROFILE_TAG}_pmc_summary.json")))
@@ -252,7 +256,7 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         sq = pm.get("sq_breakdown", {}).get("k_rx_sync")
         if sq:
             r["sq_wave_cycle_shares"] = sq
-            r["bound"] = sq.get("bound", r["bound"])
+            r["limiter"] = sq.get("bound", r["limiter"])
     except Exception:
         pass
     return r
