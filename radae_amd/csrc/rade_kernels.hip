@@ -515,9 +515,12 @@ extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
         const int gx2 = (rows + 63) / 64;
         static int pair_ok = -1; if (pair_ok < 0) pair_ok = getenv("RADE_GEMM_NO_PAIRS") ? 0 : 1;
         if (pair_ok && (((a->K0 + a->K1) >> 4) & 1) == 0 && ((a->K0 >> 4) & 1) == 0 && ntt % 3 == 0) {      // k-blocks in pairs (and the tap boundary on a pair)
+            static int rt1 = -1; if (rt1 < 0) rt1 = getenv("RADE_GEMM_RT1") ? 1 : 0;
+            // one 32-row tile per wavefront for the one-plane layers: 96 accumulator registers less, a third wavefront per SIMD
+            // (0.711 -> 0.667 ms per step over the encoder's GEMMs); six column tiles per wavefront (activations read once) changed nothing
+            if (a->Wscale) { dim3 g1(gx, ntt / 3); hipLaunchKernelGGL((k_gemm16p<3, 1, true>), g1, block, 0, st, *a); return (int)hipGetLastError(); }
             dim3 grid(gx2, ntt / 3);
-            if (a->Wscale) hipLaunchKernelGGL((k_gemm16p<3, 2, true>), grid, block, 0, st, *a);
-            else hipLaunchKernelGGL((k_gemm16p<3, 2, false>), grid, block, 0, st, *a);
+            hipLaunchKernelGGL((k_gemm16p<3, 2, false>), grid, block, 0, st, *a);
             return (int)hipGetLastError();
         }
         if (ntt % 3 == 0) { dim3 grid(gx2, ntt / 3); hipLaunchKernelGGL((k_gemm16<3, 2>), grid, block, 0, st, *a); }
