@@ -1392,6 +1392,8 @@ struct RxShared {
                 struct { char rpart_pad[8192]; double rpart[6][64][4]; };   // refine(), in-sync grid (dtr uses 5 KB): second-half partial tiles
             };
             unsigned rxh[RD_RXBUF], rxl[RD_RXBUF];   // check_pilots: rx_buf x 2^(7-E) split in two binary16 planes, one dword = (re, im) of a sample
+            double vm[8][RD_M];               // refine(), in-sync grid: ((n - 79.5) / 80)^m, m = 0..7 (rebuilt with wfwd)
+            double rmom[4][2][64][4];         // refine(), in-sync grid: partial moment tiles [quarter of the samples][frame]
         };
         struct {                          // search / candidate state: FFT pilot correlator
             float2 fftX[FFT_N];           // spectrum of the rx_buf window being correlated
@@ -1402,6 +1404,7 @@ struct RxShared {
       __attribute__((aligned(16))) unsigned char dec_raw[sizeof(DecShared)];   // decoder stage (rx_decode_pending): runs between calls, when xm and the tables are dead
     };
     double2 rtw[80], rrot[80], rt80[80];  // refine(): e^{-jw_f}, e^{-jw_f Nmf}, e^{-jw_f 80} per candidate frequency
+    double2 rq[4], rzc, rph[24]; double ral[24];   // in-sync grid (moments about the centre frequency w_c): e^{-jw_c 40 q}, e^{-jw_c}, e^{-j(w_k - w_c) 79.5}, (w_k - w_c) 80
     float rowsum1[RD_NMF], rowsum2[RD_NMF]; // sum_f |Dt1[t,f]|, |Dt2[t,f]|
     int rows48[48];
     double redd[(NT_RX / 64 + 1) * 10];   // block reductions (double): per-wave partials + totals
@@ -1723,6 +1726,73 @@ __device__ __forceinline__ void refine_tables(RxShared *sh, int k, double fstart
     dstp[fi] = make_double2(cs, sn);
 }
 
+// In-sync grid (20 frequencies fmax - 1 .. fmax + 0.9 Hz, 16 timings): the 20 frequencies lie within +-1 Hz of their centre w_c,
+// i.e. within 0.06 rad over the 160-sample window measured from its middle, so
+//   Dt(t, f_k) = sum_n y_t[n] e^{-jw_k n} = e^{-j dw_k 79.5} sum_m (-j dw_k 80)^m / m! * M_m(t),
+//   M_m(t) = sum_n ((n - 79.5) / 80)^m e^{-jw_c n} y_t[n],   y_t[n] = conj(p[n]) rx[t + n],   dw_k = w_k - w_c,
+// and eight moments M_0..M_7 (remainder <= 0.06^8 / 8! = 4e-15 of sum|y|, the size of the rounding error of the 160-term complex128
+// sum itself: 6000 random cases, worst 3.7e-16 sum|y| against a long-double evaluation, every complex64-rounded value equal to the
+// direct sum's) replace the twenty per-frequency sums: ONE 16x16 tile (8 moments x re/im) per modem frame instead of three -- the
+// f64 matrix instructions are what this phase is made of.  The moments are realified like the frequency rows were; their extra real
+// factor comes from a small table (vm).  refine() on sync entry (+-10 Hz) keeps the direct sums.
+__device__ __forceinline__ void refine_tables_sync(RxShared *sh, int k, double fstart, double fstep)
+{   // one lane, ONE sincos each (the wavefront that runs this during the FIR must not outlast it): k < 20 e^{-jw_k Nmf}, 20..39 the
+    // constants of frequency k - 20, 40..43 the quarter starts of the sample range, 44 e^{-jw_c}
+    const double delta = (fstart + fstep) - fstart;                       // np.arange fill rule
+    const double w9 = 2.0 * PI_D * (fstart + 9 * delta) / 8000.0, w10 = 2.0 * PI_D * (fstart + 10 * delta) / 8000.0, wc = 0.5 * (w9 + w10);
+    if (k < 0 || k > 44) return;
+    const int kf = k < 20 ? k : k - 20;
+    const double w = 2.0 * PI_D * (fstart + kf * delta) / 8000.0, dw = w - wc;
+    const double arg = k < 20 ? -w * RD_NMF : (k < 40 ? -dw * 79.5 : (k < 44 ? -wc * 40.0 * (k - 40) : -wc));
+    double sn, cs; sincos(arg, &sn, &cs);
+    const double2 v = make_double2(cs, sn);
+    if (k < 20) sh->rrot[k] = v;
+    else if (k < 40) { sh->rph[kf] = v; sh->ral[kf] = dw * 80.0; }
+    else if (k < 44) sh->rq[k - 40] = v;
+    else sh->rzc = v;
+}
+__device__ __forceinline__ f64x4 refine_moments(const RxShared *sh, int frame, int q, int nt, int lane)
+{
+    const int i = lane & 15, kk = lane >> 4, c = kk & 1, n0 = kk >> 1;
+    const int m = i >> 1, cp = i & 1, s0 = 20 * q;
+    const double2 z1 = sh->rzc;                                               // e^{-jw_c}
+    double2 cur = sh->rq[q];                                                  // e^{-jw_c 2 s0}
+    if (n0) cur = make_double2(cur.x * z1.x - cur.y * z1.y, cur.x * z1.y + cur.y * z1.x);
+    const double c2r = z1.x * z1.x - z1.y * z1.y, c2i = 2.0 * z1.x * z1.y;   // e^{-2jw_c}
+    const double2 prv = make_double2(cur.x * c2r + cur.y * c2i, cur.y * c2r - cur.x * c2i);   // cur * e^{+2jw_c}
+    // realified rotation: (c',c) = (0,0) cos, (0,1) sin, (1,0) -sin, (1,1) cos;  cos = Re e^{-jwn}, sin = -Im e^{-jwn}
+    double xc = cp == c ? cur.x : (cp == 0 ? -cur.y : cur.y), xp = cp == c ? prv.x : (cp == 0 ? -prv.y : prv.y);
+    const double k2 = 2.0 * c2r;
+    const double *xw = (const double *)&sh->xm[0] + 4 * (frame * 176 + (i < nt ? i : 0) + 2 * s0 + n0) + 2 * c;
+    const double2 *pp = &sh->pd[2 * s0 + n0];
+    const double *vp = &sh->vm[m][2 * s0 + n0];
+    f64x4 acc0 = { 0.0, 0.0, 0.0, 0.0 }, acc1 = acc0;
+    double2 pn[4]; double a1[4], a2[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { pn[u] = pp[2 * u]; a1[u] = xw[8 * u]; a2[u] = xw[8 * u + 1]; vv[u] = vp[2 * u]; }
+#pragma unroll 1
+    for (int s = 0; s < 20; s += 4) {
+        double b[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { b[u] = pn[u].x * a1[u]; v[u] = vv[u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) b[u] = fma(pn[u].y, a2[u], b[u]);         // component c of conj(p[n]) rx[t+n]
+        __builtin_amdgcn_sched_barrier(0);
+        const int sn = s + 4 < 20 ? s + 4 : s;                                // last batch re-reads itself: branch-free
+#pragma unroll
+        for (int u = 0; u < 4; u++) { pn[u] = pp[2 * (sn + u)]; a1[u] = xw[8 * (sn + u)]; a2[u] = xw[8 * (sn + u) + 1]; vv[u] = vp[2 * (sn + u)]; }
+        __builtin_amdgcn_sched_barrier(0);
+        const double x1 = fma(k2, xc, -xp), x2 = fma(k2, x1, -xc), x3 = fma(k2, x2, -x1);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xc * v[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1 * v[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2 * v[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3 * v[3], b[3], acc1, 0, 0, 0);
+        xp = x3; xc = fma(k2, x3, -x2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc0 + acc1;
+}
+
 __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt, double fstart, double fstop, double fstep, bool have_tables)
 {
     const int tid = rx_tid(), lane = tid & 63, wave = tid >> 6;
@@ -1758,25 +1828,39 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
         }
     };
     if (ntasks <= 6) {
-        // in-sync grid: 6 tiles x 2 halves of the sample range = 12 pieces; wave w takes piece w and (w < 4) piece w + 8,
-        // i.e. three pieces per SIMD.  Piece c < 6 = first half of tile c (kept in registers), c >= 6 = second half of
-        // tile c - 6 (handed over through LDS and added in a fixed order).
-        f64x4 mine = { 0.0, 0.0, 0.0, 0.0 };
-        if (wave < ntasks) mine = refine_tile(sh, wave >> 1, wave & 1, 0, 40, nf, nt, lane);
-        for (int c = wave + (wave < 6 ? 8 : 0); c < 12 && c >= 6; c += 8) {
-            const int task = c - 6;
-            if (task < ntasks) {
-                const f64x4 part = refine_tile(sh, task >> 1, task & 1, 40, 40, nf, nt, lane);
+        // in-sync grid: eight moments per (frame, t) instead of twenty frequencies (refine_moments): wavefront w = (quarter w >> 1 of
+        // the samples, frame w & 1), 20 matrix instructions each; the quarters meet in LDS and are added in a fixed order
+        {
+            const f64x4 part = refine_moments(sh, wave & 1, wave >> 1, nt, lane);
 #pragma unroll
-                for (int r = 0; r < 4; r++) sh->rpart[task][lane][r] = part[r];
-            }
-            if (wave >= 6) break;
+            for (int r = 0; r < 4; r++) sh->rmom[wave >> 1][wave & 1][lane][r] = part[r];
         }
         __syncthreads();
-        if (wave < ntasks) {
+        double (*mtot)[16][16] = (double (*)[16][16])&sh->rpart[0][0][0];     // [frame][2 m + (re | im)][t]
+        {   // C layout (f64 16x16x4): col = lane & 15 (t), row = (lane >> 4) + 4 * reg
+            const int frame = tid >> 8, l = (tid >> 2) & 63, r = tid & 3;
+            mtot[frame][(l >> 4) + 4 * r][l & 15] = ((sh->rmom[0][frame][l][r] + sh->rmom[1][frame][l][r]) + sh->rmom[2][frame][l][r]) + sh->rmom[3][frame][l][r];
+        }
+        __syncthreads();
+        for (int o = tid; o < 2 * nf * 16; o += NT_RX) {
+            const int frame = o / (nf * 16), rem = o - frame * nf * 16, fo = rem >> 4, t = rem & 15;
+            if (t >= nt) continue;
+            const double al = sh->ral[fo];
+            // sum_m (-j al)^m / m! M_m:  (-j)^m = 1, -j, -1, j
+            double re = 0.0, im = 0.0, cm = 1.0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) mine[r] += sh->rpart[wave][lane][r];
-            finish(mine, wave >> 1, wave & 1);
+            for (int mq = 0; mq < 8; mq++) {
+                const double mr = mtot[frame][2 * mq][t], mi = mtot[frame][2 * mq + 1][t];
+                if ((mq & 3) == 0) { re = fma(cm, mr, re); im = fma(cm, mi, im); }
+                else if ((mq & 3) == 1) { re = fma(cm, mi, re); im = fma(-cm, mr, im); }
+                else if ((mq & 3) == 2) { re = fma(-cm, mr, re); im = fma(-cm, mi, im); }
+                else { re = fma(-cm, mi, re); im = fma(cm, mr, im); }
+                cm = cm * al * (1.0 / (double)(mq + 1));
+            }
+            const double2 ph = sh->rph[fo];                                   // e^{-j dw_k 79.5}
+            double xr = re * ph.x - im * ph.y, xi = re * ph.y + im * ph.x;
+            if (frame == 1) { const double2 rt = sh->rrot[fo]; const double tr = xr * rt.x - xi * rt.y; xi = xr * rt.y + xi * rt.x; xr = tr; }   // w_vec2 = w_vec1 * exp(-1j*w*Nmf)
+            sh->dtr[(frame * nf + fo) * 16 + t] = make_float2((float)xr, (float)xi);
         }
     } else {
         for (int task = wave; task < ntasks; task += NT_RX / 64) finish(refine_tile(sh, task >> 1, task & 1, 0, 80, nf, nt, lane), task >> 1, task & 1);
@@ -2030,6 +2114,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         const float2 bpf_phase = S->bpf_phase;
         if (state == ST_SYNC && !S->lds_sync) {      // the demod / check_pilots tables share LDS with the FFT correlator
             for (int i = tid; i < RD_M * RD_NC; i += NT_RX) sh->wfwd[i / RD_NC][i % RD_NC] = make_float2(tab->Wfwd[i / RD_NC][i % RD_NC][0], tab->Wfwd[i / RD_NC][i % RD_NC][1]);
+            if (tid < RD_M) { const double nu = ((double)tid - 79.5) / 80.0; double v = 1.0; for (int m = 0; m < 8; m++) { sh->vm[m][tid] = v; v *= nu; } }
             __syncthreads();
             if (tid == 0) S->lds_sync = 1;
         }
@@ -2047,7 +2132,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         const float2 e_last = ld2(tab->bpf_E, nin - 1);    // next call's starting phase (thread 0, below): fetched ahead of the FIR
         // in sync, refine() of this call searches fmax +-1 Hz: its f64 sincos tables only depend on last call's fmax, so the last
         // wavefront (idle during the FIR) prepares them now instead of everybody waiting for them later
-        if (state == ST_SYNC && tid >= NT_RX - 64) { const double fm = S->fmax; refine_tables(sh, tid - (NT_RX - 64), fm - 1.0, fm + 1.0, 0.1); }
+        if (state == ST_SYNC && tid >= NT_RX - 64) { const double fm = S->fmax; refine_tables_sync(sh, tid - (NT_RX - 64), fm - 1.0, 0.1); }
         if (state == ST_SYNC && tid >= NT_RX - 128 && tid < NT_RX - 128 + 48) {      // check_pilots' 48 row draws of this call, likewise
             const int k = tid - (NT_RX - 128);
             const uint32_t x = LCG_A[k] * S->lcg + LCG_C[k];
