@@ -1726,29 +1726,32 @@ __device__ __forceinline__ void refine_tables(RxShared *sh, int k, double fstart
     dstp[fi] = make_double2(cs, sn);
 }
 
-// In-sync grid (20 frequencies fmax - 1 .. fmax + 0.9 Hz, 16 timings): the 20 frequencies lie within +-1 Hz of their centre w_c,
-// i.e. within 0.06 rad over the 160-sample window measured from its middle, so
+// In-sync grid (np.arange(fmax - 1, fmax + 1, 0.1): 20 or 21 frequencies, 16 timings): the frequencies lie within +-1.05 Hz of their
+// centre w_c, i.e. within 0.066 rad over the 160-sample window measured from its middle, so
 //   Dt(t, f_k) = sum_n y_t[n] e^{-jw_k n} = e^{-j dw_k 79.5} sum_m (-j dw_k 80)^m / m! * M_m(t),
 //   M_m(t) = sum_n ((n - 79.5) / 80)^m e^{-jw_c n} y_t[n],   y_t[n] = conj(p[n]) rx[t + n],   dw_k = w_k - w_c,
-// and eight moments M_0..M_7 (remainder <= 0.06^8 / 8! = 4e-15 of sum|y|, the size of the rounding error of the 160-term complex128
+// and eight moments M_0..M_7 (remainder <= 0.066^8 / 8! = 9e-15 of sum|y|, the size of the rounding error of the 160-term complex128
 // sum itself: 6000 random cases, worst 3.7e-16 sum|y| against a long-double evaluation, every complex64-rounded value equal to the
 // direct sum's) replace the twenty per-frequency sums: ONE 16x16 tile (8 moments x re/im) per modem frame instead of three -- the
 // f64 matrix instructions are what this phase is made of.  The moments are realified like the frequency rows were; their extra real
 // factor comes from a small table (vm).  refine() on sync entry (+-10 Hz) keeps the direct sums.
-__device__ __forceinline__ void refine_tables_sync(RxShared *sh, int k, double fstart, double fstep)
-{   // one lane, ONE sincos each (the wavefront that runs this during the FIR must not outlast it): k < 20 e^{-jw_k Nmf}, 20..39 the
-    // constants of frequency k - 20, 40..43 the quarter starts of the sample range, 44 e^{-jw_c}
+__device__ __forceinline__ void refine_tables_sync(RxShared *sh, int k, double fstart, double fstop, double fstep)
+{   // one lane, ONE sincos each (the wavefront that runs this during the FIR must not outlast it): k < 24 e^{-jw_k Nmf}, 24..47 the
+    // constants of frequency k - 24, 48..51 the quarter starts of the sample range, 52 e^{-jw_c}.  np.arange(fmax - 1, fmax + 1, 0.1)
+    // has 20 OR 21 entries depending on how fmax rounds, so nf is computed, not assumed (w_c = the middle of the grid either way).
+    const int nf = (int)ceil((fstop - fstart) / fstep);                 // np.arange length (<= 24 here)
     const double delta = (fstart + fstep) - fstart;                       // np.arange fill rule
-    const double w9 = 2.0 * PI_D * (fstart + 9 * delta) / 8000.0, w10 = 2.0 * PI_D * (fstart + 10 * delta) / 8000.0, wc = 0.5 * (w9 + w10);
-    if (k < 0 || k > 44) return;
-    const int kf = k < 20 ? k : k - 20;
+    const double wc = 0.5 * (2.0 * PI_D * fstart / 8000.0 + 2.0 * PI_D * (fstart + (nf - 1) * delta) / 8000.0);
+    if (k < 0 || k > 52) return;
+    const int kf = k < 24 ? k : k - 24;
+    if (k < 48 && kf >= nf) return;
     const double w = 2.0 * PI_D * (fstart + kf * delta) / 8000.0, dw = w - wc;
-    const double arg = k < 20 ? -w * RD_NMF : (k < 40 ? -dw * 79.5 : (k < 44 ? -wc * 40.0 * (k - 40) : -wc));
+    const double arg = k < 24 ? -w * RD_NMF : (k < 48 ? -dw * 79.5 : (k < 52 ? -wc * 40.0 * (k - 48) : -wc));
     double sn, cs; sincos(arg, &sn, &cs);
     const double2 v = make_double2(cs, sn);
-    if (k < 20) sh->rrot[k] = v;
-    else if (k < 40) { sh->rph[kf] = v; sh->ral[kf] = dw * 80.0; }
-    else if (k < 44) sh->rq[k - 40] = v;
+    if (k < 24) sh->rrot[k] = v;
+    else if (k < 48) { sh->rph[kf] = v; sh->ral[kf] = dw * 80.0; }
+    else if (k < 52) sh->rq[k - 48] = v;
     else sh->rzc = v;
 }
 __device__ __forceinline__ f64x4 refine_moments(const RxShared *sh, int frame, int q, int nt, int lane)
@@ -2132,7 +2135,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
         const float2 e_last = ld2(tab->bpf_E, nin - 1);    // next call's starting phase (thread 0, below): fetched ahead of the FIR
         // in sync, refine() of this call searches fmax +-1 Hz: its f64 sincos tables only depend on last call's fmax, so the last
         // wavefront (idle during the FIR) prepares them now instead of everybody waiting for them later
-        if (state == ST_SYNC && tid >= NT_RX - 64) { const double fm = S->fmax; refine_tables_sync(sh, tid - (NT_RX - 64), fm - 1.0, 0.1); }
+        if (state == ST_SYNC && tid >= NT_RX - 64) { const double fm = S->fmax; refine_tables_sync(sh, tid - (NT_RX - 64), fm - 1.0, fm + 1.0, 0.1); }
         if (state == ST_SYNC && tid >= NT_RX - 128 && tid < NT_RX - 128 + 48) {      // check_pilots' 48 row draws of this call, likewise
             const int k = tid - (NT_RX - 128);
             const uint32_t x = LCG_A[k] * S->lcg + LCG_C[k];

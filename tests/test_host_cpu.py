@@ -312,3 +312,38 @@ def test_wire_format_converters_match_reference_scripts(golden):
     assert wire.f32_to_int16(f32) == g["f2i"].tobytes()
     assert wire.f32_to_int16(f32, real=True) == g["f2i_real"].tobytes()
     assert wire.f32_to_int16(f32, scale=8192.0) == g["f2i_scale"].tobytes()
+
+
+def test_refine_moment_expansion_is_complex128_accurate():
+    """The in-sync refine() of the HIP receiver evaluates the 20 or 21 fine frequencies (np.arange(fmax - 1, fmax + 1, 0.1)) from eight moments of
+    the 160-sample window about the centre frequency and the centre of the window (rade_kernels.hip: refine_moments) instead of
+    twenty direct sums (dsp.py:233-270, complex128 dots stored as complex64).  This pins the mathematics in NumPy: against a
+    long-double evaluation the expansion is as accurate as the complex128 sum itself (a few 1e-16 of sum|y|), and every value rounded
+    to complex64 -- what the reference stores and compares -- equals the direct sum's."""
+    import math
+    rng = np.random.default_rng(2)
+    N = 160; n = np.arange(N)
+    worst_t = worst_d = 0.0; differing = 0
+    for trial in range(200):
+        y = (rng.standard_normal(N) + 1j * rng.standard_normal(N)) * rng.uniform(0.01, 100)
+        if trial % 3 == 0:                                      # a coherent component near the centre, as in sync
+            y = y + 5 * np.exp(1j * rng.uniform(0, 6.28)) * np.exp(1j * 2 * np.pi * rng.uniform(-1, 1) / 8000 * n)
+        fm = rng.uniform(-45, 45); fstart = fm - 1.0; fstep = 0.1
+        nf = int(math.ceil((fm + 1.0 - fstart) / fstep)); delta = (fstart + fstep) - fstart
+        assert nf in (20, 21)                                   # np.arange's length depends on how fm rounds: both occur
+        w = 2 * np.pi * (fstart + np.arange(nf) * delta) / 8000.0
+        exact = np.array([np.sum(y.astype(np.clongdouble) * np.exp(-1j * (np.longdouble(w[k]) * n.astype(np.longdouble)))) for k in range(nf)])
+        direct = np.array([np.sum(y * np.exp(-1j * w[k] * n)) for k in range(nf)])
+        wc = 0.5 * (w[0] + w[nf - 1]); nu = (n - 79.5) / 80.0
+        mom = np.array([np.sum(nu ** m * (y * np.exp(-1j * wc * n))) for m in range(8)])
+        out = np.empty(nf, np.complex128)
+        for k in range(nf):
+            dw = w[k] - wc; c = 1.0 + 0j; s = 0j
+            for m in range(8):
+                s += c * mom[m]; c = c * (-1j * dw * 80.0) / (m + 1)
+            out[k] = s * np.exp(-1j * dw * 79.5)
+        sy = np.sum(np.abs(y))
+        worst_t = max(worst_t, float(np.abs(out - exact).max() / sy)); worst_d = max(worst_d, float(np.abs(direct - exact).max() / sy))
+        differing += int(np.sum(out.astype(np.complex64) != direct.astype(np.complex64)))
+    assert worst_t < 1e-15 and worst_t < 20 * worst_d, (worst_t, worst_d)
+    assert differing == 0
