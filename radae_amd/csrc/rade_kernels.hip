@@ -1830,6 +1830,7 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
             }
         }
     };
+    float best = -1.0f; int bf = 0x7fffffff, bt = 0x7fffffff;
     if (ntasks <= 6) {
         // in-sync grid: eight moments per (frame, t) instead of twenty frequencies (refine_moments): wavefront w = (quarter w >> 1 of
         // the samples, frame w & 1), 20 matrix instructions each; the quarters meet in LDS and are added in a fixed order
@@ -1845,37 +1846,45 @@ __device__ void rx_refine(RxShared *sh, int *tmax, double *fmax, int t0, int nt,
             mtot[frame][(l >> 4) + 4 * r][l & 15] = ((sh->rmom[0][frame][l][r] + sh->rmom[1][frame][l][r]) + sh->rmom[2][frame][l][r]) + sh->rmom[3][frame][l][r];
         }
         __syncthreads();
-        for (int o = tid; o < 2 * nf * 16; o += NT_RX) {
-            const int frame = o / (nf * 16), rem = o - frame * nf * 16, fo = rem >> 4, t = rem & 15;
+        // one thread per (frequency, timing): both frames' polynomials, the complex64 roundings NumPy makes, and the metric
+        // |Dt1 + Dt2| straight away (no pass through LDS, no separate scan)
+        for (int o = tid; o < nf * 16; o += NT_RX) {
+            const int fo = o >> 4, t = o & 15;
             if (t >= nt) continue;
             const double al = sh->ral[fo];
-            // sum_m (-j al)^m / m! M_m:  (-j)^m = 1, -j, -1, j
-            double re = 0.0, im = 0.0, cm = 1.0;
+            const double2 ph = sh->rph[fo], rt = sh->rrot[fo];               // e^{-j dw_k 79.5}, e^{-jw_k Nmf}
+            float2 d12[2];
 #pragma unroll
-            for (int mq = 0; mq < 8; mq++) {
-                const double mr = mtot[frame][2 * mq][t], mi = mtot[frame][2 * mq + 1][t];
-                if ((mq & 3) == 0) { re = fma(cm, mr, re); im = fma(cm, mi, im); }
-                else if ((mq & 3) == 1) { re = fma(cm, mi, re); im = fma(-cm, mr, im); }
-                else if ((mq & 3) == 2) { re = fma(-cm, mr, re); im = fma(-cm, mi, im); }
-                else { re = fma(-cm, mi, re); im = fma(cm, mr, im); }
-                cm = cm * al * (1.0 / (double)(mq + 1));
+            for (int frame = 0; frame < 2; frame++) {
+                // sum_m (-j al)^m / m! M_m:  (-j)^m = 1, -j, -1, j
+                double re = 0.0, im = 0.0, cm = 1.0;
+#pragma unroll
+                for (int mq = 0; mq < 8; mq++) {
+                    const double mr = mtot[frame][2 * mq][t], mi = mtot[frame][2 * mq + 1][t];
+                    if ((mq & 3) == 0) { re = fma(cm, mr, re); im = fma(cm, mi, im); }
+                    else if ((mq & 3) == 1) { re = fma(cm, mi, re); im = fma(-cm, mr, im); }
+                    else if ((mq & 3) == 2) { re = fma(-cm, mr, re); im = fma(-cm, mi, im); }
+                    else { re = fma(-cm, mi, re); im = fma(cm, mr, im); }
+                    cm = cm * al * (1.0 / (double)(mq + 1));
+                }
+                double xr = re * ph.x - im * ph.y, xi = re * ph.y + im * ph.x;
+                if (frame == 1) { const double tr = xr * rt.x - xi * rt.y; xi = xr * rt.y + xi * rt.x; xr = tr; }   // w_vec2 = w_vec1 * exp(-1j*w*Nmf)
+                d12[frame] = make_float2((float)xr, (float)xi);
             }
-            const double2 ph = sh->rph[fo];                                   // e^{-j dw_k 79.5}
-            double xr = re * ph.x - im * ph.y, xi = re * ph.y + im * ph.x;
-            if (frame == 1) { const double2 rt = sh->rrot[fo]; const double tr = xr * rt.x - xi * rt.y; xi = xr * rt.y + xi * rt.x; xr = tr; }   // w_vec2 = w_vec1 * exp(-1j*w*Nmf)
-            sh->dtr[(frame * nf + fo) * 16 + t] = make_float2((float)xr, (float)xi);
+            const float v = hypotf(d12[0].x + d12[1].x, d12[0].y + d12[1].y);  // |Dt1 + Dt2| in complex64
+            if (v > best || (v == best && (fo < bf || (fo == bf && t < bt)))) { best = v; bf = fo; bt = t; }
         }
+        PH(13);
     } else {
         for (int task = wave; task < ntasks; task += NT_RX / 64) finish(refine_tile(sh, task >> 1, task & 1, 0, 80, nf, nt, lane), task >> 1, task & 1);
-    }
-    __syncthreads();
-    PH(13);
-    float best = -1.0f; int bf = 0x7fffffff, bt = 0x7fffffff;
-    for (int task = tid; task < nf * nt; task += NT_RX) {
-        const int fi = task / nt, ti = task - fi * nt;
-        const float2 a = sh->dtr[fi * 16 + ti], b = sh->dtr[(nf + fi) * 16 + ti];
-        const float v = hypotf(a.x + b.x, a.y + b.y);                     // |Dt1 + Dt2| in complex64
-        if (v > best || (v == best && (fi < bf || (fi == bf && ti < bt)))) { best = v; bf = fi; bt = ti; }
+        __syncthreads();
+        PH(13);
+        for (int task = tid; task < nf * nt; task += NT_RX) {
+            const int fi = task / nt, ti = task - fi * nt;
+            const float2 a = sh->dtr[fi * 16 + ti], b = sh->dtr[(nf + fi) * 16 + ti];
+            const float v = hypotf(a.x + b.x, a.y + b.y);                     // |Dt1 + Dt2| in complex64
+            if (v > best || (v == best && (fi < bf || (fi == bf && ti < bt)))) { best = v; bf = fi; bt = ti; }
+        }
     }
     PH(14);
     block_argmax(sh, best, bf, bt);                                       // dtr and the window are free from its barrier on
