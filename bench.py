@@ -32,7 +32,10 @@ NMF = 960
 F32_PEAK_TFLOPS = 157.3          # MI355X f32 matrix == f32 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 # ---- executed-work model of k_rx_sync (SURVEY.md 8d figures) --------------------------------------------
-SYNC_CALL_FLOP = 866560 * 8.0                    # in-sync DSP per modem frame (BPF, refine, check_pilots, DFT; 8 flop per cMAC): 6.93 MFLOP
+REF_SYNC_CALL_FLOP = 866560 * 8.0                # in-sync DSP per modem frame as the reference formulates it (BPF, refine, check_pilots, DFT; 8 flop per cMAC): 6.93 MFLOP
+# executed: refine() in sync runs as 8 moments x 16 timings x 2 frames x 160 samples (40,960 cMAC) + the polynomials (640 x ~40 flop)
+# instead of 20 frequencies x 16 x 2 x 160 (102,400 cMAC): 0.47 MFLOP less per call
+SYNC_CALL_FLOP = (866560 - 102400 + 40960) * 8.0 + 640 * 40.0     # 6.47 MFLOP
 DEC_MF_FLOP = 3 * 904064 * 2.0                   # CoreDecoder, 3 steps per decoded modem frame (runs inside k_rx_sync): 5.42 MFLOP = 0.452 MFLOP per feature frame
 BPF_CALL_FLOP = 960 * 101 * 8.0                  # the BPF of a search / candidate call (it is inside SYNC_CALL_FLOP for synchronised ones): 0.78 MFLOP
 FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface by FFT convolution: 1 forward + 40 inverse 2048-point FFTs (5 N log2 N) + 40 spectral products: 5.11 MFLOP
@@ -220,10 +223,10 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
                   "per_launch_counts": counts, "executed_flop_per_launch": fl, "algorithmic_bytes_per_launch": algo_bytes,
                   "flop_model": {"sync_call": SYNC_CALL_FLOP, "decoded_modem_frame": DEC_MF_FLOP, "search_call": FFT_SURFACE_FLOP + BPF_CALL_FLOP,
-                                 "note": "executed work: in-sync DSP 866,560 cMAC x 8 per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
+                                 "note": "executed work: in-sync DSP 805,120 cMAC x 8 (refine by moments: 40,960 cMAC instead of the reference formulation's 102,400) + polynomials per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
                                          "search call = one |Dt| surface by FFT convolution (41 x 5 N log2 N + 40 x 6 N, N = 2048) + BPF; priced at the f32 peak"},
                   "hbm_frac_kernel": algo_bytes / (r["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                  "equiv_ref_formulation": {"tflops": (counts["sync_calls"] * SYNC_CALL_FLOP + counts["decoded_modem_frames"] * DEC_MF_FLOP + counts["search_calls"] * REF_SEARCH_CALL_FLOP)
+                  "equiv_ref_formulation": {"tflops": (counts["sync_calls"] * REF_SYNC_CALL_FLOP + counts["decoded_modem_frames"] * DEC_MF_FLOP + counts["search_calls"] * REF_SEARCH_CALL_FLOP)
                                             / (r["avg_launch_ms"] * 1e-3) / 1e12,
                                             "note": "detect_pilots priced as the reference's two 960x40x160 complex GEMMs (98.3 MFLOP per call); work NOT executed in that form -- not a roofline"}})
     else:
