@@ -112,6 +112,11 @@ __device__ __forceinline__ float wave_max_f32(float v)
     return t;
 }
 __device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
+// sqrt(-ln(P / 5)) of the Rayleigh thresholds (dsp.py:221, 318-320), P = 1e-4 / 1e-5: correctly rounded doubles, i.e. what the
+// reference's (and the oracle's) libm returns; the device log / sqrt on the single thread that sets the thresholds were a few hundred
+// f64 instructions on the serial path of every call
+#define RD_SQRT_NLOG_1EM4_5 3.2893431387452243
+#define RD_SQRT_NLOG_1EM5_5 3.622480279781289
 // gate activations of the GRU recurrences on the hardware exp2 / rcp units (about 1 ulp each): the recurrence is a
 // serial chain, so the libm-grade expf / tanhf / IEEE division sequences would dominate every time step
 __device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
@@ -2266,7 +2271,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             const float Dmax = best; const int tbest = bt, fbest = bfi;
             const float sr = sigma_r_from_rowsums(sh);
             if (tid == 0) {
-                S->Dthresh = (double)(2.0f * sr) * sqrt(-log(0.00001 / 5.0));
+                S->Dthresh = (double)(2.0f * sr) * RD_SQRT_NLOG_1EM5_5;
                 if (Dmax > 0.0f) { S->tmax = tbest; S->f_ind_max = fbest; S->fmax = -50.0 + 2.5 * fbest;   /* = tab->fcoarse[fbest] (dsp.py:163), without the dependent global load in the serial section */ S->Dtmax12 = (double)Dmax; }
                 else { S->tmax = 0; S->f_ind_max = 0; S->fmax = 0.0; S->Dtmax12 = 0.0; }
                 S->candidate = S->Dtmax12 > S->Dthresh;
@@ -2391,11 +2396,11 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 #pragma unroll
             for (int q = 0; q < 8; q++) red[2 + q] = sh->corrp[0][q] + sh->corrp[1][q];     // prepared during the matrix phase above
             const float sr = sigma_r_from_sums(red[0], red[1]);
-            const double D = hypot(red[2], red[3]) + hypot(red[4], red[5]);
-            const double De = hypot(red[6], red[7]) + hypot(red[8], red[9]);
             if (tid == 0) {
-                S->Dthresh = (double)(2.0f * sr) * sqrt(-log(0.0001 / 5.0));
-                const double Dthresh_eoo = (double)(2.0f * sr) * sqrt(-log(0.00001 / 5.0));
+                const double D = hypot(red[2], red[3]) + hypot(red[4], red[5]);
+                const double De = hypot(red[6], red[7]) + hypot(red[8], red[9]);
+                S->Dthresh = (double)(2.0f * sr) * RD_SQRT_NLOG_1EM4_5;          // 2 sigma_r sqrt(-ln(P / 5)), P = 1e-4 (dsp.py:318-320)
+                const double Dthresh_eoo = (double)(2.0f * sr) * RD_SQRT_NLOG_1EM5_5;
                 S->Dtmax12 = D; S->Dtmax12_eoo = De;
                 S->candidate = D > S->Dthresh; S->endofover = De > Dthresh_eoo;
                 int nn = RD_NMF, t2 = tm;                                       // radae_rxe.py:209-218
