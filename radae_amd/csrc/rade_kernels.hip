@@ -2385,42 +2385,45 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             __syncthreads();
             PH(5);
-            const int tm = S->tmax; const double w = 2.0 * PI_D * S->fmax / 8000.0;
-            double red[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            for (int t = tid; t < RD_NMF; t += NT_RX) { red[0] += (double)sh->rowsum1[t]; red[1] += (double)sh->rowsum2[t]; }
-            {
-                double rs2[2] = { red[0], red[1] };
-                block_sum_multi<2>(sh, rs2);
-                red[0] = rs2[0]; red[1] = rs2[1];
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) red[2 + q] = sh->corrp[0][q] + sh->corrp[1][q];     // prepared during the matrix phase above
-            const float sr = sigma_r_from_sums(red[0], red[1]);
-            if (tid == 0) {
-                const double D = hypot(red[2], red[3]) + hypot(red[4], red[5]);
-                const double De = hypot(red[6], red[7]) + hypot(red[8], red[9]);
-                S->Dthresh = (double)(2.0f * sr) * RD_SQRT_NLOG_1EM4_5;          // 2 sigma_r sqrt(-ln(P / 5)), P = 1e-4 (dsp.py:318-320)
-                const double Dthresh_eoo = (double)(2.0f * sr) * RD_SQRT_NLOG_1EM5_5;
-                S->Dtmax12 = D; S->Dtmax12_eoo = De;
-                S->candidate = D > S->Dthresh; S->endofover = De > Dthresh_eoo;
-                int nn = RD_NMF, t2 = tm;                                       // radae_rxe.py:209-218
-                if (t2 >= RD_NMF - RD_M) { nn = RD_NMF + RD_M; t2 -= RD_M; }
-                if (t2 < RD_M) { nn = RD_NMF - RD_M; t2 += RD_M; }
-                S->nin = nn; S->tmax = t2;
-                S->synced_count++;                                              // :220-224
-                if (S->synced_count % 8 == 0) { if (S->uw_errors > 7) S->uw_fail = 1; S->uw_errors = 0; S->uw_from_row = S->n_rows; }
-            }
-            __syncthreads();
-            PH(6);
-            const int tmax = S->tmax, endofover = S->endofover, n_rows = n_rows0;
+            // From here to the equaliser ONE phase: wavefronts 0..5 run the demodulator DFT below; wavefront 6 meanwhile reduces the row
+            // sums to the Rayleigh thresholds, decides candidate / end-of-over / slip and runs the state machine (none of it feeds the DFT:
+            // the corrected window was cut with the slip-adjusted timing by the side wavefronts above); wavefront 7 advances the phase
+            // accumulator.  As a phase of its own (workgroup-wide f64 reduction, a barrier, one thread's serial work) this was ~3 k cycles.
+            const double w = 2.0 * PI_D * S->fmax / 8000.0;
             const double rph_r = S->rph_r, rph_i = S->rph_i;
+            float2 *rx1 = sh->xm;
+            if (tid >= NT_RX - 128 && tid < NT_RX - 64) {
+                const int l = tid - (NT_RX - 128);
+                double r0 = 0.0, r1 = 0.0;
+                for (int t = l; t < RD_NMF; t += 64) { r0 += (double)sh->rowsum1[t]; r1 += (double)sh->rowsum2[t]; }
+                r0 = wave_sum_f64(r0); r1 = wave_sum_f64(r1);
+                if (l == 0) {
+                    const int tm = S->tmax;
+                    double red[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) red[q] = sh->corrp[0][q] + sh->corrp[1][q];     // prepared during the matrix phase above
+                    const float sr = sigma_r_from_sums(r0, r1);
+                    const double D = hypot(red[0], red[1]) + hypot(red[2], red[3]);
+                    const double De = hypot(red[4], red[5]) + hypot(red[6], red[7]);
+                    S->Dthresh = (double)(2.0f * sr) * RD_SQRT_NLOG_1EM4_5;          // 2 sigma_r sqrt(-ln(P / 5)), P = 1e-4 (dsp.py:318-320)
+                    const double Dthresh_eoo = (double)(2.0f * sr) * RD_SQRT_NLOG_1EM5_5;
+                    S->Dtmax12 = D; S->Dtmax12_eoo = De;
+                    const int eoo = De > Dthresh_eoo;
+                    S->candidate = D > S->Dthresh; S->endofover = eoo;
+                    int nn = RD_NMF, t2 = tm;                                       // radae_rxe.py:209-218
+                    if (t2 >= RD_NMF - RD_M) { nn = RD_NMF + RD_M; t2 -= RD_M; }
+                    if (t2 < RD_M) { nn = RD_NMF - RD_M; t2 += RD_M; }
+                    S->nin = nn; S->tmax = t2;
+                    S->synced_count++;                                              // :220-224
+                    if (S->synced_count % 8 == 0) { if (S->uw_errors > 7) S->uw_fail = 1; S->uw_errors = 0; S->uw_from_row = S->n_rows; }
+                    state_update(0, !eoo, eoo);                                     // valid_output of a synchronised call = !endofover (set by the EQ below)
+                }
+            }
             // frequency correction (:227-233): rx_phase advances e^{-jw} per sample in complex128; the corrected window rx1 was
             // written by the side wavefronts of the matrix phase
-            float2 *rx1 = sh->xm;
             // the phase accumulator advances on the last wavefront, which has no part in the DFT that follows (a f64 sincos on
             // thread 0 would hold back wavefront 0 and with it the barrier after the DFT)
             if (tid == NT_RX - 64) { double s, c; sincos(-w * (double)RD_NEOO, &s, &c); S->rph_r = rph_r * c - rph_i * s; S->rph_i = rph_r * s + rph_i * c; }
-            if (tid == NT_RX - 128) state_update(0, !endofover, endofover);   // valid_output of a synchronised call = !endofover (set by the EQ below)
             PH(7);
             // The NEXT call's input, fetched under the demodulator and the equaliser (an HBM / L2 round trip of several thousand
             // cycles that would otherwise open the next call): up to nin_max samples and their mix-down phasors -- the next size
@@ -2456,6 +2459,7 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             __syncthreads();
             PH(8);
+            const int endofover = S->endofover, n_rows = n_rows0;
             int pf_n = 0;                                        // settled now (state update above): is there a next call, does the decoder stage run first
             {
                 const int nn = S->nin;
