@@ -32,7 +32,7 @@ NMF = 960
 F32_PEAK_TFLOPS = 157.3          # MI355X f32 matrix == f32 vector peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 # ---- executed-work model of k_rx_sync (SURVEY.md 8d figures) --------------------------------------------
-PREWARM_STEPS = 24                               # see main(): untimed, before the W warm-up steps
+PREWARM_SECONDS = 1.5                            # see main(): untimed, before the W warm-up steps (the clocks of an idle GPU take about a second of load to settle)
 REF_SYNC_CALL_FLOP = 866560 * 8.0                # in-sync DSP per modem frame as the reference formulates it (BPF, refine, check_pilots, DFT; 8 flop per cMAC): 6.93 MFLOP
 # executed: refine() in sync runs as 8 moments x 16 timings x 2 frames x 160 samples (40,960 cMAC) + the polynomials (640 x ~40 flop)
 # instead of 20 frequencies x 16 x 2 x 160 (102,400 cMAC): 0.47 MFLOP less per call
@@ -135,8 +135,10 @@ def main():
     torch.cuda.synchronize()
     # untimed set-up on top of the W warm-up steps the caller asks for: a freshly started GPU box runs its first few dozen launches at
     # lower clocks / with cold code and page tables (measured: 45.6 M frames/s for a whole 100-step run that started cold, 49.1 M
-    # for the same command right after another run), so the engines are exercised a little before anything is counted
-    run_steps(max(0, PREWARM_STEPS - args.warmup), 200)
+    # for the same command right after another run), so the engines are exercised for PREWARM_SECONDS before anything is counted (24 steps were not enough)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < PREWARM_SECONDS:
+        run_steps(8, 200)
     if args.warmup:
         run_steps(args.warmup, 100)
     barrier()
