@@ -33,26 +33,68 @@ F32_PEAK_TFLOPS = 157.3          # MI355X f32 matrix == f32 vector peak (MI355X_
 HBM_PEAK_GBS = 8000.0
 # ---- executed-work model of k_rx_sync (SURVEY.md 8d figures) --------------------------------------------
 PREWARM_SECONDS = 1.5                            # see main(): untimed, before the W warm-up steps (the clocks of an idle GPU take about a second of load to settle)
-REF_SYNC_CALL_FLOP = 866560 * 8.0                # in-sync DSP per modem frame as the reference formulates it (BPF, refine, check_pilots, DFT; 8 flop per cMAC): 6.93 MFLOP
+# SURVEY 8d's 866,560 cMAC per modem frame include the modulator's 24,000-cMAC IDFT, which runs in k_ofdm_mod, not in the receiver kernel
+RX_SYNC_CMAC = 866560 - 24000                    # the receiver's share: BPF, refine, check_pilots, demodulator DFT
+REF_SYNC_CALL_FLOP = RX_SYNC_CMAC * 8.0          # in-sync DSP per modem frame as the reference formulates it (8 flop per cMAC): 6.74 MFLOP
 # executed: refine() in sync runs as 8 moments x 16 timings x 2 frames x 160 samples (40,960 cMAC) + the polynomials (640 x ~40 flop)
 # instead of 20 frequencies x 16 x 2 x 160 (102,400 cMAC): 0.47 MFLOP less per call
-SYNC_CALL_FLOP = (866560 - 102400 + 40960) * 8.0 + 640 * 40.0     # 6.47 MFLOP
+SYNC_CALL_FLOP = (RX_SYNC_CMAC - 102400 + 40960) * 8.0 + 640 * 40.0     # 6.28 MFLOP
 DEC_MF_FLOP = 3 * 904064 * 2.0                   # CoreDecoder, 3 steps per decoded modem frame (runs inside k_rx_sync): 5.42 MFLOP = 0.452 MFLOP per feature frame
 BPF_CALL_FLOP = 960 * 101 * 8.0                  # the BPF of a search / candidate call (it is inside SYNC_CALL_FLOP for synchronised ones): 0.78 MFLOP
 FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface by FFT convolution: 1 forward + 40 inverse 2048-point FFTs (5 N log2 N) + 40 spectral products: 5.11 MFLOP
 REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation of detect_pilots (two surfaces as GEMMs): 98.3 MFLOP -- NOT executed here
 ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
 RX_ALGO_BYTES_PER_FRAME = 640 + 144              # the receiver kernel's share: IQ in + features out
-PROFILE_TAG = "r02"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
+PROFILE_TAG = "r03"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
 
 
 def executed_flop(search_calls, sync_calls, decoded_mf):
     return sync_calls * SYNC_CALL_FLOP + decoded_mf * DEC_MF_FLOP + search_calls * (FFT_SURFACE_FLOP + BPF_CALL_FLOP)
 
 
+def launch_plan(gpus, env, n_visible, argv, port=None):
+    """What `bench.py --gpus N` has to do before any GPU work (pure function: the CPU tests call it).
+    Returns ("inprocess", None) -- this process is the job (N == 1) or one rank of it (started by torch.distributed.run: WORLD_SIZE
+    must then equal --gpus) -- or ("spawn", argv_of_child): N > 1 asked for by a plain `python bench.py --gpus N`, so this process
+    re-executes itself under `python -m torch.distributed.run` with one rank per GPU and relays the ranks' output.
+    Raises SystemExit (non-zero) when fewer than N devices are visible or the rank count disagrees with --gpus."""
+    if gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {gpus} is not a GPU count")
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started {world} rank(s) (WORLD_SIZE): n_gpus in the line would be wrong")
+        if n_visible < int(env.get("LOCAL_RANK", "0")) + 1:
+            raise SystemExit(f"bench.py: rank with LOCAL_RANK={env.get('LOCAL_RANK', '0')} has no GPU ({n_visible} HIP device(s) visible)")
+        return "inprocess", None
+    if gpus == 1:
+        if n_visible < 1:
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+        return "inprocess", None
+    if n_visible < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} asked for but only {n_visible} HIP device(s) are visible -- refusing to report a {gpus}-GPU number from fewer GPUs")
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    return "spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def cpu_quota():
+    """(logical CPUs visible to this process, cgroup CPU quota in cores or None)"""
+    ncpu = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return ncpu, (None if q == "max" else float(q) / float(per))
+    except Exception:
+        return ncpu, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--repeats", type=int, default=3, help="the timed K-step loop is run this many times (barrier-bracketed each); value = the median repeat")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=256, help="utterances per GPU")
@@ -64,9 +106,14 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
 
+    mode, child = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0, sys.argv[1:])
+    if mode == "spawn":                  # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run; rank 0 of the child prints the line
+        import subprocess
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env["RADE_BENCH_LAUNCHER"] = "self (bench.py re-executed under torch.distributed.run)"
+        raise SystemExit(subprocess.call(child, env=env))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    assert world == args.gpus, (world, args.gpus)
+    launcher = os.environ.get("RADE_BENCH_LAUNCHER", "torch.distributed.run (caller)" if "WORLD_SIZE" in os.environ else "in-process, single rank")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if args.config == 2:
@@ -141,21 +188,31 @@ def main():
         run_steps(8, 200)
     if args.warmup:
         run_steps(args.warmup, 100)
-    barrier()
-    t0 = time.perf_counter()
-    fo, st, _, rx_last = run_steps(args.steps, 1)
-    barrier()
-    dt_local = time.perf_counter() - t0
-    dt = dt_local
-    per_rank_ms = [1e3 * dt_local / args.steps]
+    # the timed region: EXACTLY K steps between barrier + synchronize on both sides, max over ranks; run `--repeats` times (same seeds, so
+    # the same work) and the median repeat is the one reported -- every repeat is in the line (value_repeats)
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        fo, st, _, rx_last = run_steps(args.steps, 1)
+        barrier()
+        dt_local = time.perf_counter() - t0
+        dt = dt_local
+        per_rank_ms = [1e3 * dt_local / args.steps]
+        if world > 1:
+            import torch.distributed as dist
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+            allms = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(allms, torch.tensor([1e3 * dt_local / args.steps], dtype=torch.float64, device=dev))
+            per_rank_ms = [float(x.item()) for x in allms]
+        reps.append((dt, per_rank_ms))
+    dt, per_rank_ms = sorted(reps, key=lambda r: r[0])[(len(reps) - 1) // 2]      # median (lower middle for an even count)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        allms = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(allms, torch.tensor([1e3 * dt_local / args.steps], dtype=torch.float64, device=dev))
-        per_rank_ms = [float(x.item()) for x in allms]
+        ranks_seen = dist.get_world_size()
 
     total_frames = B * T * args.steps * world
     value = total_frames / dt
@@ -175,6 +232,8 @@ def main():
                       "roofline.sum_kernel_ms_per_step is one batch alone",
         "value_counts": "offered feature frames: every transmitted frame's samples pass through the receiver, decoded or not",
         "decoded_frames_per_s": value * job[1] / job[0],
+        "timed_region_s": dt, "value_repeats": [B * T * args.steps * world / r[0] for r in reps], "timed_region_s_repeats": [r[0] for r in reps],
+        "launcher": launcher, "rccl_ranks": ranks_seen,
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
         "job_last_step": {"offered_frames": int(job[0]), "decoded_frames": int(job[1]), "rx_calls": int(job[2]), "sync_calls": int(job[3]),
                           "search_calls": int(job[4]), "eoo_detected_streams": int(job[5])},
@@ -230,7 +289,7 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
                   "per_launch_counts": counts, "executed_flop_per_launch": fl, "algorithmic_bytes_per_launch": algo_bytes,
                   "flop_model": {"sync_call": SYNC_CALL_FLOP, "decoded_modem_frame": DEC_MF_FLOP, "search_call": FFT_SURFACE_FLOP + BPF_CALL_FLOP,
-                                 "note": "executed work: in-sync DSP 805,120 cMAC x 8 (refine by moments: 40,960 cMAC instead of the reference formulation's 102,400) + polynomials per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
+                                 "note": "executed work: in-sync DSP 781,120 cMAC x 8 (refine by moments: 40,960 cMAC instead of the reference formulation's 102,400) + polynomials per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
                                          "search call = one |Dt| surface by FFT convolution (41 x 5 N log2 N + 40 x 6 N, N = 2048) + BPF; priced at the f32 peak"},
                   "hbm_frac_kernel": algo_bytes / (r["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
                   "equiv_ref_formulation": {"tflops": (counts["sync_calls"] * REF_SYNC_CALL_FLOP + counts["decoded_modem_frames"] * DEC_MF_FLOP + counts["search_calls"] * REF_SEARCH_CALL_FLOP)
@@ -247,7 +306,8 @@ def roofline_leg(eng, step, steps, B, T, value, world):
     r["limiter"] = "latency (s_waitcnt/s_barrier) + valu-issue"
     r["traffic"] = None
     try:
-        pm = json.load(open(os.path.join(REPO, "profiles", f"{PROFILE_TAG}_pmc_summary.json")))
+        tag = next(t for t in (PROFILE_TAG, "r02") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
+        pm = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")))
         k = pm["kernels"][{"rx_sync": "k_rx_sync"}.get(dom, dom)]
         raw = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
         r["traffic"] = raw
@@ -258,11 +318,11 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         tb = pm.get("rx_sync_traffic_breakdown_bytes_per_launch")
         if tb and dom == "rx_sync":
             r["traffic_ratio_incl_search_state"] = tb["ratio_raw_over_io_plus_search_state"]      # |Dt| surfaces kept between search calls counted as algorithmic state
-            r["traffic_breakdown"] = f"profiles/{PROFILE_TAG}_pmc_summary.json:rx_sync_traffic_breakdown_bytes_per_launch"
+            r["traffic_breakdown"] = f"profiles/{tag}_pmc_summary.json:rx_sync_traffic_breakdown_bytes_per_launch"
         if "l2_hit_rate" in k:
             r["l2_hit_rate_pmc"] = k["l2_hit_rate"]
         r["mfma_busy_pct_pmc"] = k["mfma_busy_pct"]
-        r["counters_from"] = f"profiles/{PROFILE_TAG}_pmc_summary.json (commit {pm.get('commit', '?')})"
+        r["counters_from"] = f"profiles/{tag}_pmc_summary.json (commit {pm.get('commit', '?')})"
         sq = pm.get("sq_breakdown", {}).get("k_rx_sync")
         if sq:
             r["sq_wave_cycle_shares"] = sq
@@ -387,8 +447,10 @@ def cpu_baseline_allcores(T, n_utt=6):
         el = max(s[1] for s in spans) - min(s[0] for s in spans)      # first start to last finish of the oracle loops (process start-up excluded)
         rate = procs * n_utt * T / el
         if best is None or rate > best["value"]:
+            quota = cpu_quota()[1]
             best = {"value": rate, "unit": "frames/s", "cores": procs, "kind": "port",
-                    "sample": f"{procs} processes x {n_utt} utterances x {T} frames in {el:.1f} s ({ncpu} logical CPUs visible)"}
+                    "sample": f"{procs} processes x {n_utt} utterances x {T} frames in {el:.1f} s ({ncpu} logical CPUs visible, cgroup CPU quota "
+                              + (f"{quota:.1f} cores -- the quota, not the oracle, caps this figure" if quota else "none") + ")"}
     return best
 
 

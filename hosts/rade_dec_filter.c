@@ -6,6 +6,7 @@
  * `auxdata[0-1] [weights_blob.bin]`; per step 4 x 36 floats out: 20 features, the aux symbol in column 20 when auxdata = 1,
  * zeros elsewhere).
  */
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,8 +24,9 @@ int main(int argc, char **argv)
         FILE *f = fopen(argv[2], "rb");
         if (!f) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
         fseek(f, 0, SEEK_END); long len = ftell(f); fseek(f, 0, SEEK_SET);
-        data = malloc(len);
-        if (!data || fread(data, 1, len, f) != (size_t)len || parse_weights(&list, data, (int)len) < 0) { fprintf(stderr, "bad weight blob %s\n", argv[2]); return 1; }
+        if (len <= 0 || len > INT_MAX) { fprintf(stderr, "bad weight blob %s (size %ld)\n", argv[2], len); return 1; }
+        data = malloc((size_t)len);
+        if (!data || fread(data, 1, (size_t)len, f) != (size_t)len || parse_weights(&list, data, (int)len) < 0) { fprintf(stderr, "bad weight blob %s\n", argv[2]); return 1; }
         fclose(f);
     }
     if (init_radedec(&model, list ? list : radedec_arrays, output_dim) != 0) { fprintf(stderr, "Error initialising decoder model (output_dim %d)\n", output_dim); return 1; }
@@ -39,6 +41,7 @@ int main(int argc, char **argv)
             if (auxdata) out[i * nb_total + used] = feat[i * nf + used];
         }
         fwrite(out, sizeof(float), RADE_FRAMES_PER_STEP * nb_total, stdout);
+        fflush(stdout);                 /* per step, as test_rade_dec.c does: a live pipe (rx | dec | vocoder) must not stall on the stdio buffer */
         n++;
     }
     fflush(stdout);

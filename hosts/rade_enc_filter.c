@@ -6,6 +6,7 @@
  * `bottleneck[1-3] auxdata[0-1] [weights_blob.bin]`, same wire formats: 4 x 36 floats in per step, the first 20 of each
  * frame used, aux symbol -1 appended when auxdata = 1; 80 floats out).
  */
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,8 +24,9 @@ int main(int argc, char **argv)
         FILE *f = fopen(argv[3], "rb");
         if (!f) { fprintf(stderr, "cannot open %s\n", argv[3]); return 1; }
         fseek(f, 0, SEEK_END); long len = ftell(f); fseek(f, 0, SEEK_SET);
-        data = malloc(len);
-        if (!data || fread(data, 1, len, f) != (size_t)len || parse_weights(&list, data, (int)len) < 0) { fprintf(stderr, "bad weight blob %s\n", argv[3]); return 1; }
+        if (len <= 0 || len > INT_MAX) { fprintf(stderr, "bad weight blob %s (size %ld)\n", argv[3], len); return 1; }
+        data = malloc((size_t)len);
+        if (!data || fread(data, 1, (size_t)len, f) != (size_t)len || parse_weights(&list, data, (int)len) < 0) { fprintf(stderr, "bad weight blob %s\n", argv[3]); return 1; }
         fclose(f);
     }
     if (init_radeenc(&model, list ? list : radeenc_arrays, input_dim) != 0) { fprintf(stderr, "Error initialising encoder model (input_dim %d)\n", input_dim); return 1; }
@@ -38,6 +40,7 @@ int main(int argc, char **argv)
         }
         rade_core_encoder(&st, &model, z, feat, 0, bottleneck);
         fwrite(z, sizeof(float), RADE_LATENT_DIM, stdout);
+        fflush(stdout);                 /* per step, as test_rade_enc.c does: a live pipe (enc | tx) must not stall on the stdio buffer */
         n++;
     }
     fflush(stdout);

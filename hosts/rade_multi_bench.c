@@ -61,6 +61,7 @@ typedef struct {
     int T, n_mf, n_sig, n_pre, n_post, n_total, steps, warmup;
     float taps[100]; int low_ratio;
     pthread_barrier_t bar;
+    volatile int failed;             /* set by any device thread whose step failed: the others skip their work but still reach both barriers */
     /* per device */
     float *feat[64], *fout[64]; void *G[64], *iq[64], *rx[64]; int *avail[64]; rade_rx_status *st[64];
     double t_step[64]; double stats[64][6];
@@ -70,12 +71,18 @@ static int setup(int i, rade_batch *e, int first, int n, void *arg)
 {
     job *j = arg;
     float *hf = malloc(sizeof(float) * (size_t)n * j->T * 36);
+    if (!hf) return -1;
     for (int b = 0; b < n; b++) synth_features(1000 + first + b, j->T, hf + (size_t)b * j->T * 36);
-    if (hipMalloc((void **)&j->feat[i], sizeof(float) * (size_t)n * j->T * 36) || hipMalloc(&j->G[i], 16ull * n * j->n_sig) ||
-        hipMalloc(&j->iq[i], 8ull * n * j->n_sig) || hipMalloc(&j->rx[i], 8ull * n * j->n_total) ||
-        hipMalloc((void **)&j->fout[i], sizeof(float) * (size_t)n * (j->n_mf + 8) * 432)) return -1;
-    if (hipMemcpy(j->feat[i], hf, sizeof(float) * (size_t)n * j->T * 36, hipMemcpyHostToDevice)) return -1;
+    int bad = hipMalloc((void **)&j->feat[i], sizeof(float) * (size_t)n * j->T * 36) || hipMalloc(&j->G[i], 16ull * n * j->n_sig) ||
+              hipMalloc(&j->iq[i], 8ull * n * j->n_sig) || hipMalloc(&j->rx[i], 8ull * n * j->n_total) ||
+              hipMalloc((void **)&j->fout[i], sizeof(float) * (size_t)n * (j->n_mf + 8) * 432);
+    if (!bad) bad = hipMemcpy(j->feat[i], hf, sizeof(float) * (size_t)n * j->T * 36, hipMemcpyHostToDevice) != hipSuccess;
     free(hf);
+    if (bad) {                       /* release what this device got (hipFree(NULL) is a no-op) */
+        hipFree(j->feat[i]); hipFree(j->G[i]); hipFree(j->iq[i]); hipFree(j->rx[i]); hipFree(j->fout[i]);
+        j->feat[i] = j->fout[i] = NULL; j->G[i] = j->iq[i] = j->rx[i] = NULL;
+        return -1;
+    }
     if (rade_batch_multipath_gen(e, j->taps, 100, j->low_ratio, j->n_sig, NULL, 5000 + first, j->G[i], NULL) != j->n_sig) return -1;
     j->avail[i] = malloc(sizeof(int) * n); j->st[i] = malloc(sizeof(rade_rx_status) * n);
     for (int b = 0; b < n; b++) j->avail[i][b] = j->n_total;
@@ -96,14 +103,18 @@ static int one_step(job *j, int i, rade_batch *e, int n, unsigned long long seed
 static int run(int i, rade_batch *e, int first, int n, void *arg)
 {
     job *j = arg;
-    for (int w = 0; w < j->warmup; w++) if (one_step(j, i, e, n, 100 + w)) return -1;
+    /* a failed step must not leave the other device threads waiting at a barrier for ever: the error is recorded, the work skipped,
+     * and every thread still reaches both barriers */
+    int rc = 0;
+    for (int w = 0; w < j->warmup && !j->failed; w++) if (one_step(j, i, e, n, 100 + w)) { j->failed = 1; rc = -1; }
     hipDeviceSynchronize();
     pthread_barrier_wait(&j->bar);                               /* all devices start the timed region together */
     const double t0 = now_s();
-    for (int k = 0; k < j->steps; k++) if (one_step(j, i, e, n, 1 + k)) return -1;
+    for (int k = 0; k < j->steps && !j->failed; k++) if (one_step(j, i, e, n, 1 + k)) { j->failed = 1; rc = -1; }
     hipDeviceSynchronize();
     j->t_step[i] = (now_s() - t0) / j->steps;
     pthread_barrier_wait(&j->bar);
+    if (rc || j->failed) return -1;
     double *s = j->stats[i]; memset(s, 0, sizeof(double) * 6);
     for (int b = 0; b < n; b++) {
         const rade_rx_status *r = &j->st[i][b];

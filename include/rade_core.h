@@ -32,7 +32,7 @@ extern "C" {
 
 /* layout of Opus' WeightArray (dnn/nnet.h): one record of a DNNw blob */
 typedef struct { const char *name; int type; int size; const void *data; } WeightArray;
-/* walks a DNNw blob (src/write_rade_weights.c:51-74); *list is malloc'ed, terminated by a NULL name; returns the number of
+/* walks a DNNw blob (src/write_rade_weights.c:51-74); *list is the malloc'ed pointer itself (free(list) is valid, also while models initialised from it are in use), terminated by a NULL name; returns the number of
  * arrays or -1.  `data` must stay mapped while models initialised from the list are in use (as in the reference). */
 int rade_parse_weights(WeightArray **list, const void *data, int len);
 #ifndef RADE_CORE_KEEP_OPUS_NAMES_FREE

@@ -15,7 +15,8 @@
 #include "rade_batch.h"
 #include "rade_host.h"
 
-/* hidden record in front of every list rade_parse_weights() returns: where the blob lives */
+/* hidden record BEHIND the NULL terminator of every list rade_parse_weights() returns: where the blob lives.  *list is the
+ * malloc'ed pointer itself, so the reference harnesses' free(list) (test_rade_enc.c:115, test_rade_dec.c:115) is valid. */
 #define RD_LIST_MAGIC "__rade_blob__"
 /* the reference links compiled-in weights under these names; here they stand for "the default blob" */
 const WeightArray radeenc_arrays[1] = { { NULL, -1, 0, NULL } };
@@ -35,15 +36,16 @@ int rade_parse_weights(WeightArray **list, const void *data, int len)
     }
     WeightArray *l = calloc((size_t)n + 2, sizeof *l);
     if (!l) return -1;
-    l[0].name = RD_LIST_MAGIC; l[0].size = len; l[0].data = data;
     size_t off = 0;
     for (int i = 0; i < n; i++) {
         int type, size, block;
         memcpy(&type, p + off + 8, 4); memcpy(&size, p + off + 12, 4); memcpy(&block, p + off + 16, 4);
-        l[1 + i].name = (const char *)(p + off + 20); l[1 + i].type = type; l[1 + i].size = size; l[1 + i].data = p + off + 64;
+        l[i].name = (const char *)(p + off + 20); l[i].type = type; l[i].size = size; l[i].data = p + off + 64;
         off += 64 + (size_t)block;
     }
-    *list = l + 1;
+    /* l[n] is the NULL terminator (calloc); the blob record sits behind it, out of reach of a walk over the list */
+    l[n + 1].name = RD_LIST_MAGIC; l[n + 1].size = len; l[n + 1].data = data;
+    *list = l;
     return n;
 }
 
@@ -58,7 +60,9 @@ static int list_blob(const WeightArray *arrays, const void **blob, int *len)
 {
     static void *def_blob; static int def_len;
     if (arrays && arrays != radeenc_arrays && arrays != radedec_arrays) {
-        const WeightArray *hdr = arrays - 1;
+        const WeightArray *hdr = arrays;
+        while (hdr->name) hdr++;                               /* the terminator; the blob record follows it */
+        hdr++;
         if (!hdr->name || strcmp(hdr->name, RD_LIST_MAGIC)) { fprintf(stderr, "rade_core: weight list was not made by rade_parse_weights()\n"); return -1; }
         *blob = hdr->data; *len = hdr->size;
         return 0;
@@ -85,7 +89,7 @@ static int init_model(const WeightArray *arrays, int dim, const void **blob, int
     if (rade_parse_weights(&l, *blob, *len) < 0) return 1;
     /* the dimension the blob was exported with: enc_dense1 is (input_dim x 64) floats, dec_output has output_dim biases */
     const int w = find_array(l, "enc_dense1_weights_float"), b = find_array(l, "dec_output_bias");
-    free(l - 1);
+    free(l);
     if (w != dim * 64 * 4 || b != dim * 4) return 1;
     return 0;
 }

@@ -264,8 +264,12 @@ int rd_model_parse(const void *blob, size_t len, rd_model *m)
             m->enc_conv[i].n_in != 2 * (enc_in[i] + 64) || m->enc_conv[i].n_out != 96 || m->dec_conv[i].n_in != 2 * (dec_in[i] + 96) || m->dec_conv[i].n_out != 32) {
             fprintf(stderr, "rade: unexpected layer shape in weight blob (layer %d)\n", i + 1); rd_model_free(m); return -1;
         }
-    if ((m->enc_dense1.n_in != 84 && m->enc_dense1.n_in != 80) || m->enc_zdense.n_in != 864 || m->enc_zdense.n_out != 80 || m->dec_dense1.n_in != 80 ||
-        m->dec_output.n_out != m->enc_dense1.n_in) {   /* 4 x 21 features (model19, aux symbol) or 4 x 20 (model05, bbfm) */
+    for (int i = 0; i < 5; i++)
+        if (m->dec_glu[i].n_in != 96 || m->dec_glu[i].n_out != 96) { fprintf(stderr, "rade: unexpected GLU shape in weight blob (layer %d)\n", i + 1); rd_model_free(m); return -1; }
+    /* every dimension the engine's upload (rade_engine.c:upload_lin) hard-codes is checked here: a foreign or crafted blob with smaller
+     * layers must not get as far as the packers, which read N x K floats */
+    if ((m->enc_dense1.n_in != 84 && m->enc_dense1.n_in != 80) || m->enc_dense1.n_out != 64 || m->enc_zdense.n_in != 864 || m->enc_zdense.n_out != 80 ||
+        m->dec_dense1.n_in != 80 || m->dec_dense1.n_out != 96 || m->dec_output.n_in != 736 || m->dec_output.n_out != m->enc_dense1.n_in) {   /* 4 x 21 features (model19, aux symbol) or 4 x 20 (model05, bbfm) */
         fprintf(stderr, "rade: unexpected dense layer shape in weight blob\n"); rd_model_free(m); return -1;
     }
     return 0;

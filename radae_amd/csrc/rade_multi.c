@@ -41,12 +41,12 @@ struct rade_multi {
 };
 
 void rade_multi_shard(int n_total, int n_dev, int i, int *first, int *count)
-{   /* contiguous shards of ceil(n_total / n_dev): config 4 = 2048 utterances, device g owns [256 g, 256 g + 256) */
-    const int per = (n_total + n_dev - 1) / n_dev;
-    int lo = i * per; if (lo > n_total) lo = n_total;
-    int hi = lo + per; if (hi > n_total) hi = n_total;
+{   /* contiguous balanced shards: n_total / n_dev each, the first n_total % n_dev devices one more (no device is left empty when
+     * n_total >= n_dev: 10 streams on 8 devices = 2,2,1,1,1,1,1,1).  Config 4 = 2048 utterances: device g owns [256 g, 256 g + 256) */
+    const int base = n_total / n_dev, extra = n_total % n_dev;
+    const int lo = i * base + (i < extra ? i : extra);
     if (first) *first = lo;
-    if (count) *count = hi - lo;
+    if (count) *count = base + (i < extra ? 1 : 0);
 }
 
 static int rccl_bind(rade_multi *m)
@@ -78,6 +78,9 @@ rade_multi *rade_multi_open(const char *blob_path, int n_streams_total, int max_
     if (!m) return NULL;
     int ndev_hw = 0;
     if (hipGetDeviceCount(&ndev_hw) != hipSuccess || ndev_hw <= 0) { fprintf(stderr, "rade_multi: no HIP device available -- this library has no CPU fallback\n"); free(m); return NULL; }
+    if (ndev_hw < 64 && (device_mask >> ndev_hw)) {          /* a mask bit for a device that does not exist would silently change the sharding */
+        fprintf(stderr, "rade_multi: device mask %#llx selects device(s) beyond the %d present\n", device_mask, ndev_hw); free(m); return NULL;
+    }
     for (int g = 0; g < RM_MAXDEV && g < ndev_hw; g++) if (device_mask & (1ull << g)) m->dev[m->n_dev++] = g;
     if (m->n_dev == 0 || n_streams_total < m->n_dev || max_tx_mf <= 0) { fprintf(stderr, "rade_multi: bad arguments (mask %#llx selects %d of %d devices, %d streams)\n", device_mask, m->n_dev, ndev_hw, n_streams_total); free(m); return NULL; }
     m->n_total = n_streams_total;

@@ -30,10 +30,11 @@ def broadcast_blob(path_on_rank0: Optional[str], device, world_size: int) -> byt
 
 
 def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
-    """Contiguous utterance shard [lo, hi) of rank `rank` (config 4: GPU g gets u in [256g, 256g+256))."""
-    per = (n_items + world_size - 1) // world_size
-    lo = min(n_items, rank * per)
-    return lo, min(n_items, lo + per)
+    """Contiguous balanced utterance shard [lo, hi) of rank `rank`: n // world each, the first n % world ranks one more (same rule
+    as rade_multi_shard in C; config 4: GPU g gets u in [256g, 256g+256))."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
 
 
 def gather_stats(local: np.ndarray, device, world_size: int) -> np.ndarray:

@@ -81,21 +81,33 @@ def test_core_level_model_init_on_cpu(lib):
         assert L.init_radeenc(C.byref(m), lst, good) == 0 and m.dim == good and m.nb_z == 80
         assert L.init_radeenc(C.byref(m), lst, bad) != 0 and L.init_radedec(C.byref(m), lst, bad) != 0 and L.init_radedec(C.byref(m), lst, 64) != 0
         assert L.init_radedec(C.byref(m), lst, good) == 0
+        # the reference harnesses free(list) after init (test_rade_enc.c:115, test_rade_dec.c:115): *list must be the malloc'ed pointer
+        # itself (glibc aborts on an interior pointer), and a model initialised from it keeps working from the blob alone
+        libc = C.CDLL(None); libc.free.argtypes = [C.c_void_p]; libc.free.restype = None
+        n_names = 0
+        while lst[n_names].name:
+            n_names += 1
+        assert n_names > 100
+        libc.free(C.cast(lst, C.c_void_p))
+        assert m.dim == good
 
 
 def test_multi_gpu_sharding_rule(lib):
-    """rade_multi_shard: contiguous ceil(total / n_dev) shards -- config 4: 2048 utterances, GPU g owns [256 g, 256 g + 256) -- and the
-    same rule as the torchrun path's radae_amd.parallel.shard_range; rade_multi_open refuses to run without a GPU."""
+    """rade_multi_shard: contiguous balanced shards (no device left empty when there are at least as many streams as devices: 9 or 10
+    streams on 8 GPUs) -- config 4: 2048 utterances, GPU g owns [256 g, 256 g + 256) -- and the same rule as the torchrun path's
+    radae_amd.parallel.shard_range; rade_multi_open refuses to run without a GPU."""
     from radae_amd.parallel import shard_range
     lib.rade_multi_shard.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]; lib.rade_multi_shard.restype = None
-    for total, ndev in ((2048, 8), (256, 1), (10, 4), (7, 8), (1000, 3)):
+    for total, ndev in ((2048, 8), (256, 1), (10, 4), (7, 8), (1000, 3), (9, 8), (10, 8), (8, 8), (2047, 8)):
         got = []
         for i in range(ndev):
             lo, n = C.c_int(), C.c_int()
             lib.rade_multi_shard(total, ndev, i, C.byref(lo), C.byref(n))
             got.append((lo.value, lo.value + n.value))
         assert got == [shard_range(total, r, ndev) for r in range(ndev)]
-        assert sum(b - a for a, b in got) == total
+        assert sum(b - a for a, b in got) == total and got[0][0] == 0 and all(got[i][1] == got[i + 1][0] for i in range(ndev - 1))
+        sizes = [b - a for a, b in got]
+        assert max(sizes) - min(sizes) <= 1 and (total < ndev or min(sizes) >= 1)
     lo, n = C.c_int(), C.c_int()
     lib.rade_multi_shard(2048, 8, 5, C.byref(lo), C.byref(n))
     assert (lo.value, n.value) == (1280, 256)
@@ -249,6 +261,13 @@ def test_host_blob_reader_rejects_hostile_headers(lib):
     assert rejected(lambda b: struct.pack_into("<i", b, o3 + 12, size3 - 96))         # weight count not n_in x n_out
     o4, size4, _ = recs["enc_gru2_input_weights_int8"]
     assert rejected(lambda b: struct.pack_into("<i", b, o4 + 12, size4 - 32))         # fewer 8x4 blocks than the index walk needs
+    # self-consistent but SMALLER dense layers (a foreign model): the engine's upload hard-codes 64 / 96 / 736, so the parser refuses them
+    def shrink(b, name, n_in, n_out):
+        struct.pack_into("<i", b, recs[name + "_weights_float"][0] + 12, n_in * n_out * 4); struct.pack_into("<i", b, recs[name + "_bias"][0] + 12, n_out * 4)
+    assert not rejected(lambda b: shrink(b, "enc_dense1", 84, 64))                    # (the unchanged shape parses)
+    assert rejected(lambda b: shrink(b, "enc_dense1", 84, 32))
+    assert rejected(lambda b: shrink(b, "dec_dense1", 80, 48))
+    assert rejected(lambda b: shrink(b, "dec_output", 368, 84))
     rng = np.random.default_rng(5)                                                    # random header bytes: refuse or parse, never crash
     for _ in range(200):
         b = bytearray(blob)
