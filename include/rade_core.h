@@ -62,6 +62,9 @@ void rade_core_decoder(RADEDecState *dec_state, const RADEDec *model, float *fea
 /* additive: release the device-side state of a stream */
 void rade_free_encoder(RADEEncState *enc_state);
 void rade_free_decoder(RADEDecState *dec_state);
+/* additive: zero GRU / conv state of an initialised stream, keeping its uploaded weights (rade_init_* on a state in use would leak them) */
+void rade_reset_encoder(RADEEncState *enc_state);
+void rade_reset_decoder(RADEDecState *dec_state);
 
 #ifdef __cplusplus
 }

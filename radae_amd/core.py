@@ -10,7 +10,7 @@ import numpy as np
 from .engine import DEFAULT_BLOB, load_library
 
 CORE_SYMBOLS = ["rade_parse_weights", "init_radeenc", "init_radedec", "rade_init_encoder", "rade_core_encoder", "rade_init_decoder",
-                "rade_core_decoder", "rade_free_encoder", "rade_free_decoder"]
+                "rade_core_decoder", "rade_free_encoder", "rade_reset_encoder", "rade_reset_decoder", "rade_free_decoder"]
 
 
 class WeightArray(C.Structure):
@@ -30,7 +30,7 @@ def _lib():
     L.rade_parse_weights.argtypes = [C.POINTER(C.POINTER(WeightArray)), C.c_void_p, C.c_int]
     L.init_radeenc.argtypes = [C.POINTER(_Model), C.POINTER(WeightArray), C.c_int]
     L.init_radedec.argtypes = [C.POINTER(_Model), C.POINTER(WeightArray), C.c_int]
-    for n in ("rade_init_encoder", "rade_init_decoder", "rade_free_encoder", "rade_free_decoder"):
+    for n in ("rade_init_encoder", "rade_init_decoder", "rade_free_encoder", "rade_reset_encoder", "rade_reset_decoder", "rade_free_decoder"):
         getattr(L, n).argtypes = [C.POINTER(_State)]; getattr(L, n).restype = None
     L.rade_core_encoder.argtypes = [C.POINTER(_State), C.POINTER(_Model), C.c_void_p, C.c_void_p, C.c_int, C.c_int]; L.rade_core_encoder.restype = None
     L.rade_core_decoder.argtypes = [C.POINTER(_State), C.POINTER(_Model), C.c_void_p, C.c_void_p, C.c_int]; L.rade_core_decoder.restype = None
@@ -62,8 +62,10 @@ class _Core:
         self.reset()
 
     def reset(self):
-        (self.L.rade_free_encoder if self.enc else self.L.rade_free_decoder)(C.byref(self.state))
-        (self.L.rade_init_encoder if self.enc else self.L.rade_init_decoder)(C.byref(self.state))
+        if self.state.initialized:
+            (self.L.rade_reset_encoder if self.enc else self.L.rade_reset_decoder)(C.byref(self.state))
+        else:
+            (self.L.rade_init_encoder if self.enc else self.L.rade_init_decoder)(C.byref(self.state))
 
     def close(self):
         (self.L.rade_free_encoder if self.enc else self.L.rade_free_decoder)(C.byref(self.state))

@@ -10,10 +10,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "rade_core.h"
 #include "rade_batch.h"
 #include "rade_host.h"
+#include "rade_dev.h"
 
 /* hidden record BEHIND the NULL terminator of every list rade_parse_weights() returns: where the blob lives.  *list is the
  * malloc'ed pointer itself, so the reference harnesses' free(list) (test_rade_enc.c:115, test_rade_dec.c:115) is valid. */
@@ -112,30 +114,65 @@ int init_radedec(RADEDec *model, const WeightArray *arrays, int output_dim)
     return 0;
 }
 
-/* device side of one state: a single-stream engine and its staging buffers */
-/* One step is ~20 short dependent launches for a single stream (launch-bound), so after the first call the sequence
- * [input H2D, encoder / decoder kernels, output D2H] is captured once and replayed as a hipGraph, as rade_tx() does. */
-typedef struct { rade_batch *eng; float *d_in, *d_out; int dim; hipStream_t gs; hipGraphExec_t graph; int calls, graph_off; float *h_in, *h_out; } core_dev;
+/* ---- device side of one state ------------------------------------------------------------------------------------
+ * One step = ONE launch of k_core_step (rade_core_step.hip): the whole layer stack for the stream's next 40 ms in a single
+ * workgroup, weights row-major in HBM / L2 (int8 layers as one binary16 plane of integers + row scales), GRU and conv state in
+ * HBM between calls, input and output in pinned host memory the kernel reads / writes directly (no copy nodes).
+ * $RADE_CORE_LAYERWISE=1 selects the previous implementation instead (the batched layer-wise engine with B = 1 replayed as a
+ * hipGraph: ~20 dependent launches per step) -- kept for A/B measurements, same results to rounding. */
+#define CORE_MAXBUF 64
+typedef struct {
+    int dim, layerwise;
+    /* single-launch path */
+    rd_core_args a; void *bufs[CORE_MAXBUF]; int n_bufs; hipStream_t gs; float *h_in, *h_out; int device;
+    /* layer-wise path */
+    rade_batch *eng; float *d_in, *d_out; hipGraphExec_t graph; int calls, graph_off;
+} core_dev;
 
-static core_dev *dev_open(const void *blob, int len, int dim)
+static void *core_upload(core_dev *d, const void *src, size_t bytes)
 {
-    core_dev *d = calloc(1, sizeof *d);
-    if (!d) return NULL;
-    rade_batch_config cfg = { 1, 1, 0, 0, 0, 0.0f };
-    const char *dv = getenv("RADE_DEVICE");
-    if (dv) cfg.device = atoi(dv);
-    d->eng = rade_batch_open_mem(blob, (size_t)len, &cfg);
-    d->dim = dim;
-    if (!d->eng || hipMalloc((void **)&d->d_in, sizeof(float) * 96) != hipSuccess || hipMalloc((void **)&d->d_out, sizeof(float) * 96) != hipSuccess) {
-        if (d->eng) rade_batch_close(d->eng);
-        if (d->d_in) hipFree(d->d_in);
-        free(d);
-        return NULL;
-    }
-    if (getenv("RADE_NO_GRAPH") || hipStreamCreate(&d->gs) != hipSuccess || hipHostMalloc((void **)&d->h_in, sizeof(float) * 96, 0) != hipSuccess ||
-        hipHostMalloc((void **)&d->h_out, sizeof(float) * 96, 0) != hipSuccess) { d->graph_off = 1; (void)hipGetLastError(); }
-    return d;
+    void *p = NULL;
+    if (d->n_bufs >= CORE_MAXBUF || hipMalloc(&p, bytes) != hipSuccess) return NULL;
+    if (src ? hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess : hipMemset(p, 0, bytes) != hipSuccess) { hipFree(p); return NULL; }
+    d->bufs[d->n_bufs++] = p;
+    return p;
 }
+/* one layer, chunk-major [Kpad / 8][Npad][8] (rade_core_step.hip): the integers of an int8 layer as a binary16 plane + row scales
+ * when `want_q` (the kernel's product for this layer is the binary16 one), float32 otherwise */
+static int core_layer(core_dev *d, rd_mv *L, const float *w, const float *bias, const float *row_scale, int N, int K, int want_q)
+{
+    const int Kpad = (K + 7) & ~7, Npad = (N + 63) & ~63;
+    memset(L, 0, sizeof *L);
+    L->N = N; L->K = Kpad;
+    if (want_q) {
+        /* a float layer where the kernel expects integers cannot be represented: every GRU / conv / GLU layer of the blob format is int8 */
+        unsigned short *q = malloc(sizeof(unsigned short) * (size_t)Npad * Kpad);
+        float *sc = calloc(Npad, sizeof(float));
+        if (!q || !sc || rd_chunkmajor_q16(w, row_scale, N, K, Kpad, Npad, q)) { fprintf(stderr, "rade_core: a GRU / conv / GLU layer of the blob is not int8 x row scale\n"); free(q); free(sc); return -1; }
+        memcpy(sc, row_scale, sizeof(float) * N);
+        L->wq = core_upload(d, q, sizeof(unsigned short) * (size_t)Npad * Kpad);
+        L->scale = core_upload(d, sc, sizeof(float) * Npad);
+        free(q); free(sc);
+        if (!L->wq || !L->scale) return -1;
+    } else {
+        float *f = malloc(sizeof(float) * (size_t)Npad * Kpad);
+        if (!f) return -1;
+        rd_chunkmajor_f32(w, N, K, Kpad, Npad, f);
+        L->wf = core_upload(d, f, sizeof(float) * (size_t)Npad * Kpad);
+        free(f);
+        if (!L->wf) return -1;
+    }
+    if (bias) {
+        float *bp = calloc(Npad, sizeof(float));
+        if (!bp) return -1;
+        memcpy(bp, bias, sizeof(float) * N);
+        L->bias = core_upload(d, bp, sizeof(float) * Npad);
+        free(bp);
+        if (!L->bias) return -1;
+    }
+    return 0;
+}
+
 static void dev_close(core_dev *d)
 {
     if (!d) return;
@@ -143,7 +180,71 @@ static void dev_close(core_dev *d)
     if (d->h_in) hipHostFree(d->h_in);
     if (d->h_out) hipHostFree(d->h_out);
     if (d->gs) hipStreamDestroy(d->gs);
-    rade_batch_close(d->eng); hipFree(d->d_in); hipFree(d->d_out); free(d);
+    for (int i = 0; i < d->n_bufs; i++) hipFree(d->bufs[i]);
+    if (d->eng) rade_batch_close(d->eng);
+    if (d->d_in) hipFree(d->d_in);
+    if (d->d_out) hipFree(d->d_out);
+    free(d);
+}
+
+static core_dev *dev_open(const void *blob, int len, int dim, int enc)
+{
+    core_dev *d = calloc(1, sizeof *d);
+    if (!d) return NULL;
+    const char *dv = getenv("RADE_DEVICE");
+    d->device = dv ? atoi(dv) : 0; d->dim = dim;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "rade_core: no HIP device available -- this library has no CPU fallback\n"); free(d); return NULL; }
+    if (getenv("RADE_CORE_LAYERWISE")) {
+        rade_batch_config cfg = { 1, 1, 0, 0, 0, 0.0f };
+        cfg.device = d->device; d->layerwise = 1;
+        d->eng = rade_batch_open_mem(blob, (size_t)len, &cfg);
+        if (!d->eng || hipMalloc((void **)&d->d_in, sizeof(float) * 96) != hipSuccess || hipMalloc((void **)&d->d_out, sizeof(float) * 96) != hipSuccess) { dev_close(d); return NULL; }
+        if (getenv("RADE_NO_GRAPH") || hipStreamCreate(&d->gs) != hipSuccess || hipHostMalloc((void **)&d->h_in, sizeof(float) * 96, 0) != hipSuccess ||
+            hipHostMalloc((void **)&d->h_out, sizeof(float) * 96, 0) != hipSuccess) { d->graph_off = 1; (void)hipGetLastError(); }
+        return d;
+    }
+    rd_model m;
+    if (hipSetDevice(d->device) != hipSuccess || rd_model_parse(blob, (size_t)len, &m)) { free(d); return NULL; }
+    static const int ENC_DIL_[5] = { 1, 2, 2, 2, 2 };
+    rd_core_args *a = &d->a;
+    int e = 0;
+    a->is_enc = enc;
+    if (enc) {
+        a->n_in = dim; a->n_out = RADE_LATENT_DIM; a->W = 864; a->H = 64; a->in0 = 64; a->conv_out = 96;
+        e |= core_layer(d, &a->dense1, m.enc_dense1.w, m.enc_dense1.b, NULL, 64, m.enc_dense1.n_in, 0);
+        e |= core_layer(d, &a->out, m.enc_zdense.w, m.enc_zdense.b, NULL, 80, 864, 0);
+        for (int l = 0; l < 5 && !e; l++) {
+            a->dil[l] = ENC_DIL_[l];
+            e |= core_layer(d, &a->gin[l], m.enc_gru[l].w_ih, m.enc_gru[l].b_ih, m.enc_gru[l].s_ih, 192, m.enc_gru[l].n_in, 1);
+            e |= core_layer(d, &a->ghh[l], m.enc_gru[l].w_hh, m.enc_gru[l].b_hh, m.enc_gru[l].s_hh, 192, 64, 1);
+            e |= core_layer(d, &a->conv[l], m.enc_conv[l].w, m.enc_conv[l].b, m.enc_conv[l].row_scale, 96, m.enc_conv[l].n_in, 1);
+        }
+    } else {
+        a->n_in = RADE_LATENT_DIM; a->n_out = dim; a->W = 736; a->H = 96; a->in0 = 96; a->conv_out = 32;
+        e |= core_layer(d, &a->dense1, m.dec_dense1.w, m.dec_dense1.b, NULL, 96, 80, 0);
+        e |= core_layer(d, &a->out, m.dec_output.w, m.dec_output.b, NULL, m.dec_output.n_out, 736, 0);
+        for (int l = 0; l < 5 && !e; l++) {
+            a->dil[l] = 1;
+            e |= core_layer(d, &a->gin[l], m.dec_gru[l].w_ih, m.dec_gru[l].b_ih, m.dec_gru[l].s_ih, 288, m.dec_gru[l].n_in, 1);
+            e |= core_layer(d, &a->ghh[l], m.dec_gru[l].w_hh, m.dec_gru[l].b_hh, m.dec_gru[l].s_hh, 288, 96, 1);
+            e |= core_layer(d, &a->glu[l], m.dec_glu[l].w, NULL, m.dec_glu[l].row_scale, 96, 96, 1);
+            e |= core_layer(d, &a->conv[l], m.dec_conv[l].w, m.dec_conv[l].b, m.dec_conv[l].row_scale, 32, m.dec_conv[l].n_in, 1);
+        }
+    }
+    if (!e && (enc ? m.enc_dense1.n_in : m.dec_output.n_out) != dim) e = -1;
+    rd_model_free(&m);
+    a->hist = core_upload(d, NULL, sizeof(float) * 2 * a->W);          /* zero state = rade_init_encoder / rade_init_decoder */
+    a->h = core_upload(d, NULL, sizeof(float) * 5 * a->H);
+    if (e || !a->hist || !a->h || hipStreamCreate(&d->gs) != hipSuccess ||
+        hipHostMalloc((void **)&d->h_in, sizeof(float) * 96, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&d->h_out, sizeof(float) * 128, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&a->in, d->h_in, 0) != hipSuccess || hipHostGetDevicePointer((void **)&a->out_vec, d->h_out, 0) != hipSuccess) {
+        fprintf(stderr, "rade_core: device set-up failed\n"); dev_close(d); return NULL;
+    }
+    memset(d->h_out, 0, sizeof(float) * 128);
+    a->done = (unsigned *)(a->out_vec + 96);
+    return d;
 }
 
 void rade_init_encoder(RADEEncState *s) { memset(s, 0, sizeof *s); }     /* rade_enc.c:39-43: the caller's memory may be uninitialised */
@@ -151,9 +252,43 @@ void rade_init_decoder(RADEDecState *s) { memset(s, 0, sizeof *s); }
 void rade_free_encoder(RADEEncState *s) { if (s && s->initialized) dev_close(s->dev); if (s) memset(s, 0, sizeof *s); }
 void rade_free_decoder(RADEDecState *s) { if (s && s->initialized) dev_close(s->dev); if (s) memset(s, 0, sizeof *s); }
 
-/* one step through the engine: in[n_in] (host) -> out[n_out] (host); enc selects rade_batch_encode / rade_batch_decode */
+/* additive: back to the zero state without releasing the device side (weights stay uploaded) */
+static void core_reset(int *initialized, void **dev)
+{
+    core_dev *d = *initialized ? *dev : NULL;
+    if (!d) return;
+    if (d->layerwise) { dev_close(d); *initialized = 0; *dev = NULL; return; }      /* re-opened by the next step */
+    (void)hipSetDevice(d->device);
+    (void)hipMemsetAsync(d->a.hist, 0, sizeof(float) * 2 * d->a.W, d->gs);
+    (void)hipMemsetAsync(d->a.h, 0, sizeof(float) * 5 * d->a.H, d->gs);
+    (void)hipStreamSynchronize(d->gs);
+}
+void rade_reset_encoder(RADEEncState *s) { if (s) core_reset(&s->initialized, &s->dev); }
+void rade_reset_decoder(RADEDecState *s) { if (s) core_reset(&s->initialized, &s->dev); }
+
+/* one step: in[n_in] (host) -> out[n_out] (host) */
 static int core_step(core_dev *d, int enc, const float *in, int n_in, float *out, int n_out)
 {
+    if (!d->layerwise) {
+        if (hipSetDevice(d->device) != hipSuccess) return -1;
+        memcpy(d->h_in, in, sizeof(float) * n_in);
+        volatile unsigned *done = (volatile unsigned *)(d->h_out + 96);
+        d->a.seq++;
+        if (rd_launch_core_step(&d->a, d->gs)) return -1;
+        /* the kernel writes its completion word into pinned host memory after the output: polling it returns as soon as the result is
+         * there (a stream synchronisation goes through the runtime's interrupt path: ~100 us of wake-up for a 40 us kernel); a kernel
+         * that has not signalled after 20 ms is waited for the ordinary way, which also surfaces device errors */
+        struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0; *done != d->a.seq; spins++) {
+            if ((spins & 1023u) == 1023u) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 20.0) { if (hipStreamSynchronize(d->gs) != hipSuccess || *done != d->a.seq) return -1; break; }
+            }
+        }
+        __sync_synchronize();
+        memcpy(out, d->h_out, sizeof(float) * n_out);
+        return 0;
+    }
     int ok = 0;
     if (d->calls > 0 && !d->graph_off) {
         if (!d->graph) {                                       /* second call: record the sequence (nothing runs during capture) */
@@ -187,7 +322,7 @@ void rade_core_encoder(RADEEncState *s, const RADEEnc *model, float *z, const fl
 {
     (void)arch;
     if (!s->initialized) {                        /* first step after rade_init_encoder(): zero state = a fresh engine */
-        s->dev = dev_open(model->blob, model->blob_len, model->input_dim);
+        s->dev = dev_open(model->blob, model->blob_len, model->input_dim, 1);
         if (!s->dev) die("rade_core_encoder");
         s->initialized = 1;
     }
@@ -200,7 +335,7 @@ void rade_core_decoder(RADEDecState *s, const RADEDec *model, float *features, c
 {
     (void)arch;
     if (!s->initialized) {
-        s->dev = dev_open(model->blob, model->blob_len, model->output_dim);
+        s->dev = dev_open(model->blob, model->blob_len, model->output_dim, 0);
         if (!s->dev) die("rade_core_decoder");
         s->initialized = 1;
     }

@@ -1,0 +1,269 @@
+// rade_core_step.hip -- one 40 ms step of CoreEncoderStatefull / CoreDecoderStatefull for ONE stream as ONE kernel launch
+// (the call granularity of /root/reference/src/rade_enc.c:55-114 and rade_dec.c:50-102; radae_base.py:260-286, :400-416).
+//
+// A single stream is a chain of dependent mat-vec stages with M = 1: there is nothing to batch, so the layer-wise GEMM engine (one
+// launch per layer, rade_engine.c:encode_core) spends its time in launch gaps.  Here one workgroup of 8 wavefronts (256 registers per lane: a whole stage of weight fragments in flight) walks the whole
+// stack in one launch:
+//  * every activation lives in LDS; GRU / conv state persists in HBM between calls; input and output are device-visible host buffers;
+//  * weights stream once per step from L2, CHUNK-MAJOR: W[c][n][8] (chunk c = 8 consecutive k, rows padded to a multiple of 64), the int8
+//    layers of the blob as ONE binary16 plane of the integers q plus a row scale (exact, half the bytes of float32).  Lane = output row,
+//    wavefront w takes chunks w, w + 8, ..: a wave-load is 1 KB contiguous, every byte used, the x chunk is a wave-uniform LDS
+//    broadcast, and no cross-lane reduction exists -- the 8 per-wave partial sums of a row meet in LDS and the row's own thread adds
+//    them in wave order (deterministic), applies scale / bias / activation and writes the activation;
+//  * the chain is latency-bound (one L2 round trip per stage on a GPU whose clocks idle low between single-stream calls), so a stage's
+//    weight loads are ALL issued before the barriers that finish the stage before it: the layer shapes are template parameters, the
+//    fragments of the next stage sit in registers while this stage's partial sums are combined.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "rade_dev.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define CS_THREADS 512
+#define CS_WAVES (CS_THREADS / 64)
+#define CS_PS 320                 // row stride of a partial-sum area: 288 rows padded to 5 x 64
+#define CS_WMAX 864
+
+__device__ __forceinline__ float cs_clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
+__device__ __forceinline__ float cs_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct CsShared {
+    __attribute__((aligned(16))) float x[CS_WMAX];            // the DenseNet concat row of this step
+    __attribute__((aligned(16))) float hist[2][CS_WMAX];      // rows t-1, t-2 (conv taps, dilation 1 or 2)
+    __attribute__((aligned(16))) float vin[96];               // input vector, zero padded to dense1's K
+    __attribute__((aligned(16))) float h[5][96];              // GRU states at entry
+    __attribute__((aligned(16))) float hc[96];                // clamp(h') of the layer at hand (decoder GLU operand)
+    __attribute__((aligned(16))) float gh[288];               // W_hh h + b_hh of the layer at hand
+    __attribute__((aligned(16))) float pa[CS_WAVES][CS_PS];   // per-wave partial sums, product A of a stage
+    __attribute__((aligned(16))) float pb[CS_WAVES][CS_PS];   // product B (the next layer's W_hh h, riding along)
+};
+
+// fragments of one binary16 product: NRB row blocks of 64 x NCI chunks per wavefront
+template <int NRB, int NCI> struct WQ { f16x8 w[NRB][NCI]; };
+template <int NRB, int NCI>
+__device__ __forceinline__ void cs_issue(const rd_mv &L, WQ<NRB, NCI> &r)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = L.K >> 3;
+#pragma unroll
+    for (int i = 0; i < NCI; i++) {
+        const int c = min(wave + CS_WAVES * i, nch - 1);                      // chunks past the end re-read the last one (times zero below)
+#pragma unroll
+        for (int rb = 0; rb < NRB; rb++) r.w[rb][i] = *(const f16x8 *)(L.wq + ((size_t)c * (NRB * 64) + rb * 64 + lane) * 8);
+    }
+}
+// partial sums of this wavefront's chunks into part[wave][row]; v = [v0[0..K0) | v1[..]] in LDS
+template <int NRB, int NCI>
+__device__ __forceinline__ void cs_consume(const rd_mv &L, const WQ<NRB, NCI> &r, const float *v0, int K0, const float *v1, float (*part)[CS_PS])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = L.K >> 3;
+    float acc[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; rb++) acc[rb] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NCI; i++) {
+        const int c = wave + CS_WAVES * i, k = 8 * min(c, nch - 1);
+        const float *src = k < K0 ? v0 + k : v1 + (k - K0);
+        f32x4 a = *(const f32x4 *)src, b = *(const f32x4 *)(src + 4);        // wave-uniform address: an LDS broadcast
+        if (c >= nch) { a = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; b = a; }
+#pragma unroll
+        for (int rb = 0; rb < NRB; rb++) {
+            float s0 = acc[rb], s1 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                s0 = fmaf((float)r.w[rb][i][j], a[j], s0); s1 = fmaf((float)r.w[rb][i][j + 1], a[j + 1], s1);
+                s0 = fmaf((float)r.w[rb][i][4 + j], b[j], s0); s1 = fmaf((float)r.w[rb][i][4 + j + 1], b[j + 1], s1);
+            }
+            acc[rb] = s0 + s1;
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < NRB; rb++) part[wave][rb * 64 + lane] = acc[rb];
+}
+// row n of a product: the per-wave partials in wave order, times the row scale, plus bias
+__device__ __forceinline__ float cs_row(const rd_mv &L, const float (*part)[CS_PS], int n)
+{
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < CS_WAVES; w++) s += part[w][n];
+    return s * (L.scale ? L.scale[n] : 1.0f) + (L.bias ? L.bias[n] : 0.0f);
+}
+
+// float32 layers (dense1, the output layer: raw features / received symbols are unbounded, and the blob holds these as floats): the same
+// chunk-major scheme with two 16-byte loads per chunk, one row block at a time
+template <int NCI>
+__device__ __forceinline__ void cs_f32_product(const rd_mv &L, int nrb, const float *v, float (*part)[CS_PS])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nch = L.K >> 3;
+    for (int rb = 0; rb < nrb; rb++) {
+        f32x4 w[NCI][2];
+#pragma unroll
+        for (int i = 0; i < NCI; i++) {
+            const int c = min(wave + CS_WAVES * i, nch - 1);
+            const float *p = L.wf + ((size_t)c * (nrb * 64) + rb * 64 + lane) * 8;
+            w[i][0] = *(const f32x4 *)p; w[i][1] = *(const f32x4 *)(p + 4);
+        }
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCI; i++) {
+            const int c = wave + CS_WAVES * i, k = 8 * min(c, nch - 1);
+            f32x4 a = *(const f32x4 *)(v + k), b = *(const f32x4 *)(v + k + 4);
+            if (c >= nch) { a = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; b = a; }
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                s0 = fmaf(w[i][0][j], a[j], s0); s1 = fmaf(w[i][0][j + 1], a[j + 1], s1);
+                s0 = fmaf(w[i][1][j], b[j], s0); s1 = fmaf(w[i][1][j + 1], b[j + 1], s1);
+            }
+        }
+        part[wave][rb * 64 + lane] = s0 + s1;
+    }
+}
+
+// GRU gates of hidden unit j (torch order r, z, n; radae_base.py:97-108) from the input projection's partial sums and gh
+__device__ __forceinline__ float cs_gru_unit(const rd_mv &G, const float (*part)[CS_PS], const float *gh, float hj, int H, int j)
+{
+    const float gr = cs_row(G, part, j), gz = cs_row(G, part, H + j), gn = cs_row(G, part, 2 * H + j);
+    const float r = cs_sigmoid(gh[j] + gr);
+    const float z = cs_sigmoid(gh[H + j] + gz);
+    const float nn = tanhf(gn + gh[2 * H + j] * r);
+    return (hj - nn) * z + nn;
+}
+
+#define CS_SYNC() __syncthreads()
+
+// ---- encoder: dense1 | 5 x (GRU 64, conv 96, dilation 1,2,2,2,2) | z_dense ---------------------------------------------------
+// one layer; the fragments of its input projection (gq) were issued by the stage before, the next layer's (gnext) are issued here
+template <int GCI, int CCI, int GNEXT, bool LAST>
+__device__ __forceinline__ void cs_enc_layer(CsShared *sh, const rd_core_args &a, int l, int n, WQ<3, GCI> &gq, WQ<3, GNEXT> &gnext)
+{
+    const int tid = threadIdx.x, H = 64;
+    WQ<2, CCI> cq; WQ<3, 1> hq;
+    cs_consume<3, GCI>(a.gin[l], gq, sh->x, n, sh->x, sh->pa);
+    cs_issue<2, CCI>(a.conv[l], cq);                               // this layer's conv and the next layer's W_hh h: in flight across the gate stage
+    if (!LAST) cs_issue<3, 1>(a.ghh[l + 1], hq);
+    CS_SYNC();
+    if (tid < H) {
+        const float hn = cs_gru_unit(a.gin[l], sh->pa, sh->gh, sh->h[l][tid], H, tid);
+        a.h[l * H + tid] = hn;
+        sh->x[n + tid] = cs_clamp1(hn);
+    }
+    CS_SYNC();
+    const int cin = n + H;
+    cs_consume<2, CCI>(a.conv[l], cq, sh->hist[a.dil[l] - 1], cin, sh->x, sh->pa);
+    if (!LAST) { cs_consume<3, 1>(a.ghh[l + 1], hq, sh->h[l + 1], H, sh->h[l + 1], sh->pb); cs_issue<3, GNEXT>(a.gin[l + 1], gnext); }
+    CS_SYNC();
+    if (tid < 96) sh->x[cin + tid] = cs_clamp1(tanhf(cs_row(a.conv[l], sh->pa, tid)));       // Conv1d k=2 + tanh (radae_base.py:110-134)
+    else if (!LAST && tid >= 128 && tid < 128 + 3 * H) sh->gh[tid - 128] = cs_row(a.ghh[l + 1], sh->pb, tid - 128);
+    CS_SYNC();
+}
+
+__global__ __launch_bounds__(CS_THREADS) void k_core_enc_step(rd_core_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
+    CsShared *sh = (CsShared *)cs_raw;
+    const int tid = threadIdx.x, W = 864, H = 64;
+    WQ<3, 1> g0, h0;
+    cs_issue<3, 1>(a.gin[0], g0); cs_issue<3, 1>(a.ghh[0], h0);
+    for (int i = tid; i < 2 * W; i += CS_THREADS) sh->hist[i / W][i % W] = a.hist[i];
+    if (tid < 96) sh->vin[tid] = tid < a.n_in ? a.in[tid] : 0.0f;
+    if (tid < 5 * H) sh->h[tid / H][tid % H] = a.h[tid];
+    CS_SYNC();
+    cs_f32_product<2>(a.dense1, 1, sh->vin, sh->pa);                // dense1 + tanh (radae_base.py:263)
+    cs_consume<3, 1>(a.ghh[0], h0, sh->h[0], H, sh->h[0], sh->pb);
+    CS_SYNC();
+    if (tid < 64) sh->x[tid] = cs_clamp1(tanhf(cs_row(a.dense1, sh->pa, tid)));
+    else if (tid >= 128 && tid < 128 + 3 * H) sh->gh[tid - 128] = cs_row(a.ghh[0], sh->pb, tid - 128);
+    CS_SYNC();
+    WQ<3, 4> g1; WQ<3, 6> g2; WQ<3, 9> g3; WQ<3, 11> g4;
+    cs_enc_layer<1, 4, 4, false>(sh, a, 0, 64, g0, g1);
+    cs_enc_layer<4, 9, 6, false>(sh, a, 1, 224, g1, g2);
+    cs_enc_layer<6, 14, 9, false>(sh, a, 2, 384, g2, g3);
+    cs_enc_layer<9, 19, 11, false>(sh, a, 3, 544, g3, g4);
+    cs_enc_layer<11, 24, 11, true>(sh, a, 4, 704, g4, g4);
+    cs_f32_product<14>(a.out, 2, sh->x, sh->pa);                    // z_dense, linear (bottleneck 3; the tanh of bottleneck 1 is the caller's)
+    for (int i = tid; i < W; i += CS_THREADS) { a.hist[W + i] = sh->hist[0][i]; a.hist[i] = sh->x[i]; }      // history of the next step
+    CS_SYNC();
+    if (tid < a.n_out) { a.out_vec[tid] = cs_row(a.out, sh->pa, tid); __threadfence_system(); }
+    CS_SYNC();
+    // completion word in the caller's (pinned host) memory: the host polls it instead of going through a stream synchronisation,
+    // whose interrupt / wake-up path costs more than this whole kernel
+    if (tid == 0 && a.done) { __threadfence_system(); *(volatile unsigned *)a.done = a.seq; }
+}
+
+// ---- decoder: dense1 | 5 x (GRU 96, GLU 96, conv 32) | output ---------------------------------------------------------------------
+template <int GCI, int CCI, int GNEXT, bool LAST>
+__device__ __forceinline__ void cs_dec_layer(CsShared *sh, const rd_core_args &a, int l, int n, WQ<5, GCI> &gq, WQ<5, GNEXT> &gnext)
+{
+    const int tid = threadIdx.x, H = 96;
+    WQ<2, 2> uq; WQ<1, CCI> cq; WQ<5, 2> hq;
+    cs_consume<5, GCI>(a.gin[l], gq, sh->x, n, sh->x, sh->pa);
+    cs_issue<2, 2>(a.glu[l], uq); cs_issue<1, CCI>(a.conv[l], cq);
+    CS_SYNC();
+    if (tid < H) {
+        const float hn = cs_gru_unit(a.gin[l], sh->pa, sh->gh, sh->h[l][tid], H, tid);
+        a.h[l * H + tid] = hn;
+        sh->hc[tid] = cs_clamp1(hn);
+    }
+    CS_SYNC();
+    cs_consume<2, 2>(a.glu[l], uq, sh->hc, H, sh->hc, sh->pa);      // GLU: x * sigmoid(W x), no bias (radae_base.py:149-153)
+    if (!LAST) cs_issue<5, 2>(a.ghh[l + 1], hq);
+    CS_SYNC();
+    if (tid < H) sh->x[n + tid] = cs_clamp1(sh->hc[tid] * cs_sigmoid(cs_row(a.glu[l], sh->pa, tid)));
+    CS_SYNC();
+    const int cin = n + H;
+    cs_consume<1, CCI>(a.conv[l], cq, sh->hist[0], cin, sh->x, sh->pa);
+    if (!LAST) { cs_consume<5, 2>(a.ghh[l + 1], hq, sh->h[l + 1], H, sh->h[l + 1], sh->pb); cs_issue<5, GNEXT>(a.gin[l + 1], gnext); }
+    CS_SYNC();
+    if (tid < 32) sh->x[cin + tid] = cs_clamp1(tanhf(cs_row(a.conv[l], sh->pa, tid)));
+    else if (!LAST && tid >= 64 && tid < 64 + 3 * H) sh->gh[tid - 64] = cs_row(a.ghh[l + 1], sh->pb, tid - 64);
+    CS_SYNC();
+}
+
+__global__ __launch_bounds__(CS_THREADS) void k_core_dec_step(rd_core_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
+    CsShared *sh = (CsShared *)cs_raw;
+    const int tid = threadIdx.x, W = 736, H = 96;
+    WQ<5, 2> g0, h0;
+    cs_issue<5, 2>(a.gin[0], g0); cs_issue<5, 2>(a.ghh[0], h0);
+    for (int i = tid; i < W; i += CS_THREADS) sh->hist[0][i] = a.hist[i];
+    if (tid < 96) sh->vin[tid] = tid < a.n_in ? a.in[tid] : 0.0f;
+    if (tid < 5 * H) sh->h[tid / H][tid % H] = a.h[tid];
+    CS_SYNC();
+    cs_f32_product<2>(a.dense1, 2, sh->vin, sh->pa);                // dense1 + tanh (radae_base.py:403)
+    cs_consume<5, 2>(a.ghh[0], h0, sh->h[0], H, sh->h[0], sh->pb);
+    CS_SYNC();
+    if (tid < 96) sh->x[tid] = cs_clamp1(tanhf(cs_row(a.dense1, sh->pa, tid)));
+    else if (tid >= 128 && tid < 128 + 3 * H) sh->gh[tid - 128] = cs_row(a.ghh[0], sh->pb, tid - 128);
+    CS_SYNC();
+    WQ<5, 4> g1; WQ<5, 6> g2; WQ<5, 8> g3; WQ<5, 10> g4;
+    cs_dec_layer<2, 6, 4, false>(sh, a, 0, 96, g0, g1);
+    cs_dec_layer<4, 10, 6, false>(sh, a, 1, 224, g1, g2);
+    cs_dec_layer<6, 14, 8, false>(sh, a, 2, 352, g2, g3);
+    cs_dec_layer<8, 18, 10, false>(sh, a, 3, 480, g3, g4);
+    cs_dec_layer<10, 22, 10, true>(sh, a, 4, 608, g4, g4);
+    cs_f32_product<12>(a.out, 2, sh->x, sh->pa);                    // output layer, linear
+    for (int i = tid; i < W; i += CS_THREADS) a.hist[i] = sh->x[i];
+    CS_SYNC();
+    if (tid < a.n_out) { a.out_vec[tid] = cs_row(a.out, sh->pa, tid); __threadfence_system(); }
+    CS_SYNC();
+    // completion word in the caller's (pinned host) memory: the host polls it instead of going through a stream synchronisation,
+    // whose interrupt / wake-up path costs more than this whole kernel
+    if (tid == 0 && a.done) { __threadfence_system(); *(volatile unsigned *)a.done = a.seq; }
+}
+
+extern "C" int rd_launch_core_step(const rd_core_args *a, rd_stream_t s)
+{
+    static int attr_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    if (!attr_dev[dev_ & 63]) {
+        (void)hipFuncSetAttribute((const void *)k_core_enc_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsShared));
+        (void)hipFuncSetAttribute((const void *)k_core_dec_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsShared));
+        attr_dev[dev_ & 63] = 1;
+    }
+    if (a->is_enc) hipLaunchKernelGGL(k_core_enc_step, dim3(1), dim3(CS_THREADS), sizeof(CsShared), (hipStream_t)s, *a);
+    else hipLaunchKernelGGL(k_core_dec_step, dim3(1), dim3(CS_THREADS), sizeof(CsShared), (hipStream_t)s, *a);
+    return (int)hipGetLastError();
+}

@@ -190,6 +190,22 @@ int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
 
 int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
 
+/* ---- one core encoder / decoder step of ONE stream as one launch (rade_core_step.hip; include/rade_core.h) ----
+ * A layer = row-major W[N][K] (K a multiple of 8, zero padded): wq != NULL: ONE binary16 plane of the integers q of an int8 layer
+ * (w = q * scale[n], exact); else float32 wf (scale NULL). */
+typedef struct { const unsigned short *wq; const float *wf; const float *scale; const float *bias; int N, K; } rd_mv;
+typedef struct {
+    rd_mv dense1, gin[5], ghh[5], glu[5], conv[5], out;
+    int is_enc, n_in, n_out;           /* floats in / out per step (80 or 84 features, 80 latents) */
+    int W, H, in0, conv_out;           /* concat width 864 / 736, GRU width 64 / 96, dense1 outputs 64 / 96, conv outputs 96 / 32 */
+    int dil[5];                        /* conv dilation (1 or 2): tap 0 reads row t - dil */
+    float *hist;                       /* [2][W]: concat rows t-1, t-2 of the previous steps */
+    float *h;                          /* [5][H] GRU states */
+    const float *in; float *out_vec;   /* device-visible buffers (pinned host memory in rade_core.c) */
+    unsigned *done; unsigned seq;      /* optional completion word (device-visible host memory): set to seq after out_vec is written */
+} rd_core_args;
+int rd_launch_core_step(const rd_core_args *a, rd_stream_t s);
+
 
 #ifdef __cplusplus
 }

@@ -390,6 +390,29 @@ static int q_of(float w, float sc, float *q)
     *q = rintf(w / sc);
     return (fabsf(*q) <= 127.0f && *q * sc == w) ? 0 : -1;
 }
+/* chunk-major binary16 plane of the integers q of an int8 layer (w = q * row_scale[n] exactly) for the single-stream step kernel
+ * (rade_core_step.hip): out[(c * Npad + n) * 8 + j] = q(W[n][8 c + j]), K zero-padded to Kpad (a multiple of 8), rows to Npad (a
+ * multiple of 64).  Returns 0, or -1 when the layer is not int8-exact. */
+int rd_chunkmajor_q16(const float *W, const float *row_scale, int N, int K, int Kpad, int Npad, unsigned short *out)
+{
+    if (!row_scale) return -1;
+    for (int c = 0; c < Kpad / 8; c++)
+        for (int n = 0; n < Npad; n++)
+            for (int j = 0; j < 8; j++) {
+                const int k = 8 * c + j;
+                float q = 0.0f;
+                if (n < N && k < K && q_of(W[(size_t)n * K + k], row_scale[n], &q)) return -1;
+                out[((size_t)c * Npad + n) * 8 + j] = f32_to_f16(q);
+            }
+    return 0;
+}
+void rd_chunkmajor_f32(const float *W, int N, int K, int Kpad, int Npad, float *out)
+{
+    for (int c = 0; c < Kpad / 8; c++)
+        for (int n = 0; n < Npad; n++)
+            for (int j = 0; j < 8; j++) { const int k = 8 * c + j; out[((size_t)c * Npad + n) * 8 + j] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.0f; }
+}
+
 long rd_pack_weights_q16(const float *W, const float *row_scale, int N, int K, unsigned short *out, float *scale_out)
 {
     const int nkb = K / 16, ntt = (N + 31) / 32;

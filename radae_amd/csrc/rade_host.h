@@ -34,6 +34,8 @@ long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out);
 /* int8-exact layers for k_gemm16: ONE plane of integers in the B-operand order of v_mfma_f32_32x32x16_f16, out[K/16][ceil(N/32)][64][8];
  * scale_out[32 ceil(N/32)].  Returns the size in halfs or -1 when W is not q * row_scale with integer |q| <= 127. */
 long rd_pack_weights_q16(const float *W, const float *row_scale, int N, int K, unsigned short *out, float *scale_out);
+int rd_chunkmajor_q16(const float *W, const float *row_scale, int N, int K, int Kpad, int Npad, unsigned short *out);
+void rd_chunkmajor_f32(const float *W, int N, int K, int Kpad, int Npad, float *out);
 long rd_packed16a_size(int N, int K);
 /* int8-exact layers: ONE binary16 plane holding the integers q (exact), out[K/32][ceil(N/16)][64][8]; scale_out[16 ceil(N/16)] = row scale (0 past N).
  * Returns the plane's size in halfs, or -1 when W is not q * row_scale with integer |q| <= 127. */

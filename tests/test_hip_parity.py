@@ -789,6 +789,61 @@ def test_bbfm_config5(Engine, torch_dev, golden):
     eng.close()
 
 
+@pytest.mark.parametrize("blobname,mode", [("model05.bin", "rs"), ("bbfm_random_seed20240501.bin", "bbfm")])
+def test_configs_1_and_5_at_batch_256_split_f16_gemm(Engine, torch_dev, oracle, blobname, mode):
+    """BASELINE configs 1 and 5 at their stated batch (256 streams): with more than 16 k GEMM rows the 80-wide-input blobs run the
+    split-binary16 matrix-core kernels (k_gemm16p / k_gemm16), not the f32 kernels their B = 1 parity tests above select.  Three
+    streams each against the oracle's CoreEncoder / CoreDecoder on the same rows (z within 2e-5 of full scale, features within
+    1e-4 RMS), including a stream whose raw features / received symbols are far outside +-1 (dense1's operands are unbounded)."""
+    import os
+    import torch
+    from radae_amd.engine import DEFAULT_BLOB
+    blob = os.path.join(os.path.dirname(DEFAULT_BLOB), blobname)
+    B, T = 256, 72                                            # 18,432 rows per GEMM
+    assert B * T > 16384
+    rng = np.random.default_rng(20240929)
+    x = np.zeros((B, T, 4, 20), np.float32)                   # AR(1) "speech-like" features, frame by frame
+    v = np.zeros((B, 20), np.float32)
+    for t in range(4 * T):
+        v = np.float32(0.9) * v + np.float32(0.436) * rng.standard_normal((B, 20)).astype(np.float32)
+        x[:, t // 4, t % 4] = v
+    x[..., 0] *= 4.0
+    x[100] *= np.float32(120.0)                               # one stream far past +-256
+    feats = x.reshape(B, T, 80)
+    eng = Engine(B, max_tx_mf=T // 3, blob=blob, flags=0x100)      # RADE_BATCH_BOTTLENECK1
+    z = eng.encode(torch.tensor(feats, device=torch_dev)).cpu().numpy()
+    assert np.isfinite(z).all()
+    m = oracle.Model(blob)
+    picks = (0, 100, 255)
+    for b in picks:
+        enc = oracle.Encoder(m)
+        zr = np.stack([enc.step(r, bottleneck=1) for r in feats[b]])
+        # tanh bottleneck: full scale 1, bar 1e-5 RMS.  Peak bar: these blobs' z_dense sums reach tens before the tanh (most latents sit
+        # at +-1), where the 22-bit operand planes' 2^-22 relative error is 2..4e-5 on single values (measured 2.2e-5 on an ordinary
+        # stream, 3.8e-5 on the x120 stream that drives every layer into saturation): 5e-5 / 1e-4
+        assert np.abs(z[b] - zr).max() < (1e-4 if b == 100 else 5e-5) and rms(z[b], zr) < 1e-5, (blobname, b, float(np.abs(z[b] - zr).max()))
+    # channel on the device (explicit noise => comparable), then the stand-alone decoder on what came out of it
+    noise = rng.standard_normal((B, T * 80)).astype(np.float32)
+    zt = torch.tensor(z, device=torch_dev)
+    if mode == "rs":
+        sigma = 10 ** (-6.0 / 20)
+        zh = eng.channel_symbol(zt, "rs", sigma, noise=torch.tensor(noise, device=torch_dev)).cpu().numpy()
+        for b in picks:
+            assert np.abs(zh[b].ravel() - oracle.channel_rs(z[b].ravel(), None, noise[b], sigma)).max() < 1e-6
+        zh[100, 5::7] *= np.float32(1e3)                          # a deep fade / false sync: symbols divided by a tiny pilot magnitude
+    else:
+        zh = eng.channel_symbol(zt, "bbfm", 14.0, 13.47, noise=torch.tensor(noise, device=torch_dev)).cpu().numpy()
+        for b in picks:
+            assert np.abs(zh[b].ravel() - oracle.channel_bbfm(z[b].ravel(), None, noise[b], 14.0, 13.47)).max() < 5e-6
+    fh = eng.decode(torch.tensor(zh, device=torch_dev), 80).cpu().numpy()
+    assert np.isfinite(fh).all()
+    for b in picks:
+        dec = oracle.Decoder(m)
+        ref = np.stack([dec.step(r) for r in zh[b]])
+        assert rms(fh[b], ref) < 1e-4, (blobname, b)
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # single-carrier modem for BBFM symbols (SURVEY.md 8f-5; reference radae/dsp.py:579-860)
 # ---------------------------------------------------------------------------------------------------------------------
