@@ -57,6 +57,8 @@ struct rade_batch {
     int prof_on, prof_cnt; hipEvent_t prof_ev[2 * RADE_PROF_MAXEV]; int prof_cls[RADE_PROF_MAXEV]; double prof_fl[RADE_PROF_MAXEV];
     double prof_ms[RADE_PROF_NCLASS], prof_flops[RADE_PROF_NCLASS]; long prof_n[RADE_PROF_NCLASS];
     long rx_calls_search, rx_calls_sync;
+    /* encoder in two time chunks on two HIP streams (encode_core): the side stream and the events that order the chunks */
+    int enc_chunks; hipStream_t enc_side; hipEvent_t ev_fork, ev_join, ev_scan[5];
 };
 
 static const int ENC_IN[5] = { 64, 224, 384, 544, 704 };    /* GRU input widths (radae_base.py:240-248) */
@@ -263,6 +265,13 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->d_lcg_seeds = dev_upload(h->lcg_seeds, sizeof(unsigned) * B);
     if (!h->d_lcg_seeds) goto fail;
     for (int i = 0; i < 2 * RADE_PROF_MAXEV; i++) CHK(hipEventCreate(&h->prof_ev[i]));
+    h->enc_chunks = getenv("RADE_ENC_CHUNKS") ? atoi(getenv("RADE_ENC_CHUNKS")) : 1;     /* measured (profiles/r03_tx_side_ab.json): 2 chunks gain 3 % with one batch in flight, lose 7 % with two (the default) */
+    if (h->enc_chunks != 1) {
+        h->enc_chunks = 2;
+        CHK(hipStreamCreateWithFlags(&h->enc_side, hipStreamNonBlocking));
+        CHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        for (int l = 0; l < 5; l++) CHK(hipEventCreateWithFlags(&h->ev_scan[l], hipEventDisableTiming));
+    }
     rade_batch_rx_reset(h);
     if (rd_launch_eoo_build(h->d_tab, NULL, h->eoo, h->B, NULL)) goto fail;
     CHK(hipDeviceSynchronize());
@@ -302,6 +311,10 @@ void rade_batch_close(rade_batch *h)
         for (int i = 0; i < 7; i++) if (p[i]) hipFree(p[i]);
     }
     if (h->h_small) hipHostFree(h->h_small);
+    if (h->enc_side) hipStreamDestroy(h->enc_side);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    for (int l = 0; l < 5; l++) if (h->ev_scan[l]) hipEventDestroy(h->ev_scan[l]);
     for (int i = 0; i < 2 * RADE_PROF_MAXEV; i++) if (h->prof_ev[i]) hipEventDestroy(h->prof_ev[i]);
     free(h->lcg_seeds);
     free(h);
@@ -357,27 +370,47 @@ static int gemm(rade_batch *hh, const dev_lin *w, const float *a1, long a1_sb, l
     return rc;
 }
 
-/* ---- CoreEncoderStatefull.forward over T steps for all streams (radae_base.py:260-286); xin = [B][T][enc_kpad] ---- */
+/* ---- CoreEncoderStatefull.forward over T steps for all streams (radae_base.py:260-286); xin = [B][T][enc_kpad] ----
+ * Layer by layer over all B x T rows: the feed-forward pieces are GEMMs, the five W_hh recurrences serial scans (one workgroup of four
+ * wavefronts per stream: latency-bound, most of the chip idle).  With enough rows the T steps are cut into two time chunks that run
+ * the same layer sequence on two HIP streams, the second chunk one recurrence behind the first (it needs that layer's GRU state and
+ * the conv history rows the first chunk leaves): chunk 0's GEMMs of layer l+1 then fill the chip while chunk 1's scan of layer l
+ * waits on its serial chain, and vice versa.  No extra passes, same kernels, same arithmetic per row: results are bit-identical to
+ * the one-chunk order ($RADE_ENC_CHUNKS=1). */
 static int encode_core(rade_batch *h, int T, float *z, void *stream)
 {
     const int B = h->B, W = RD_ENC_W;
     const long xsb = (long)(2 + h->Tcap) * W;
-    float *x = h->enc_x + 2 * W;               /* time row 0 of each stream; rows -2,-1 hold the conv history */
+    float *x0 = h->enc_x + 2 * W;              /* time row 0 of each stream; rows -2,-1 hold the conv history */
+    hipStream_t S[2] = { (hipStream_t)stream, h->enc_side };
+    /* small jobs (single-stream ABI, tests with a handful of rows) stay on one stream: nothing to overlap, and rade_tx() captures its
+     * launches into a hipGraph on the caller's stream */
+    const int nC = (h->enc_chunks == 2 && (long)B * T > 16384 && T >= 16) ? 2 : 1;
+    const int tsplit = nC == 2 ? ((T / 2 + 3) & ~3) : T;
+    const int t0[2] = { 0, tsplit }, tn[2] = { tsplit, T - tsplit };
     int e = 0;
+    if (nC == 2) { if (hipEventRecord(h->ev_fork, S[0]) != hipSuccess || hipStreamWaitEvent(S[1], h->ev_fork, 0) != hipSuccess) return -1; }
     /* dense1 reads raw features: the one encoder operand that is not tanh-bounded, so it stays on the f32 matrix cores
      * (the 2^8-scaled binary16 planes of the split-f16 kernels overflow beyond +-255.9) */
     dev_lin d1 = h->enc_dense1; d1.wp16 = NULL; d1.wscale16 = NULL;
-    e |= gemm(h, &d1, h->enc_xin, (long)T * h->enc_kpad, h->enc_kpad, h->enc_kpad, NULL, 0, 0, 0, NULL, NULL, x, xsb, W, B, T, 1, stream);
+    for (int c = 0; c < nC; c++)
+        e |= gemm(h, &d1, h->enc_xin + (long)t0[c] * h->enc_kpad, (long)T * h->enc_kpad, h->enc_kpad, h->enc_kpad, NULL, 0, 0, 0, NULL, NULL, x0 + (long)t0[c] * W, xsb, W, B, tn[c], 1, S[c]);
     for (int l = 0; l < 5 && !e; l++) {
-        const int in = ENC_IN[l];
-        e |= gemm(h, &h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, h->enc_gi, (long)T * 192, 192, B, T, 0, stream);
-        rd_scan_args s = { h->enc_gi, (long)T * 192, 192, h->enc_whh[l], h->enc_bhh[l], h->enc_h[l], x + in, xsb, W, NULL, 0, NULL, B, T, 64 };
-        PROF_BEGIN(h, stream); e |= rd_launch_gru_scan(&s, stream); PROF_END(h, stream, RADE_PROF_SCAN, 2.0 * B * T * 192 * 64);
-        const int cin = in + 64;
-        e |= gemm(h, &h->enc_conv[l], x, xsb, W, cin, x - (long)ENC_DIL[l] * W, xsb, W, cin, NULL, NULL, x + cin, xsb, W, B, T, 1, stream);
+        const int in = ENC_IN[l], cin = in + 64;
+        for (int c = 0; c < nC && !e; c++) {
+            float *x = x0 + (long)t0[c] * W, *gi = h->enc_gi + (long)t0[c] * 192;
+            e |= gemm(h, &h->enc_gin[l], x, xsb, W, in, NULL, 0, 0, 0, NULL, NULL, gi, (long)T * 192, 192, B, tn[c], 0, S[c]);
+            if (c == 1 && hipStreamWaitEvent(S[1], h->ev_scan[l], 0) != hipSuccess) return -1;      /* GRU state + history rows of chunk 0 */
+            rd_scan_args s = { gi, (long)T * 192, 192, h->enc_whh[l], h->enc_bhh[l], h->enc_h[l], x + in, xsb, W, NULL, 0, NULL, B, tn[c], 64 };
+            PROF_BEGIN(h, S[c]); e |= rd_launch_gru_scan(&s, S[c]); PROF_END(h, S[c], RADE_PROF_SCAN, 2.0 * B * tn[c] * 192 * 64);
+            if (c == 0 && nC == 2 && hipEventRecord(h->ev_scan[l], S[0]) != hipSuccess) return -1;
+            e |= gemm(h, &h->enc_conv[l], x, xsb, W, cin, x - (long)ENC_DIL[l] * W, xsb, W, cin, NULL, NULL, x + cin, xsb, W, B, tn[c], 1, S[c]);
+        }
     }
     /* bottleneck 1: z = tanh(z_dense) (radae_base.py:281-284); bottleneck 3: linear */
-    e |= gemm(h, &h->enc_zdense, x, xsb, W, 864, NULL, 0, 0, 0, NULL, NULL, z, (long)T * RD_LATENT, RD_LATENT, B, T, h->bottleneck1 ? 1 : 0, stream);
+    for (int c = 0; c < nC; c++)
+        e |= gemm(h, &h->enc_zdense, x0 + (long)t0[c] * W, xsb, W, 864, NULL, 0, 0, 0, NULL, NULL, z + (long)t0[c] * RD_LATENT, (long)T * RD_LATENT, RD_LATENT, B, tn[c], h->bottleneck1 ? 1 : 0, S[c]);
+    if (nC == 2) { if (hipEventRecord(h->ev_join, S[1]) != hipSuccess || hipStreamWaitEvent(S[0], h->ev_join, 0) != hipSuccess) return -1; }
     e |= rd_launch_carry_rows(h->enc_x, B, h->Tcap, W, 2, T, NULL, stream);
     return e;
 }
