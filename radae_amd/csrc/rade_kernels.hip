@@ -2606,9 +2606,20 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
     }
 }
 
+#include "rade_rx2.inc"
+
 extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
 {
     if (a->B <= 0) return 0;
+    if (a->variant == 2) {
+        static int attr2_set_dev[64];
+        int d2 = 0; (void)hipGetDevice(&d2);
+        if (!attr2_set_dev[d2 & 63]) { (void)hipFuncSetAttribute((const void *)k_rx_sync2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared2)); attr2_set_dev[d2 & 63] = 1; }
+        static int lds2 = -1;                        // developer switch: RADE_RX2_SOLO=1 asks for more than half the LDS, i.e. one workgroup per CU
+        if (lds2 < 0) { lds2 = getenv("RADE_RX2_SOLO") ? 100 * 1024 : (int)sizeof(RxShared2); (void)hipFuncSetAttribute((const void *)k_rx_sync2, hipFuncAttributeMaxDynamicSharedMemorySize, lds2); }
+        hipLaunchKernelGGL(k_rx_sync2, dim3(a->B), dim3(NT2), lds2, (hipStream_t)s, *a);
+        return (int)hipGetLastError();
+    }
     static int attr_set_dev[64];                     // the attribute is per device (one engine per GPU in a multi-GPU host process)
     int dev_ = 0; (void)hipGetDevice(&dev_);
     if (!attr_set_dev[dev_ & 63]) { (void)hipFuncSetAttribute((const void *)k_rx_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared)); attr_set_dev[dev_ & 63] = 1; }

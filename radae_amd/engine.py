@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradehip.so")
+LIB_PATH = os.environ.get("RADE_LIBRADEHIP") or os.path.join(_HERE, "libradehip.so")      # the override is a developer aid (A/B builds, tools/ab_build.sh)
 DEFAULT_BLOB = os.path.join(os.path.dirname(_HERE), "weights", "model19_check3.bin")
 
 NMF, NEOO, NIN_MAX, FEAT_MF, NEOO_BITS, ZMF = 960, 1152, 1120, 432, 180, 240
