@@ -32,6 +32,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // two IEEE fused multiply-adds per lane in one instruction (v_pk_fma_f32: the full-rate f32 path of the vector ALU)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define PI_D 3.14159265358979323846
 
@@ -123,7 +124,7 @@ __device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn
 __device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
 __device__ __forceinline__ float2 ld2(const float (*p)[2], int i) { return make_float2(p[i][0], p[i][1]); }
 
-#ifdef RD_PHASE_TIMING   // developer aid: per-phase shader-clock totals of workgroup 0 (make EXTRA=-DRD_PHASE_TIMING)
+#if defined(RD_PHASE_TIMING) && !defined(RADE_RX2_TU)
 __device__ long long g_phase_cycles[32];
 #define PH_T0() long long ph_t_ = clock64()
 #define PH(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); atomicAdd((unsigned long long *)&g_phase_cycles[i], (unsigned long long)(n_ - ph_t_)); ph_t_ = n_; } } while (0)
@@ -133,6 +134,7 @@ extern "C" void rd_debug_phase_cycles(long long *out) { hipMemcpyFromSymbol(out,
 #define PH(i) do { } while (0)
 #endif
 
+#ifndef RADE_RX2_TU   // rade_rx2.hip includes this file for its device helpers only: kernels and launch shims stay in this translation unit
 __device__ float g_zero_row[2048];   // tap-0 source of a conv row whose decoder state was just reset
 
 // =====================================================================================================
@@ -219,7 +221,6 @@ __global__ __launch_bounds__(64) void k_gemm(rd_gemm_args a)
 
 // The same GEMM on the f16 matrix cores, operands split in two binary16 planes (see ds_gemm16 below for the
 // arithmetic): activations are split on the fly, W comes from rd_pack_weights_f16x2.  K segments are multiples of 16.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int NT, int RT>
 __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
 {   // one wavefront = RT row tiles of 32 rows x NT column tiles: every W fragment is applied to RT row tiles, so the L2 traffic
@@ -627,6 +628,7 @@ extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
     return (int)hipGetLastError();
 }
 
+#endif  // !RADE_RX2_TU
 // =====================================================================================================
 // Per-stream decoder stage of the receiver kernel: the whole DenseNet stack for one stream's pending rows, run by the
 // stream's own workgroup of eight wavefronts with every activation RESIDENT IN LDS.  Only the weights stream in (from L2);
@@ -999,6 +1001,7 @@ __device__ void dq_layers(DecShared *sh, const rd_decs_args &a, int b, const flo
     __syncthreads();
 }
 
+#ifndef RADE_RX2_TU
 // =====================================================================================================
 // small data-movement kernels
 // =====================================================================================================
@@ -1352,6 +1355,7 @@ extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
     return (int)hipGetLastError();
 }
 
+#endif  // !RADE_RX2_TU
 // =====================================================================================================
 // receiver: one workgroup (512 threads) per stream, up to round_calls do_radae_rx calls per launch
 // =====================================================================================================
@@ -2027,6 +2031,7 @@ __device__ __forceinline__ void check_rows_tiles(RxShared *sh, const unsigned sh
         }
 }
 
+#ifndef RADE_RX2_TU
 __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2606,20 +2611,12 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
     }
 }
 
-#include "rade_rx2.inc"
+extern "C" int rd_launch_rx_sync2(const rd_sync_args *a, rd_stream_t s);      /* rade_rx2.hip */
 
 extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
 {
     if (a->B <= 0) return 0;
-    if (a->variant == 2) {
-        static int attr2_set_dev[64];
-        int d2 = 0; (void)hipGetDevice(&d2);
-        if (!attr2_set_dev[d2 & 63]) { (void)hipFuncSetAttribute((const void *)k_rx_sync2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared2)); attr2_set_dev[d2 & 63] = 1; }
-        static int lds2 = -1;                        // developer switch: RADE_RX2_SOLO=1 asks for more than half the LDS, i.e. one workgroup per CU
-        if (lds2 < 0) { lds2 = getenv("RADE_RX2_SOLO") ? 100 * 1024 : (int)sizeof(RxShared2); (void)hipFuncSetAttribute((const void *)k_rx_sync2, hipFuncAttributeMaxDynamicSharedMemorySize, lds2); }
-        hipLaunchKernelGGL(k_rx_sync2, dim3(a->B), dim3(NT2), lds2, (hipStream_t)s, *a);
-        return (int)hipGetLastError();
-    }
+    if (a->variant == 2) return rd_launch_rx_sync2(a, s);
     static int attr_set_dev[64];                     // the attribute is per device (one engine per GPU in a multi-GPU host process)
     int dev_ = 0; (void)hipGetDevice(&dev_);
     if (!attr_set_dev[dev_ & 63]) { (void)hipFuncSetAttribute((const void *)k_rx_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared)); attr_set_dev[dev_ & 63] = 1; }
@@ -2646,3 +2643,5 @@ extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, doubl
     return (int)hipGetLastError();
 }
 
+
+#endif  // !RADE_RX2_TU

@@ -8,8 +8,11 @@ branched around (`s_cbranch_execz`).  The slot then keeps stale data and the lat
 every lane.  In k_rx_sync this silently corrupted a long-lived f64 polynomial coefficient of sincos() (frequency
 estimates off by 0.01 Hz) in builds that differed from the good one only by an unrelated reduction helper.
 
-This script disassembles the gfx950 code object embedded in a built object / shared library and reports every basic
-block in which a scratch access precedes the EXEC restore (`s_or_b64 exec, exec, ...` or `s_or_saveexec_b64`).  Exit status 1 if any is found.
+This script disassembles the gfx950 code objects embedded in a built object / shared library and reports every basic
+block in which a spill STORE precedes the EXEC restore (`s_or_b64 exec, exec, ...` or `s_or_saveexec_b64`), and every RELOAD there whose
+register is still read after the restore (a reload whose value is consumed inside the masked block and overwritten before any later
+read -- the compiler re-materialising a short-lived temporary under the branch's own mask -- is correct and is not reported).
+Exit status 1 if any is found.
 
     python tools/check_spill_exec.py radae_amd/libradehip.so
 """
@@ -24,14 +27,53 @@ TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
 def disassemble(path):
-    """-> disassembly text of the gfx950 code object inside a host object / shared library built by hipcc."""
+    """-> disassembly text of every gfx950 code object (one per translation unit) inside a host object / shared library built by hipcc."""
+    out = []
     with tempfile.TemporaryDirectory() as td:
-        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        fat = os.path.join(td, "fat.bin")
         subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", path, fat], check=True)
         if not os.path.exists(fat) or os.path.getsize(fat) == 0:
             raise RuntimeError(f"{path}: no .hip_fatbin section")
-        subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}", f"--targets={TARGET}", f"--output={co}"], check=True)
-        return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout
+        data = open(fat, "rb").read()
+        offs = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+        for k, o in enumerate(offs):
+            part, co = os.path.join(td, f"b{k}.bin"), os.path.join(td, f"d{k}.co")
+            open(part, "wb").write(data[o:offs[k + 1] if k + 1 < len(offs) else len(data)])
+            r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}", f"--targets={TARGET}", f"--output={co}"], capture_output=True)
+            if r.returncode == 0 and os.path.exists(co) and os.path.getsize(co):
+                out.append(subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], check=True, capture_output=True, text=True).stdout)
+    if not out:
+        raise RuntimeError(f"{path}: no gfx950 code object found")
+    return "\n".join(out)
+
+
+VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _vregs(text):
+    regs = set()
+    for m in VREG.finditer(text):
+        if m.group(1) is not None:
+            regs.add(int(m.group(1)))
+        else:
+            regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return regs
+
+
+def _read_after(ins, k, regs, limit=3000):
+    """is any register of `regs` read by the instructions after index k before it is overwritten?  (linear scan within the function)"""
+    live = set(regs); fn = ins[k][3]
+    for addr, op, args, f, tgt in ins[k + 1:k + 1 + limit]:
+        if f != fn or not live:
+            break
+        ops = [a.strip() for a in args.split(",")] if args else []
+        store_like = op.startswith(("scratch_store", "global_store", "ds_write", "buffer_store", "flat_store", "s_", "v_cmp", "v_readlane", "v_readfirstlane", "global_atomic", "ds_max", "ds_add", "ds_xor"))
+        srcs = _vregs(",".join(ops if store_like else ops[1:]))
+        if srcs & live:
+            return True
+        if not store_like and ops:
+            live -= _vregs(ops[0])
+    return False
 
 
 SYM = re.compile(r"^([0-9a-f]+) <([^>]+)>:")
@@ -59,14 +101,17 @@ def scan(text):
             if k + 1 < len(ins):
                 leaders.add(ins[k + 1][0])
     hits, pend = [], []
-    for addr, op, args, fn, tgt in ins:
+    for k, (addr, op, args, fn, tgt) in enumerate(ins):
         if addr in leaders:
             pend = []
-        if op.startswith("scratch_store") or op.startswith("scratch_load"):
-            pend.append(f"{addr:#x}: {op} {args}")
+        if op.startswith("scratch_store"):
+            pend.append((f"{addr:#x}: {op} {args}", None))
+        elif op.startswith("scratch_load"):
+            pend.append((f"{addr:#x}: {op} {args}", _vregs(args.split(",")[0])))
         elif (op == "s_or_b64" and args.replace(" ", "").startswith("exec,exec,")) or op == "s_or_saveexec_b64":
-            if pend:                  # EXEC widens here (join after an if, or the else side taking over the remaining lanes)
-                hits.append((fn, addr, pend))
+            bad = [t for t, regs in pend if regs is None or _read_after(ins, k, regs)]
+            if bad:                   # EXEC widens here (join after an if, or the else side taking over the remaining lanes)
+                hits.append((fn, addr, bad))
             pend = []
         elif "exec" in args.split(",")[0] or op == "s_barrier" or "saveexec" in op:
             pend = []          # any other EXEC write / barrier: what follows is not the join prologue
