@@ -210,7 +210,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         h->vm = dev_upload(vm, sizeof vm);
     }
     /* receiver kernel: 1 = one stream per CU (k_rx_sync), 2 = two streams per CU (k_rx_sync2) */
-    h->rx_variant = getenv("RADE_RX_VARIANT") ? atoi(getenv("RADE_RX_VARIANT")) : 1;
+    h->rx_variant = getenv("RADE_RX_VARIANT") ? atoi(getenv("RADE_RX_VARIANT")) : ((cfg->flags & RADE_BATCH_RX_TWO_PER_CU) ? 2 : 1);
     if (h->rx_variant != 2) h->rx_variant = 1;
     if (!h->d_tab || !h->fftG || !h->ffttw || !h->corr16 || !h->vm) goto fail;
 

@@ -124,12 +124,14 @@ def test_channel_df_dt_golden(Engine, torch_dev, golden, name):
     eng.close()
 
 
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync / k_rx_sync2 (RADE_BATCH_RX_TWO_PER_CU)
 @pytest.mark.parametrize("name", RX_CASES + ["dfdt", "nounsync"])
-def test_rx_trace_golden(Engine, torch_dev, golden, name):
+def test_rx_trace_golden(Engine, torch_dev, golden, name, rxflags, monkeypatch):
     import torch
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     g = golden("rxtrace_" + name)
     du = float(g["disable_unsync"]) if "disable_unsync" in g else 0.0       # radae_rxe.py --disable_unsync (ctests radae_rx_mpp / _mpg)
-    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=4 if name == "foff" else 0, disable_unsync=du)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags | (4 if name == "foff" else 0), disable_unsync=du)
     feats, st, eoo = eng.rx(torch.tensor(g["rx_in"][None], device=torch_dev))
     d = eng.rx_trace(0)
     for k in INT_KEYS:
@@ -842,6 +844,36 @@ def test_configs_1_and_5_at_batch_256_split_f16_gemm(Engine, torch_dev, oracle, 
         ref = np.stack([dec.step(r) for r in zh[b]])
         assert rms(fh[b], ref) < 1e-4, (blobname, b)
     eng.close()
+
+
+RX2 = 0x200          # RADE_BATCH_RX_TWO_PER_CU (include/rade_batch.h)
+
+
+def test_rx2_replicas_agree_when_two_workgroups_share_a_cu(Engine, torch_dev, golden, monkeypatch):
+    """300 copies of one stream: more workgroups than CUs, so 44 CUs run two of them side by side -- the situation k_rx_sync2 exists
+    for, and the one in which packed f32 FMAs in its band-pass filter corrupted lanes 48..63.  Bit-identical in every
+    slot, three fresh launches, and equal to the one-stream-per-CU kernel's discrete outputs."""
+    import torch
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
+    g = golden("rxtrace_mpp")
+    B = 300
+    buf = torch.tensor(np.stack([g["rx_in"]] * B), device=torch_dev)
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64, flags=RX2)
+    ref = Engine(1, max_tx_mf=1, rx_trace_calls=64)
+    fr, sr, _ = ref.rx(buf[:1].contiguous()); tr = ref.rx_trace(0)
+    for rep in range(3):
+        eng.rx_reset()
+        f, st, _ = eng.rx(buf)
+        f = f.cpu().numpy()
+        assert all(st[b].n_calls == st[0].n_calls and st[b].n_valid == st[0].n_valid for b in range(B))
+        bad = [b for b in range(1, B) if not np.array_equal(f[b], f[0])]
+        assert not bad, (rep, bad[:10])
+        t = eng.rx_trace(B - 1)
+        for k in INT_KEYS:
+            assert np.array_equal(t[k], tr[k]), k
+        nv = st[0].n_valid
+        assert sr[0].n_valid == nv and rms(f[0, :nv], fr[0, :nv].cpu().numpy()) < 2e-6
+    eng.close(); ref.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -60,11 +60,12 @@ def _vregs(text):
     return regs
 
 
-def _read_after(ins, k, regs, limit=3000):
-    """is any register of `regs` read by the instructions after index k before it is overwritten?  (linear scan within the function)"""
+def _read_after(ins, k, regs, limit=96):
+    """is any register of `regs` read by the instructions right after index k before it is overwritten?  A linear scan of the next
+    `limit` instructions, ended by a barrier or an unconditional branch: far-away reads belong to other paths, where the allocator reloads again."""
     live = set(regs); fn = ins[k][3]
     for addr, op, args, f, tgt in ins[k + 1:k + 1 + limit]:
-        if f != fn or not live:
+        if f != fn or not live or op in ("s_barrier", "s_branch", "s_endpgm", "s_setpc_b64"):
             break
         ops = [a.strip() for a in args.split(",")] if args else []
         store_like = op.startswith(("scratch_store", "global_store", "ds_write", "buffer_store", "flat_store", "s_", "v_cmp", "v_readlane", "v_readfirstlane", "global_atomic", "ds_max", "ds_add", "ds_xor"))
