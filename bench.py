@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1008, help="10 ms feature frames per utterance (multiple of 12)")
     ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="3: the headline batch workload; 2: single-stream core encoder/decoder latency")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight: engines + HIP streams + host threads that take the steps in turn (1 = one batch at a time)")
+    ap.add_argument("--two-pass-channel", action="store_true", help="rade_batch_tx + rade_batch_channel as two calls (k_chan_power + k_chan_apply) instead of rade_batch_tx_channel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -156,8 +157,10 @@ def main():
     def step(seed, e=None):
         e = e or eng
         e.reset()
-        iq = e.tx(feats)
-        rx = e.channel(iq, sigma, -11.0, n_pre=n_pre, n_post=n_post, with_eoo=True, G=G, seed=seed)
+        if args.two_pass_channel:
+            rx = e.channel(e.tx(feats), sigma, -11.0, n_pre=n_pre, n_post=n_post, with_eoo=True, G=G, seed=seed)
+        else:           # transmit + channel in one pass (rade_batch_tx_channel: the modulator applies the two-path model, no second pass over tx and G)
+            rx = e.tx_channel(feats, sigma, -11.0, n_pre=n_pre, n_post=n_post, with_eoo=True, G=G, seed=seed)
         return e.rx(rx) + (rx,)
 
     def run_steps(n, seed0):

@@ -95,6 +95,12 @@ typedef struct {
 int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *rx_out_dev, long rx_stride,
                        const rade_channel_params *p, void *stream);
 
+/* transmit and channel in one pass (what RADAE.forward does, radae.py:529-589): features [B][12 n_mf][36] -> received samples, with
+ * p->n_sig == 960 n_mf.  With p->G_dev the modulator applies the two-path model itself and leaves the power sums (no second pass over
+ * tx and G); iq_out_dev (the clean transmit samples) is then optional.  Returns n_total like rade_batch_channel, or <0. */
+int rade_batch_tx_channel(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, void *rx_out_dev, long rx_stride,
+                          const rade_channel_params *p, void *stream);
+
 /* ---- Watterson / Doppler-spread sample generator on the device (doppler_spread.m:7-50, multipath_samples.m:10-31):
  * per stream two independent paths G1, G2 = complex Gaussian noise at the low rate Fs/low_ratio through the
  * n_taps Gaussian-PSD FIR (taps designed by the caller, e.g. radae_amd/channel_tools.py), linearly interpolated to

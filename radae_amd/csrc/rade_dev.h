@@ -134,13 +134,16 @@ int rd_launch_chan_symbol(const float *z, const float *H, const float *noise, fl
 int rd_launch_carry_rows(float *x, int B, int Tcap, int W, int nhist, int T, const int *n_rows, rd_stream_t s);
 /* z [B][n_mf*3][80] -> tx [b*stride + mf*960 ...] (transmitter_one, dsp.py:340-378) */
 int rd_launch_ofdm_mod(const rd_tables *tab, const float *z, void *tx, long tx_stride, int B, int n_mf, rd_stream_t s);
+/* the same with the two-path multipath model applied on the way out: mp [B][n_mf*960] c64, part [B][n_mf][2] sums of |tx|^2, |mp|^2; tx optional */
+int rd_launch_ofdm_mod_mp(const rd_tables *tab, const float *z, void *tx, long tx_stride, int B, int n_mf, const void *G, void *mp, double *part, rd_stream_t s);
 /* EOO data symbols: bits [B][180] -> eoo frames [B][1152] (radae.py:441-455); bits NULL = defaults */
 int rd_launch_eoo_build(const rd_tables *tab, const float *bits, float *eoo, int B, rd_stream_t s);
 int rd_launch_copy_eoo(const float *eoo, void *out, long stride, int B, rd_stream_t s);
 
 typedef struct {
     const rd_tables *tab; const void *tx; long tx_stride; void *rx; long rx_stride;
-    const void *G; const void *noise; const float *eoo; void *scratch; /* >= B*64*2 doubles */
+    const void *G; const void *noise; const float *eoo; void *scratch; /* >= B * max(64, n_sig / 960) * 2 doubles */
+    const void *mp;                    /* optional [B][n_sig] c64: the multipath output k_ofdm_mod_mp left (scratch then holds its n_sig / 960 per-frame power sums per stream) */
     int B, n_sig, n_pre, n_post, with_eoo; float sigma, freq_offset, df_dt; unsigned long long seed;
     float sine_amp, sine_freq, rx_gain;
 } rd_chan_args;

@@ -43,7 +43,7 @@ struct rade_batch {
     float *enc_whh[5], *enc_bhh[5], *dec_whh[5], *dec_bhh[5];
     /* transmit side */
     float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
-    void *chan_scratch;
+    void *chan_scratch; void *chan_mp;        /* chan_mp [B][max_tx_mf * 960] c64: multipath output of the fused modulator (rade_batch_tx_channel), allocated on first use */
     /* receive side */
     rd_rx_stream *rx_st; rd_rx_round *rx_round;
     int *rx_avail, *rx_acc, *rx_progress, *rx_status;
@@ -240,7 +240,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->enc_z = dev_zeros(sizeof(float) * B * T * RD_LATENT);
     h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
     h->eoo_bits = dev_zeros(sizeof(float) * B * RD_NEOOBITS);
-    h->chan_scratch = dev_zeros(sizeof(double) * B * 64 * 2);
+    h->chan_scratch = dev_zeros(sizeof(double) * B * (cfg->max_tx_mf > 64 ? cfg->max_tx_mf : 64) * 2);
     for (int l = 0; l < 5; l++) { h->enc_h[l] = dev_zeros(sizeof(float) * B * 64); h->dec_h[l] = dev_zeros(sizeof(float) * B * 96); if (!h->enc_h[l] || !h->dec_h[l]) goto fail; }
     h->rx_st = dev_zeros(sizeof(rd_rx_stream) * B);
     h->rx_round = dev_zeros(sizeof(rd_rx_round) * B);
@@ -310,7 +310,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16, h->vm };
+                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16, h->vm, h->chan_mp };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -475,6 +475,39 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
     memset(&a, 0, sizeof a);
     a.tab = h->d_tab; a.tx = tx_dev; a.tx_stride = tx_stride; a.rx = rx_out_dev; a.rx_stride = rx_stride; a.G = p->G_dev; a.noise = p->noise_dev;
     a.eoo = h->eoo; a.scratch = h->chan_scratch; a.B = h->B; a.n_sig = p->n_sig; a.n_pre = p->n_pre; a.n_post = p->n_post; a.with_eoo = p->with_eoo;
+    a.sigma = p->sigma; a.freq_offset = p->freq_offset; a.df_dt = p->df_dt; a.seed = p->seed;
+    a.sine_amp = p->sine_amp; a.sine_freq = p->sine_freq; a.rx_gain = p->rx_gain != 0.0f ? p->rx_gain : 1.0f;
+    PROF_BEGIN(h, stream);
+    if (rd_launch_channel(&a, stream)) return -1;
+    PROF_END(h, stream, RADE_PROF_CHAN, 0.0);
+    return p->n_pre + p->n_sig + (p->with_eoo ? RD_NEOO : 0) + p->n_post;
+}
+
+/* ---- transmit + channel in one pass (RADAE.forward, radae.py:529-589: latents -> OFDM -> multipath -> noise) -------------------
+ * The modulator applies the two-path model while a frame's samples are in LDS and leaves the power sums, so tx is never re-read and
+ * k_chan_power does not run; without G (AWGN only) it is the two calls back to back. */
+int rade_batch_tx_channel(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, void *rx_out_dev, long rx_stride,
+                          const rade_channel_params *p, void *stream)
+{
+    ON_DEV(h);
+    if (!h || !p || n_mf <= 0 || n_mf > h->max_tx_mf || h->feat_in != 84 || p->n_sig != n_mf * RD_NMF || !rx_out_dev) return -1;
+    if (!p->G_dev) {
+        if (!iq_out_dev) return -1;
+        if (rade_batch_tx(h, features_dev, n_mf, iq_out_dev, iq_stride, NULL, stream) != p->n_sig) return -1;
+        return rade_batch_channel(h, iq_out_dev, iq_stride, rx_out_dev, rx_stride, p, stream);
+    }
+    if (!h->chan_mp && !(h->chan_mp = dev_zeros(sizeof(float) * 2 * (size_t)h->B * h->max_tx_mf * RD_NMF))) return -1;
+    const int B = h->B, T = 3 * n_mf;
+    int e = rd_launch_enc_pack(features_dev, h->enc_xin, B, T, stream);
+    e |= encode_core(h, T, h->enc_z, stream);
+    PROF_BEGIN(h, stream);
+    e |= rd_launch_ofdm_mod_mp(h->d_tab, h->enc_z, iq_out_dev, iq_stride, B, n_mf, p->G_dev, h->chan_mp, (double *)h->chan_scratch, stream);
+    PROF_END(h, stream, RADE_PROF_MOD, 8.0 * B * n_mf * 5 * 30 * 160);
+    if (e) return -1;
+    rd_chan_args a;
+    memset(&a, 0, sizeof a);
+    a.tab = h->d_tab; a.tx = NULL; a.tx_stride = 0; a.rx = rx_out_dev; a.rx_stride = rx_stride; a.G = p->G_dev; a.noise = p->noise_dev; a.mp = h->chan_mp;
+    a.eoo = h->eoo; a.scratch = h->chan_scratch; a.B = B; a.n_sig = p->n_sig; a.n_pre = p->n_pre; a.n_post = p->n_post; a.with_eoo = p->with_eoo;
     a.sigma = p->sigma; a.freq_offset = p->freq_offset; a.df_dt = p->df_dt; a.seed = p->seed;
     a.sine_amp = p->sine_amp; a.sine_freq = p->sine_freq; a.rx_gain = p->rx_gain != 0.0f ? p->rx_gain : 1.0f;
     PROF_BEGIN(h, stream);

@@ -1107,6 +1107,89 @@ extern "C" int rd_launch_ofdm_mod(const rd_tables *tab, const float *z, void *tx
     return (int)hipGetLastError();
 }
 
+// The modulator with the first half of the channel simulator folded in (rade_batch_tx_channel: RADAE.forward goes from latents to received
+// samples in one pass too, radae.py:529-589): the workgroup keeps its modem frame's 960 samples in LDS, applies the two-path
+// multipath model mp[i] = tx[i] G1[i] + tx[i-16] G2[i-16] while they are there (the 16 samples it needs from the frame before are
+// re-synthesised: 16 x 30 terms) and leaves per-frame sums of |tx|^2 and |mp|^2 for the power normalisation.  tx never makes a round
+// trip through HBM, k_chan_power disappears, and k_chan_apply reads 8 bytes per sample (mp) instead of 24 (tx + G).
+__global__ __launch_bounds__(192) void k_ofdm_mod_mp(const rd_tables *tab, const float *z, float2 *tx, long tx_stride, int n_mf, const float2 *G, float2 *mp, double *part)
+{
+    __shared__ float2 sym[RD_NS + 1][RD_NC];
+    __shared__ float2 prevsym[RD_NC];
+    __shared__ float2 fr[16 + RD_NMF];                    // [0, 16): tail of the previous frame, then this frame
+    __shared__ double red[2][192];
+    const int mf = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *zf = z + ((size_t)b * n_mf + mf) * RD_ZMF;
+    if (tid < RD_NC) sym[0][tid] = make_float2(tab->P[tid] * tab->pilot_gain, 0.0f * tab->pilot_gain);
+    if (tid < 120) sym[1 + tid / RD_NC][tid % RD_NC] = make_float2(zf[2 * tid], zf[2 * tid + 1]);
+    if (tid >= 128 && tid < 128 + RD_NC && mf > 0) { const int c = tid - 128; prevsym[c] = make_float2(zf[-RD_ZMF + 2 * (90 + c)], zf[-RD_ZMF + 2 * (90 + c) + 1]); }   // last data symbol of frame mf - 1
+    __syncthreads();
+    if (tid < RD_M) {
+        float2 acc[RD_NS + 1];
+#pragma unroll
+        for (int s = 0; s <= RD_NS; s++) acc[s] = make_float2(0.0f, 0.0f);
+#pragma unroll 6
+        for (int c = 0; c < RD_NC; c++) {
+            const float2 w = ld2(tab->Winv[c], tid);
+#pragma unroll
+            for (int s = 0; s <= RD_NS; s++) acc[s] = cadd(acc[s], cmul(sym[s][c], w));
+        }
+#pragma unroll
+        for (int s = 0; s <= RD_NS; s++) {
+            const float2 v = pa_limit(acc[s]);
+            fr[16 + s * RD_SYM + RD_NCP + tid] = v;
+            if (tid >= RD_M - RD_NCP) fr[16 + s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
+        }
+    } else if (tid < RD_M + 16) {                          // samples 944..959 of the previous frame = the last 16 of its last symbol
+        const int n = RD_M - 16 + (tid - RD_M);
+        float2 a = make_float2(0.0f, 0.0f);
+        if (mf > 0) { for (int c = 0; c < RD_NC; c++) a = cadd(a, cmul(prevsym[c], ld2(tab->Winv[c], n))); a = pa_limit(a); }
+        fr[tid - RD_M] = a;                                // frame 0: the signal starts here, nothing before it (chan_mp: i >= 16)
+    }
+    __syncthreads();
+    const size_t base = (size_t)mf * RD_NMF;
+    const f32x4 *Gb = (const f32x4 *)G + (size_t)b * n_mf * RD_NMF;      // (G1[i], G2[i]) as one 16-byte load per sample
+    float2 *mpo = mp + (size_t)b * n_mf * RD_NMF + base;
+    float2 *txo = tx ? tx + (size_t)b * tx_stride + base : nullptr;
+    // second path: c2[i + 16] = tx[i] G2[i], written to LDS by the thread that holds G2[i]; the first 16 slots of the frame come from the
+    // previous frame's tail (fr[0..16)) and its G2
+    __shared__ float2 c2[16 + RD_NMF];
+    float2 a1[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int i = tid + 192 * q;                       // 960 = 5 x 192
+        const f32x4 g = Gb[base + i];
+        const float2 x = fr[16 + i];
+        a1[q] = cmul(x, make_float2(g[0], g[1]));
+        c2[16 + i] = cmul(x, make_float2(g[2], g[3]));
+    }
+    if (tid < 16) { float2 v = make_float2(0.0f, 0.0f); if (mf > 0) { const f32x4 g = Gb[base - 16 + tid]; v = cmul(fr[tid], make_float2(g[2], g[3])); } c2[tid] = v; }
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const int i = tid + 192 * q;
+        const float2 x = fr[16 + i];
+        const float2 m = cadd(a1[q], c2[i]);               // c2[i] = tx[base + i - 16] G2[base + i - 16]; zero for the first 16 samples of the signal
+        mpo[i] = m;
+        if (txo) txo[i] = x;
+        const float ax = hypotf(x.x, x.y), am = hypotf(m.x, m.y);
+        s0 += (double)(ax * ax); s1 += (double)(am * am);
+    }
+    red[0][tid] = s0; red[1][tid] = s1;
+    __syncthreads();
+    if (tid < 64) { red[0][tid] += red[0][tid + 64] + red[0][tid + 128]; red[1][tid] += red[1][tid + 64] + red[1][tid + 128]; }
+    __syncthreads();
+    for (int w = 32; w > 0; w >>= 1) { if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; } __syncthreads(); }
+    if (tid == 0) { part[((size_t)b * n_mf + mf) * 2] = red[0][0]; part[((size_t)b * n_mf + mf) * 2 + 1] = red[1][0]; }
+}
+extern "C" int rd_launch_ofdm_mod_mp(const rd_tables *tab, const float *z, void *tx, long tx_stride, int B, int n_mf, const void *G, void *mp, double *part, rd_stream_t s)
+{
+    if (B <= 0 || n_mf <= 0) return 0;
+    hipLaunchKernelGGL(k_ofdm_mod_mp, dim3(n_mf, B), dim3(192), 0, (hipStream_t)s, tab, z, (float2 *)tx, tx_stride, n_mf, (const float2 *)G, (float2 *)mp, part);
+    return (int)hipGetLastError();
+}
+
 // EOO frame per stream: default table copy, optionally with 3 data symbols (90 QPSK) inserted
 __global__ __launch_bounds__(192) void k_eoo_build(const rd_tables *tab, const float *bits, float2 *eoo)
 {
@@ -1203,7 +1286,7 @@ __device__ __forceinline__ double chan_phase_acc(int i, float f0, float df_dt)
     return (2.0 * PI_D / 8000.0) * (n * (double)f0 + ((double)df_dt / 8000.0) * 0.5 * (double)i * n);
 }
 
-__global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double *part)
+__global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double *part, int n_part)
 {
     const int b = blockIdx.y;
     const int n_eoo = a.with_eoo ? RD_NEOO : 0;
@@ -1211,7 +1294,7 @@ __global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double
     __shared__ float s_gain; __shared__ float2 s_fin;
     if (threadIdx.x == 0) {
         double p0 = 0.0, p1 = 0.0;
-        for (int c = 0; c < CH_NCH; c++) { p0 += part[((size_t)b * CH_NCH + c) * 2]; p1 += part[((size_t)b * CH_NCH + c) * 2 + 1]; }
+        for (int c = 0; c < n_part; c++) { p0 += part[((size_t)b * n_part + c) * 2]; p1 += part[((size_t)b * n_part + c) * 2 + 1]; }
         const float tx_power = (float)(p0 / a.n_sig), mp_power = (float)(p1 / a.n_sig);
         s_gain = a.G ? powf(tx_power / mp_power, 0.5f) : 1.0f;
         float2 fin = make_float2(1.0f, 0.0f);
@@ -1225,13 +1308,15 @@ __global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double
     const float2 *noise = a.noise ? (const float2 *)a.noise + (size_t)b * n_total : nullptr;
     const float2 *eoo = (const float2 *)a.eoo + (size_t)b * RD_NEOO;
     float2 *rx = (float2 *)a.rx + (size_t)b * a.rx_stride;
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < n_total; j += gridDim.x * 256) {
+    // two consecutive samples per thread: one Philox4x32 call yields the four uniforms of both (the generator and the Box-Muller
+    // transcendentals, not the bytes, are what this kernel's time is made of), and a thread's store is 16 bytes
+    auto sample = [&](int j, uint32_t u0, uint32_t u1) -> float2 {
         float2 v = make_float2(0.0f, 0.0f);
         bool real_noise = true;
         const int i = j - a.n_pre;
         if (i >= 0 && i < a.n_sig) {
             real_noise = false;
-            const float2 m = chan_mp(tx, G, i);
+            const float2 m = a.mp ? ((const float2 *)a.mp)[(size_t)b * a.n_sig + i] : chan_mp(tx, G, i);
             v = make_float2(m.x * gain, m.y * gain);
             if (a.freq_offset != 0.0f) { float sn, cs; sincosf((float)chan_phase_acc(i, a.freq_offset, a.df_dt), &sn, &cs); v = cmul(v, make_float2(cs, sn)); }
         } else if (i >= a.n_sig && i < a.n_sig + n_eoo) {
@@ -1242,9 +1327,7 @@ __global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double
         }
         if (noise) { v.x += a.sigma * noise[j].x; v.y += a.sigma * noise[j].y; }
         else if (a.seed) {
-            uint32_t r[4];
-            philox4x32((uint32_t)j, (uint32_t)b, 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
-            const float2 g = gauss_pair(r[0], r[1]);
+            const float2 g = gauss_pair(u0, u1);
             if (real_noise) v.x += a.sigma * g.x;                                  // inference.py:277-284: real-valued randn
             else { v.x += a.sigma * 0.70710678f * g.x; v.y += a.sigma * 0.70710678f * g.y; }   // complex randn: 1/2 per component
         }
@@ -1253,7 +1336,19 @@ __global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double
             float sn, cs; sincosf((float)(6.283185307179586 * (cyc - floor(cyc))), &sn, &cs);
             v.x += a.sine_amp * cs; v.y += a.sine_amp * sn;
         }
-        rx[j] = make_float2(v.x * a.rx_gain, v.y * a.rx_gain);
+        return make_float2(v.x * a.rx_gain, v.y * a.rx_gain);
+    };
+    const int n_pairs = (n_total + 1) >> 1;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += gridDim.x * 256) {
+        uint32_t r[4] = { 0u, 0u, 0u, 0u };
+        if (!noise && a.seed) philox4x32((uint32_t)p, (uint32_t)b, 0u, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), r);
+        const int j = 2 * p;
+        const float2 v0 = sample(j, r[0], r[1]);
+        if (j + 1 < n_total) {
+            const float2 v1 = sample(j + 1, r[2], r[3]);
+            if (((uintptr_t)rx & 15) == 0) *(f32x4 *)&rx[j] = (f32x4){ v0.x, v0.y, v1.x, v1.y };
+            else { rx[j] = v0; rx[j + 1] = v1; }
+        } else rx[j] = v0;
     }
 }
 
@@ -1348,10 +1443,10 @@ extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
     if (a->B <= 0) return 0;
     hipStream_t st = (hipStream_t)s;
     double *part = (double *)a->scratch;
-    hipLaunchKernelGGL(k_chan_power, dim3(CH_NCH, a->B), dim3(256), 0, st, *a, part);
+    if (!a->mp) hipLaunchKernelGGL(k_chan_power, dim3(CH_NCH, a->B), dim3(256), 0, st, *a, part);      // a->mp: the modulator left mp and its per-frame power sums (k_ofdm_mod_mp)
     const int n_total = a->n_pre + a->n_sig + (a->with_eoo ? RD_NEOO : 0) + a->n_post;
     int gx = (n_total + 255) / 256; if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_chan_apply, dim3(gx, a->B), dim3(256), 0, st, *a, (const double *)part);
+    hipLaunchKernelGGL(k_chan_apply, dim3(gx, a->B), dim3(256), 0, st, *a, (const double *)part, a->mp ? a->n_sig / RD_NMF : CH_NCH);
     return (int)hipGetLastError();
 }
 

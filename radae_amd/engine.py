@@ -58,6 +58,7 @@ def load_library() -> C.CDLL:
     L.rade_batch_close.argtypes = [vp]
     L.rade_batch_n_streams.argtypes = [vp]
     L.rade_batch_tx.argtypes = [vp, vp, C.c_int, vp, C.c_long, vp, vp]
+    L.rade_batch_tx_channel.argtypes = [vp, vp, C.c_int, vp, C.c_long, vp, C.c_long, vp, vp]
     L.rade_batch_tx_set_eoo_bits.argtypes = [vp, vp]
     L.rade_batch_tx_eoo.argtypes = [vp, vp, C.c_long, vp]
     L.rade_batch_tx_reset.argtypes = [vp]
@@ -86,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "rade_freq_offset", "rade_snrdB_3k_est",
     # include/rade_batch.h
     "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_set_eoo_bits",
-    "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
+    "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_tx_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
     "rade_batch_rx_stream_cycles",
@@ -250,6 +251,30 @@ class BatchEngine:
         if r != n_total:
             raise RuntimeError("rade_batch_channel failed")
         return rx
+
+    def tx_channel(self, features, sigma: float, freq_offset: float = 0.0, n_pre: int = 0, n_post: int = 0, with_eoo: bool = False,
+                   G=None, noise=None, seed: int = 0, df_dt: float = 0.0, want_iq: bool = False):
+        """Transmit and channel in one pass (RADAE.forward): features [B, n_mf*12, 36] -> rx complex64 [B, n_total] (and iq if wanted).
+        With G the modulator applies the two-path model itself (rade_batch_tx_channel); the whole utterance must fit max_tx_mf."""
+        import torch
+        assert features.is_cuda and features.dtype == torch.float32 and features.is_contiguous()
+        B, nfr, w = features.shape
+        assert B == self.B and w == 36 and nfr % 12 == 0 and nfr // 12 <= self.max_tx_mf
+        n_mf = nfr // 12; n_sig = n_mf * NMF
+        n_total = n_pre + n_sig + (NEOO if with_eoo else 0) + n_post
+        rx = torch.empty((B, n_total), dtype=torch.complex64, device=features.device)
+        iq = torch.empty((B, n_sig), dtype=torch.complex64, device=features.device) if (want_iq or G is None) else None
+        p = ChannelParams(n_sig, n_pre, n_post, int(with_eoo), sigma, freq_offset, df_dt, None, None, seed, 0.0, 0.0, 1.0)
+        if G is not None:
+            assert G.is_cuda and G.dtype == torch.complex64 and G.is_contiguous() and tuple(G.shape) == (B, n_sig, 2)
+            p.G_dev = G.data_ptr()
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.complex64 and noise.is_contiguous() and tuple(noise.shape) == (B, n_total)
+            p.noise_dev = noise.data_ptr()
+        r = self.lib.rade_batch_tx_channel(self.h, features.data_ptr(), n_mf, iq.data_ptr() if iq is not None else None, n_sig, rx.data_ptr(), n_total, C.byref(p), _stream_ptr())
+        if r != n_total:
+            raise RuntimeError("rade_batch_tx_channel failed")
+        return (rx, iq) if want_iq else rx
 
     def multipath_gen(self, channel: str, n_out: int, seed: int = 1, noise_low=None, fs: int = 8000):
         """Doppler-spread samples G [B, n_out, 2] complex64 generated on the device (multipath_samples.m presets

@@ -846,6 +846,44 @@ def test_configs_1_and_5_at_batch_256_split_f16_gemm(Engine, torch_dev, oracle, 
     eng.close()
 
 
+def test_tx_channel_one_pass_equals_two_calls(Engine, torch_dev, oracle, oracle_model):
+    """rade_batch_tx_channel (the modulator applies the two-path model and leaves the power sums: RADAE.forward in one pass) against
+    rade_batch_tx + rade_batch_channel on the same inputs, and against the oracle's transmitter + channel for one stream."""
+    import torch
+    from radae_amd.channel_tools import multipath_g, synth_features
+    from radae_amd.engine import sigma_from_EbNodB
+    B, n_mf = 3, 12
+    feats = np.stack([synth_features(40 + b, 12 * n_mf) for b in range(B)])
+    G = np.stack([multipath_g("mpp", 8000, n_mf * 960, 70 + b) for b in range(B)])
+    rng = np.random.default_rng(8)
+    n_tot = 300 + n_mf * 960 + 1152 + 200
+    noise = ((rng.standard_normal((B, n_tot)) + 1j * rng.standard_normal((B, n_tot))) / np.sqrt(2)).astype(np.complex64)
+    sigma = sigma_from_EbNodB(6.0)
+    ft, Gt, nt = torch.tensor(feats, device=torch_dev), torch.tensor(G, device=torch_dev), torch.tensor(noise, device=torch_dev)
+    e1 = Engine(B, max_tx_mf=n_mf); e2 = Engine(B, max_tx_mf=n_mf)
+    iq = e1.tx(ft)
+    rx_two = e1.channel(iq, sigma, -7.0, n_pre=300, n_post=200, with_eoo=True, G=Gt, noise=nt).cpu().numpy()
+    rx_one, iq_one = e2.tx_channel(ft, sigma, -7.0, n_pre=300, n_post=200, with_eoo=True, G=Gt, noise=nt, want_iq=True)
+    assert np.array_equal(iq_one.cpu().numpy(), iq.cpu().numpy())                 # the clean transmit samples are the same bits
+    assert np.abs(rx_one.cpu().numpy() - rx_two).max() < 2e-6                     # power sums meet in a different order: gain within an ulp
+    e2.tx_reset()
+    rx_noiq = e2.tx_channel(ft, sigma, -7.0, n_pre=300, n_post=200, with_eoo=True, G=Gt, noise=nt)
+    assert np.array_equal(rx_noiq.cpu().numpy(), rx_one.cpu().numpy())            # iq output optional
+    # AWGN-only: falls back to the two calls
+    e1.tx_reset(); e2.tx_reset()
+    a = e1.channel(e1.tx(ft), sigma, 0.0, noise=nt[:, :n_mf * 960].contiguous()).cpu().numpy()
+    b_ = e2.tx_channel(ft, sigma, 0.0, noise=nt[:, :n_mf * 960].contiguous()).cpu().numpy()
+    assert np.array_equal(a, b_)
+    # oracle, stream 1
+    tx = oracle.Tx(oracle_model)
+    sig = np.concatenate([tx.frame(feats[1, 12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+    r, fin = oracle.channel(sig, G[1], noise[1, 300:300 + len(sig)], sigma, -7.0)
+    ee = oracle.channel_eoo(tx.eoo(), noise[1, 300 + len(sig):300 + len(sig) + 1152], sigma, -7.0, 0.0, fin)
+    full = np.concatenate([sigma * noise[1, :300], r, ee, sigma * noise[1, -200:]]).astype(np.complex64)
+    assert np.abs(rx_one.cpu().numpy()[1] - full).max() < 5e-5
+    e1.close(); e2.close()
+
+
 RX2 = 0x200          # RADE_BATCH_RX_TWO_PER_CU (include/rade_batch.h)
 
 

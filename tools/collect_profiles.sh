@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats of the bench command + separate PMC passes (never combined with
 # trace domains other than --kernel-trace).  Outputs land in gpurun_out/prof_$TAG/ and are summarised into profiles/ by
 # tools/make_profile_summary.py (run it afterwards in the repo).  Usage: bash tools/collect_profiles.sh [tag]
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
@@ -24,6 +24,14 @@ pass write WRITE_SIZE
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 pass sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA
 pass l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# 3b. the other configurations and variants (plain lines, no profiler): configs[1] alone, the two-streams-per-CU receiver at 2 and 3 batches in flight,
+#     configs 1 and 5 rates, rocprofv3 stats of the single-stream step kernels
+python $R/bench.py --config 2 > $O/bench_config2.json 2> $O/bench_config2.err
+for p in 2 3; do RADE_RX_VARIANT=2 python $R/bench.py --steps 60 --pipeline $p --no-cpu-baseline > $O/bench_rx2_p$p.json 2> /dev/null; done
+python $R/bench.py --steps 60 --pipeline 3 --no-cpu-baseline > $O/bench_rx1_p3.json 2> /dev/null
+python $R/tools/config_rates.py > $O/config_rates.txt 2>&1; cp $R/gpurun_out/config_rates.json $O/ 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python $R/bench.py --config 2 > /dev/null 2> $O/stats_c2.err
+RADE_RX_VARIANT=2 python $R/tools/stream_cycles.py > $O/stream_cycles_rx2.json 2> /dev/null
 # 4. per-stream duration of the receiver launch (tail analysis) and the receiver's traffic by source
 python $R/tools/stream_cycles.py > $O/stream_cycles.json 2> $O/stream_cycles.err
 find $O -name "*.csv" | head -30

@@ -3,13 +3,16 @@
 <tag>_bench_kernel_stats.csv, <tag>_bench_line.json, <tag>_bench_under_rocprof.json, <tag>_pmc_per_kernel.txt, <tag>_pmc_summary.json,
 <tag>_stream_cycles.json.  Usage: python tools/make_profile_summary.py [tag]"""
 import csv, glob, json, os, shutil, subprocess, sys, collections
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(R, "gpurun_out", "prof_" + tag); dst = os.path.join(R, "profiles")
 shutil.copy(glob.glob(os.path.join(src, "stats", "**", "bench_kernel_stats.csv"), recursive=True)[0], os.path.join(dst, tag + "_bench_kernel_stats.csv"))
 pp = glob.glob(os.path.join(src, "stats_pipe", "**", "bench_kernel_stats.csv"), recursive=True)
 if pp: shutil.copy(pp[0], os.path.join(dst, tag + "_bench_pipelined_kernel_stats.csv"))      # the default command (two batches in flight)
-for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles"):
+pc = glob.glob(os.path.join(src, "stats_c2", "**", "c2_kernel_stats.csv"), recursive=True)
+if pc: shutil.copy(pc[0], os.path.join(dst, tag + "_config2_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "config_rates.json")): shutil.copy(os.path.join(src, "config_rates.json"), os.path.join(dst, tag + "_config_rates.json"))
+for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles", "bench_config2", "bench_rx2_p2", "bench_rx2_p3", "bench_rx1_p3", "stream_cycles_rx2"):
     if not os.path.exists(os.path.join(src, name + ".json")): continue
     line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
