@@ -39,12 +39,14 @@ REF_SYNC_CALL_FLOP = RX_SYNC_CMAC * 8.0          # in-sync DSP per modem frame a
 # executed: refine() in sync runs as 8 moments x 16 timings x 2 frames x 160 samples (40,960 cMAC) + the polynomials (640 x ~40 flop)
 # instead of 20 frequencies x 16 x 2 x 160 (102,400 cMAC): 0.47 MFLOP less per call
 SYNC_CALL_FLOP = (RX_SYNC_CMAC - 102400 + 40960) * 8.0 + 640 * 40.0     # 6.28 MFLOP
+ENC_STEP_FLOP = 2.0 * (96 * 64 + (64 + 224 + 384 + 544 + 704) * 192 + 2 * (128 + 288 + 448 + 608 + 768) * 96 + 864 * 80 + 5 * 64 * 192)   # CoreEncoder, one 40 ms step (4 feature frames): 1.87 MFLOP
 DEC_MF_FLOP = 3 * 904064 * 2.0                   # CoreDecoder, 3 steps per decoded modem frame (runs inside k_rx_sync): 5.42 MFLOP = 0.452 MFLOP per feature frame
 BPF_CALL_FLOP = 960 * 101 * 8.0                  # the BPF of a search / candidate call (it is inside SYNC_CALL_FLOP for synchronised ones): 0.78 MFLOP
 FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface by FFT convolution: 1 forward + 40 inverse 2048-point FFTs (5 N log2 N) + 40 spectral products: 5.11 MFLOP
 REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation of detect_pilots (two surfaces as GEMMs): 98.3 MFLOP -- NOT executed here
 ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
 RX_ALGO_BYTES_PER_FRAME = 640 + 144              # the receiver kernel's share: IQ in + features out
+RX_KERNEL_NAME = "k_rx_sync2"                     # set from --rx-kernel in main(): the PMC summary is looked up under the kernel that ran
 PROFILE_TAG = "r03"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
 
 
@@ -100,7 +102,8 @@ def main():
     ap.add_argument("--streams", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1008, help="10 ms feature frames per utterance (multiple of 12)")
     ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="3: the headline batch workload; 2: single-stream core encoder/decoder latency")
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight: engines + HIP streams + host threads that take the steps in turn (1 = one batch at a time)")
+    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight: engines + HIP streams + host threads that take the steps in turn (1 = one batch at a time)")
+    ap.add_argument("--rx-kernel", type=int, default=2, choices=(1, 2), help="receiver kernel: 2 = k_rx_sync2, two streams per CU (RADE_BATCH_RX_TWO_PER_CU: workgroups of two batches in flight share a CU); 1 = k_rx_sync, one stream per CU")
     ap.add_argument("--two-pass-channel", action="store_true", help="rade_batch_tx + rade_batch_channel as two calls (k_chan_power + k_chan_apply) instead of rade_batch_tx_channel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -139,7 +142,10 @@ def main():
     # encoder / channel kernels (and the head of its receiver launch) fill the CUs that the slowest streams of the previous batch's receiver
     # launch leave idle (a receiver launch lasts as long as its slowest stream; rade_batch_rx synchronises its stream, hence one thread each)
     depth = max(1, min(args.pipeline, args.steps))
-    engs = [BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob) for _ in range(depth)]
+    global RX_KERNEL_NAME
+    RX_KERNEL_NAME = "k_rx_sync2" if args.rx_kernel == 2 else "k_rx_sync"
+    rx_flags = 0x200 if args.rx_kernel == 2 else 0                       # RADE_BATCH_RX_TWO_PER_CU
+    engs = [BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob, flags=rx_flags) for _ in range(depth)]
     eng = engs[0]
     lanes = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 
@@ -247,8 +253,11 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline_leg(eng, step, args.steps, B, T, value, world)
+        out["roofline"]["rx_kernel"] = "k_rx_sync2 (two streams per CU)" if args.rx_kernel == 2 else "k_rx_sync (one stream per CU)"
+        if depth > 1 and out["roofline"].get("kernel") == "rx_sync":
+            pipelined_roofline(out["roofline"], engs, run_steps, min(args.steps, 24), dev)
     if rank == 0 and not args.no_parity:
-        out["parity_sample"] = parity_leg(feats_np, fo, st, rx_last, blob, local, B)
+        out["parity_sample"] = parity_leg(feats_np, fo, st, rx_last, blob, local, B, rx_flags)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(feats_np, T)
         out["cpu_baseline_allcores"] = cpu_baseline_allcores(T)
@@ -297,7 +306,11 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         fl = executed_flop(counts["search_calls"], counts["sync_calls"], counts["decoded_modem_frames"])
         achieved = fl / (r["avg_launch_ms"] * 1e-3) / 1e12
         algo_bytes = RX_ALGO_BYTES_PER_FRAME * B * T
+        step_flop = fl + ENC_STEP_FLOP * B * T / 4 + 8.0 * B * (T // 12) * 5 * 30 * 160          # receiver + encoder + modulator IDFT, as executed
         r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
+                  "whole_job": {"executed_flop_per_step": step_flop, "executed_flop_per_frame": step_flop / (B * T), "achieved": value / world * step_flop / (B * T) / 1e12,
+                                "frac": value / world * step_flop / (B * T) / 1e12 / F32_PEAK_TFLOPS,
+                                "note": "every kernel's executed work (receiver as above + CoreEncoder GEMMs / recurrences + modulator) x the timed frames/s, against the same f32 peak: the figure that does not depend on how the kernels overlap"},
                   "per_launch_counts": counts, "executed_flop_per_launch": fl, "algorithmic_bytes_per_launch": algo_bytes,
                   "flop_model": {"sync_call": SYNC_CALL_FLOP, "decoded_modem_frame": DEC_MF_FLOP, "search_call": FFT_SURFACE_FLOP + BPF_CALL_FLOP,
                                  "note": "executed work: in-sync DSP 781,120 cMAC x 8 (refine by moments: 40,960 cMAC instead of the reference formulation's 102,400) + polynomials per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
@@ -319,7 +332,7 @@ def roofline_leg(eng, step, steps, B, T, value, world):
     try:
         tag = next(t for t in (PROFILE_TAG, "r02") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
         pm = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")))
-        k = pm["kernels"][{"rx_sync": "k_rx_sync"}.get(dom, dom)]
+        k = pm["kernels"][{"rx_sync": RX_KERNEL_NAME}.get(dom, dom)]
         raw = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
         r["traffic"] = raw
         r["traffic_fetch_wide_corrected"] = 2.0 * k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]   # gfx950: FETCH_SIZE halves 16-byte-per-lane loads (upper bound: not every load is that wide)
@@ -334,7 +347,7 @@ def roofline_leg(eng, step, steps, B, T, value, world):
             r["l2_hit_rate_pmc"] = k["l2_hit_rate"]
         r["mfma_busy_pct_pmc"] = k["mfma_busy_pct"]
         r["counters_from"] = f"profiles/{tag}_pmc_summary.json (commit {pm.get('commit', '?')})"
-        sq = pm.get("sq_breakdown", {}).get("k_rx_sync")
+        sq = pm.get("sq_breakdown", {}).get(RX_KERNEL_NAME)
         if sq:
             r["sq_wave_cycle_shares"] = sq
             r["limiter"] = sq.get("bound", r["limiter"])
@@ -343,7 +356,45 @@ def roofline_leg(eng, step, steps, B, T, value, world):
     return r
 
 
-def parity_leg(feats_np, fo, st, rx, blob, local, B):
+def pipelined_roofline(r, engs, run_steps, n, dev):
+    """The dominant kernel as it runs in the TIMED configuration: with several batches in flight the receiver launches of different engines
+    overlap on the device (k_rx_sync2: two workgroups per CU), so one launch's duration says little about the chip.  Every receiver launch
+    of `n` more pipelined steps (same seeds as the leg above, hence the same per-launch work) is put on one time axis with HIP events
+    (rade_batch_profile_intervals); achieved = executed FLOP of all of them / the time during which at least one was running."""
+    ref = torch.cuda.Event(enable_timing=True); ref.record(); torch.cuda.synchronize()
+    for e in engs:
+        e.profile_ref(ref.cuda_event); e.profile(True)
+    run_steps(n, 1)
+    torch.cuda.synchronize()
+    iv = []
+    for e in engs:
+        e.profile(False)
+        t0, t1 = e.profile_intervals("rx_sync")
+        iv += list(zip(t0.tolist(), t1.tolist()))
+        e.profile_ref(0)
+    iv.sort()
+    union, cur0, cur1 = 0.0, None, None
+    for a, b in iv:
+        if cur1 is None or a > cur1:
+            if cur1 is not None: union += cur1 - cur0
+            cur0, cur1 = a, b
+        else:
+            cur1 = max(cur1, b)
+    if cur1 is not None: union += cur1 - cur0
+    total = sum(b - a for a, b in iv)
+    fl = r["executed_flop_per_launch"] * len(iv)
+    ach = fl / (union * 1e-3) / 1e12
+    r["alone"] = {"avg_launch_ms": r["avg_launch_ms"], "achieved": r["achieved"], "frac": r["frac"], "note": "one launch with the chip to itself (the leg above)"}
+    r["pipelined"] = {"launches": len(iv), "avg_launch_ms_overlapped": total / max(len(iv), 1), "busy_union_ms_per_launch": union / max(len(iv), 1),
+                      "mean_concurrency": total / union if union else 0.0, "achieved": ach, "frac": ach / F32_PEAK_TFLOPS,
+                      "note": "receiver launches of all engines in flight on one time axis (HIP events, rade_batch_profile_intervals); achieved = launches x executed FLOP per launch / time with at least one receiver launch running"}
+    # the line's (achieved, frac) describe the timed configuration; the single-launch figures stay beside them
+    r["achieved"], r["frac"] = ach, ach / F32_PEAK_TFLOPS
+    r["avg_launch_ms"] = union / max(len(iv), 1)
+    r["avg_launch_ms_note"] = "busy time of the receiver kernel per launch in the timed (pipelined) configuration; alone.avg_launch_ms = one launch by itself; pipelined.avg_launch_ms_overlapped = event duration of a launch sharing the chip"
+
+
+def parity_leg(feats_np, fo, st, rx, blob, local, B, rx_flags=0):
     """The oracle on the timed workload itself: the received samples of a few streams of the LAST timed step (device Philox noise
     included) are copied back and run through the CPU oracle; the same samples are replayed through a small traced engine, which
     must reproduce the timed engine's features bit for bit and the oracle's per-call discrete outputs exactly."""
@@ -354,7 +405,7 @@ def parity_leg(feats_np, fo, st, rx, blob, local, B):
     m = O.Model()
     idx = sorted({0, B // 3, (2 * B) // 3, B - 1})
     rx_host = rx[idx].cpu().numpy()
-    e2 = BatchEngine(len(idx), max_tx_mf=1, device=local, blob_bytes=blob, rx_trace_calls=128)
+    e2 = BatchEngine(len(idx), max_tx_mf=1, device=local, blob_bytes=blob, rx_trace_calls=128, flags=rx_flags)       # the same receiver kernel as the timed engines
     fo2, st2, _ = e2.rx(rx[idx].contiguous())
     torch.cuda.synchronize()
     keys = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]

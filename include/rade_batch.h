@@ -159,6 +159,10 @@ enum { RADE_PROF_GEMM = 0, RADE_PROF_SCAN, RADE_PROF_MOD, RADE_PROF_CHAN, RADE_P
 void rade_batch_profile(rade_batch *h, int enable);
 /* accumulated since enable: device milliseconds, algorithmic FLOPs, launches */
 int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches);
+/* every profiled launch of a class as [start, end] in ms after a caller-supplied hipEvent_t (so that launches of several engines, which
+ * may overlap on the device, can be put on one time axis): set the reference before enabling, read after disabling; returns the count */
+void rade_batch_profile_ref(rade_batch *h, void *ref_event);
+int rade_batch_profile_intervals(rade_batch *h, int cls, float *t0_ms, float *t1_ms, int max);
 
 /* ---- several GPUs from one host process (BASELINE.json configs[3]: 2048 utterances over 8 MI355X) -------------------
  * The n_streams_total independent utterances are sharded contiguously over the devices of device_mask (bit g = HIP device g),

@@ -30,11 +30,12 @@ typedef struct { float *wp, *bias; unsigned short *wp16, *wa16; float *wscale, *
 #define ON_DEV(h) do { if (h) (void)hipSetDevice((h)->device); } while (0)
 
 #define RADE_PROF_MAXEV 256   /* launches recorded per profiled interval before the events are drained */
+#define RADE_PROF_MAXIV 4096  /* launch intervals kept per profiling session (rade_batch_profile_intervals) */
 struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
     int unsync_off_after;                 /* int(disable_unsync * Fs / Nmf) or -1 */
-    float *fftG, *ffttw; unsigned short *corr16; double *vm; int rx_variant;
+    float *fftG, *ffttw, *wfwd_t; unsigned short *corr16; double *vm; int rx_variant;
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -56,6 +57,8 @@ struct rade_batch {
     /* optional per-kernel-class timing with HIP events (bench.py roofline leg; never on in timed runs) */
     int prof_on, prof_cnt; hipEvent_t prof_ev[2 * RADE_PROF_MAXEV]; int prof_cls[RADE_PROF_MAXEV]; double prof_fl[RADE_PROF_MAXEV];
     double prof_ms[RADE_PROF_NCLASS], prof_flops[RADE_PROF_NCLASS]; long prof_n[RADE_PROF_NCLASS];
+    /* optional: absolute start / end of every profiled launch relative to a caller-supplied event (launches of several engines on one time axis) */
+    hipEvent_t prof_ref; int iv_n; int iv_cls[RADE_PROF_MAXIV]; float iv_t0[RADE_PROF_MAXIV], iv_t1[RADE_PROF_MAXIV];
     long rx_calls_search, rx_calls_sync;
     /* encoder in two time chunks on two HIP streams (encode_core): the side stream and the events that order the chunks */
     int enc_chunks; hipStream_t enc_side; hipEvent_t ev_fork, ev_join, ev_scan[5];
@@ -203,6 +206,10 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         unsigned short *c16 = malloc(sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8);
         if (c16) { rd_corr16_table_fill(tab, c16); h->corr16 = dev_upload(c16, sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8); free(c16); }
     }
+    {   /* Wfwd carrier-major for k_rx_sync2 */
+        float *wt = malloc(sizeof(float) * RD_NC * RD_M * 2);
+        if (wt) { for (int c = 0; c < RD_NC; c++) for (int n = 0; n < RD_M; n++) { wt[(c * RD_M + n) * 2] = tab->Wfwd[n][c][0]; wt[(c * RD_M + n) * 2 + 1] = tab->Wfwd[n][c][1]; } h->wfwd_t = dev_upload(wt, sizeof(float) * RD_NC * RD_M * 2); free(wt); }
+    }
     free(tab);
     {   /* ((n - 79.5) / 80)^m, m = 0..7, by repeated multiplication (the order the kernels build their LDS copy in) */
         double vm[8][RD_M];
@@ -212,7 +219,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     /* receiver kernel: 1 = one stream per CU (k_rx_sync), 2 = two streams per CU (k_rx_sync2) */
     h->rx_variant = getenv("RADE_RX_VARIANT") ? atoi(getenv("RADE_RX_VARIANT")) : ((cfg->flags & RADE_BATCH_RX_TWO_PER_CU) ? 2 : 1);
     if (h->rx_variant != 2) h->rx_variant = 1;
-    if (!h->d_tab || !h->fftG || !h->ffttw || !h->corr16 || !h->vm) goto fail;
+    if (!h->d_tab || !h->fftG || !h->ffttw || !h->corr16 || !h->vm || !h->wfwd_t) goto fail;
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
@@ -310,7 +317,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16, h->vm, h->chan_mp };
+                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16, h->vm, h->chan_mp, h->wfwd_t };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -339,6 +346,10 @@ static void prof_drain(rade_batch *h)
         float ms = 0;
         if (hipEventSynchronize(h->prof_ev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]) == hipSuccess) {
             h->prof_ms[h->prof_cls[i]] += ms; h->prof_flops[h->prof_cls[i]] += h->prof_fl[i]; h->prof_n[h->prof_cls[i]]++;
+            float t0 = 0;
+            if (h->prof_ref && h->iv_n < RADE_PROF_MAXIV && hipEventElapsedTime(&t0, h->prof_ref, h->prof_ev[2 * i]) == hipSuccess) {
+                h->iv_cls[h->iv_n] = h->prof_cls[i]; h->iv_t0[h->iv_n] = t0; h->iv_t1[h->iv_n] = t0 + ms; h->iv_n++;
+            }
         }
     }
     h->prof_cnt = 0;
@@ -352,7 +363,18 @@ void rade_batch_profile(rade_batch *h, int enable)
     ON_DEV(h);
     if (!enable && h->prof_on) prof_drain(h);
     h->prof_on = enable;
-    if (enable) { h->prof_cnt = 0; memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_flops, 0, sizeof h->prof_flops); memset(h->prof_n, 0, sizeof h->prof_n); }
+    if (enable) { h->prof_cnt = 0; h->iv_n = 0; memset(h->prof_ms, 0, sizeof h->prof_ms); memset(h->prof_flops, 0, sizeof h->prof_flops); memset(h->prof_n, 0, sizeof h->prof_n); }
+}
+/* launches of class `cls` since profiling was enabled as [start, end] in ms after `ref_event` (a hipEvent_t of the caller, recorded and
+ * complete before the first launch): call rade_batch_profile_ref before enabling, read the intervals after disabling */
+void rade_batch_profile_ref(rade_batch *h, void *ref_event) { h->prof_ref = (hipEvent_t)ref_event; }
+int rade_batch_profile_intervals(rade_batch *h, int cls, float *t0_ms, float *t1_ms, int max)
+{
+    ON_DEV(h);
+    prof_drain(h);
+    int n = 0;
+    for (int i = 0; i < h->iv_n && n < max; i++) if (h->iv_cls[i] == cls) { t0_ms[n] = h->iv_t0[i]; t1_ms[n] = h->iv_t1[i]; n++; }
+    return n;
 }
 int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches)
 {
@@ -606,7 +628,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
     sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
-    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.variant = h->rx_variant;
+    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd_t = h->wfwd_t; sa.variant = h->rx_variant;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
     sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only

@@ -88,7 +88,7 @@ EXPORTED_SYMBOLS = [
     # include/rade_batch.h
     "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_set_eoo_bits",
     "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_tx_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
-    "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get",
+    "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get", "rade_batch_profile_ref", "rade_batch_profile_intervals",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
     "rade_batch_rx_stream_cycles",
     "rade_multi_open", "rade_multi_close", "rade_multi_n_devices", "rade_multi_transport", "rade_multi_engine", "rade_multi_shard", "rade_multi_foreach",
@@ -146,6 +146,17 @@ class BatchEngine:
 
     def profile(self, enable: bool):
         self.lib.rade_batch_profile(self.h, int(enable))
+
+    def profile_ref(self, event_handle: int):
+        """absolute launch intervals (profile_intervals) are measured from this hipEvent_t (e.g. torch.cuda.Event(enable_timing=True).cuda_event after record())"""
+        self.lib.rade_batch_profile_ref.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.rade_batch_profile_ref(self.h, C.c_void_p(event_handle))
+
+    def profile_intervals(self, cls_name: str, max_n: int = 4096):
+        self.lib.rade_batch_profile_intervals.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        t0 = np.zeros(max_n, np.float32); t1 = np.zeros(max_n, np.float32)
+        n = self.lib.rade_batch_profile_intervals(self.h, self.PROF_CLASSES.index(cls_name), t0.ctypes.data_as(C.c_void_p), t1.ctypes.data_as(C.c_void_p), max_n)
+        return t0[:n].astype(np.float64), t1[:n].astype(np.float64)
 
     def profile_get(self):
         out = {}
