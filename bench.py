@@ -5,16 +5,20 @@ Workload (BASELINE.json configs[2]): 256 synthetic uttera
 frames (84 modem frames, 10.08 s) each, model19_check3 weights, MPP Doppler-spread two-path channel,
 AWGN at Eb/No = 3 dB, -11 Hz offset, 1 s of noise prepended, EOO frame + 1152 samples appended.
 A "step" = that whole batch once, starting from reset encoder/receiver state, inputs (features, G)
-already resident in HBM.  N > 1: one process per GPU (torchrun), utterances sharded with no data-path
+already resident in HBM.  `--gpus N` > 1: one process per GPU -- started by this script itself under
+torch.distributed.run, or by the caller (WORLD_SIZE must then equal --gpus) -- utterances sharded with no data-path
 collective; the only collective is the RCCL broadcast of the weight blob.
+Defaults: the receiver kernel with two streams per CU (k_rx_sync2) and three batches in flight.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
 `--config 2` instead measures BASELINE.json configs[1] (one stream through the rade_core.h-level encoder / decoder,
 latency-bound by construction) and prints its own line.
 
-roofline block (DESIGN.md 5): `frac` prices the work the dominant kernel EXECUTES (FFT correlator, decoder, in-sync
-DSP -- the constants below) at the f32 peak; the reference-formulation figure (98 MFLOP of GEMM per search call that this
-kernel never performs in that form) is reported separately as `equiv_ref_formulation` and is not a roofline.
+roofline block (DESIGN.md 3.5): `frac` prices the work the dominant kernel EXECUTES (FFT correlator, decoder, in-sync
+DSP -- the constants below) at the f32 peak, over the time that kernel is busy in the TIMED configuration (launches of the
+batches in flight overlap); `alone` = one launch by itself, `whole_job` = every kernel's executed work x frames/s.  The
+reference-formulation figure (98 MFLOP of GEMM per search call that this kernel never performs in that form) is reported
+separately as `equiv_ref_formulation` and is not a roofline.
 """
 import argparse
 import json

@@ -27,12 +27,15 @@ pass l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 # 3b. the other configurations and variants (plain lines, no profiler): configs[1] alone, the two-streams-per-CU receiver at 2 and 3 batches in flight,
 #     configs 1 and 5 rates, rocprofv3 stats of the single-stream step kernels
 python $R/bench.py --config 2 > $O/bench_config2.json 2> $O/bench_config2.err
-for p in 2 3; do RADE_RX_VARIANT=2 python $R/bench.py --steps 60 --pipeline $p --no-cpu-baseline > $O/bench_rx2_p$p.json 2> /dev/null; done
-python $R/bench.py --steps 60 --pipeline 3 --no-cpu-baseline > $O/bench_rx1_p3.json 2> /dev/null
+for p in 2 3; do python $R/bench.py --steps 60 --rx-kernel 1 --pipeline $p --no-cpu-baseline > $O/bench_rx1_p$p.json 2> /dev/null; done      # the one-stream-per-CU receiver (round 2's configuration at p = 2)
+python $R/bench.py --steps 60 --pipeline 2 --no-cpu-baseline > $O/bench_rx2_p2.json 2> /dev/null
+python $R/bench.py --steps 60 --two-pass-channel --no-cpu-baseline > $O/bench_two_pass_channel.json 2> /dev/null
+python $R/tools/rx2_stress.py > $O/rx2_stress.json 2> /dev/null
 python $R/tools/config_rates.py > $O/config_rates.txt 2>&1; cp $R/gpurun_out/config_rates.json $O/ 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python $R/bench.py --config 2 > /dev/null 2> $O/stats_c2.err
 RADE_RX_VARIANT=2 python $R/tools/stream_cycles.py > $O/stream_cycles_rx2.json 2> /dev/null
+RADE_RX_VARIANT=1 python $R/tools/stream_cycles.py > $O/stream_cycles_rx1.json 2> /dev/null
 # 4. per-stream duration of the receiver launch (tail analysis) and the receiver's traffic by source
-python $R/tools/stream_cycles.py > $O/stream_cycles.json 2> $O/stream_cycles.err
+RADE_RX_VARIANT=2 python $R/tools/stream_cycles.py > $O/stream_cycles.json 2> $O/stream_cycles.err
 find $O -name "*.csv" | head -30
 tail -c 400 $O/bench_line.json

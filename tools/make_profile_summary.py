@@ -12,7 +12,7 @@ if pp: shutil.copy(pp[0], os.path.join(dst, tag + "_bench_pipelined_kernel_stats
 pc = glob.glob(os.path.join(src, "stats_c2", "**", "c2_kernel_stats.csv"), recursive=True)
 if pc: shutil.copy(pc[0], os.path.join(dst, tag + "_config2_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "config_rates.json")): shutil.copy(os.path.join(src, "config_rates.json"), os.path.join(dst, tag + "_config_rates.json"))
-for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles", "bench_config2", "bench_rx2_p2", "bench_rx2_p3", "bench_rx1_p3", "stream_cycles_rx2"):
+for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles", "bench_config2", "bench_rx2_p2", "bench_rx1_p2", "bench_rx1_p3", "bench_two_pass_channel", "stream_cycles_rx2", "stream_cycles_rx1", "rx2_stress"):
     if not os.path.exists(os.path.join(src, name + ".json")): continue
     line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
@@ -61,15 +61,19 @@ for k in mf:
 # where k_rx_sync's counter bytes go (per launch): what can be computed from the call counts of the un-profiled bench line, the rest by difference
 try:
     bl = json.load(open(os.path.join(dst, tag + "_bench_line.json")))
-    c = bl["roofline"]["per_launch_counts"]; k = out["kernels"]["k_rx_sync"]; B = bl["config"]["streams_per_gpu"]
+    rxk = "k_rx_sync2" if "k_rx_sync2" in out["kernels"] else "k_rx_sync"
+    c = bl["roofline"]["per_launch_counts"]; k = out["kernels"][rxk]; B = bl["config"]["streams_per_gpu"]
     surf = 960 * 40 * 4
     rd = {"rx samples in (algorithmic)": 640.0 * c["offered_frames"], "|Dt| surface of the previous search call (dtcache)": c["search_calls"] * surf,
           "per-stream state at launch start": B * 33e3, "decoder latents / history (zrows, hist)": c["decoded_modem_frames"] * 960 + c["decoded_modem_frames"] / 8 * 2944 * 1.0}
     wr = {"features out (algorithmic)": 144.0 * 12 * c["decoded_modem_frames"], "|Dt| surface written by every search call (dtcache)": c["search_calls"] * surf,
           "per-stream state at launch end": B * 33e3, "decoder latents, 84-float rows, history": c["decoded_modem_frames"] * (960 + 1008) + c["decoded_modem_frames"] / 8 * 2944}
+    if rxk == "k_rx_sync2":          # rx_buf + row sums parked in HBM while the decoder stage runs (every 8 frames): 24.6 KB out and back
+        rd["rx_buf / row sums back from HBM after each decoder stage"] = c["decoded_modem_frames"] / 8 * 24576
+        wr["rx_buf / row sums parked in HBM during each decoder stage"] = c["decoded_modem_frames"] / 8 * 24576
     rd["remainder: L2 misses on weights / FFT tables / pilot planes + scratch reloads"] = k["fetch_bytes_per_dispatch"] - sum(rd.values())
     wr["remainder: scratch spills (about 2.5 M wave-stores of 256 B)"] = k["write_bytes_per_dispatch"] - sum(wr.values())
-    out["rx_sync_traffic_breakdown_bytes_per_launch"] = {"fetch_raw": k["fetch_bytes_per_dispatch"], "write_raw": k["write_bytes_per_dispatch"], "fetch": rd, "write": wr,
+    out["rx_sync_traffic_breakdown_bytes_per_launch"] = {"kernel": rxk, "fetch_raw": k["fetch_bytes_per_dispatch"], "write_raw": k["write_bytes_per_dispatch"], "fetch": rd, "write": wr,
         "algorithmic_io_bytes": 784.0 * c["offered_frames"], "ratio_raw_over_io": (k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]) / (784.0 * c["offered_frames"]),
         "ratio_raw_over_io_plus_search_state": (k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]) / (784.0 * c["offered_frames"] + 2 * c["search_calls"] * surf),
         "note": "the |Dt| surface (960 x 40 float32 = 153.6 KB) a search call leaves for the next one is state the reference's algorithm defines (dsp.py keeps Dt1/Dt2 between calls); it does not fit beside the FFT work area in LDS and must stay float32 for the arg-max to stay bit-exact"}
