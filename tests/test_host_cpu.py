@@ -229,6 +229,32 @@ def test_host_blob_reader_and_packing(lib, golden):
     assert np.sort(out[out != 0]).tolist() == np.sort(W.ravel()).tolist()
 
 
+def test_chunk_major_packing_for_the_single_stream_kernel(lib):
+    """rd_chunkmajor_q16 / rd_chunkmajor_f32 (rade_core_step.hip's operand layout): out[(c * Npad + n) * 8 + j] = W[n][8 c + j], rows and K zero-padded;
+    the binary16 plane holds the integers of an int8 x scale layer exactly and refuses anything else."""
+    rng = np.random.default_rng(11)
+    N, K, Kpad, Npad = 80, 84, 88, 128
+    q = rng.integers(-127, 128, size=(N, K)).astype(np.float32)
+    sc = (rng.uniform(0.001, 0.02, size=N)).astype(np.float32)
+    W = (q * sc[:, None]).astype(np.float32)
+    out = np.zeros(Npad * Kpad, np.uint16)
+    lib.rd_chunkmajor_q16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]; lib.rd_chunkmajor_q16.restype = C.c_int
+    assert lib.rd_chunkmajor_q16(W.ctypes.data, sc.ctypes.data, N, K, Kpad, Npad, out.ctypes.data) == 0
+    got = out.view(np.float16).astype(np.float32).reshape(Kpad // 8, Npad, 8)
+    exp = np.zeros((Kpad // 8, Npad, 8), np.float32)
+    for c in range(Kpad // 8):
+        for j in range(8):
+            if 8 * c + j < K: exp[c, :N, j] = q[:, 8 * c + j]
+    assert np.array_equal(got, exp)
+    W2 = W.copy(); W2[3, 5] *= np.float32(1.0001)                  # not an integer multiple of its row scale any more
+    assert lib.rd_chunkmajor_q16(W2.ctypes.data, sc.ctypes.data, N, K, Kpad, Npad, out.ctypes.data) != 0
+    outf = np.zeros(Npad * Kpad, np.float32)
+    lib.rd_chunkmajor_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]; lib.rd_chunkmajor_f32.restype = None
+    lib.rd_chunkmajor_f32(W.ctypes.data, N, K, Kpad, Npad, outf.ctypes.data)
+    gf = outf.reshape(Kpad // 8, Npad, 8)
+    assert all(np.array_equal(gf[c, :N, j], W[:, 8 * c + j]) for c in range(Kpad // 8) for j in range(8) if 8 * c + j < K) and not gf[:, N:, :].any() and not gf[-1, :, 4:].any()
+
+
 def test_host_blob_reader_rejects_hostile_headers(lib):
     """The blob path is caller-controlled (rade_open argument / $RADE_MODEL_FILE): record headers with negative or
     inconsistent sizes, wild sparse-index entries and zero-sized arrays must be refused before anything is written."""
