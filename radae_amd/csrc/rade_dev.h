@@ -165,6 +165,7 @@ typedef struct {
     float *out; long out_sb; int out_w;        /* [B][.][84] */
     rd_lin dense1, gin[5], glu[5], conv[5], output;
     const float *whh[5], *bhh[5];
+    const unsigned short *whq[5]; const float *whs[5];   /* W_hh as int8-exact A-operand fragments (rd_pack_weights_q16_a16) + row scales, or NULL: k_rx_sync2 runs the recurrence on the matrix cores (dq2_scan_mfma) */
     int B;
 } rd_decs_args;
 

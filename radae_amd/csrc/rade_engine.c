@@ -42,6 +42,7 @@ struct rade_batch {
     /* weights */
     dev_lin enc_dense1, enc_zdense, dec_dense1, dec_output, enc_gin[5], dec_gin[5], enc_conv[5], dec_conv[5], dec_glu[5];
     float *enc_whh[5], *enc_bhh[5], *dec_whh[5], *dec_bhh[5];
+    unsigned short *dec_whq[5]; float *dec_whs[5];      /* decoder W_hh as matrix-core fragments (int8-exact) + row scales; NULL when the blob's recurrent weights are not int8 x scale */
     /* transmit side */
     float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
     void *chan_scratch; void *chan_mp;        /* chan_mp [B][max_tx_mf * 960] c64: multipath output of the fused modulator (rade_batch_tx_channel), allocated on first use */
@@ -237,6 +238,12 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         h->enc_bhh[l] = dev_upload(m.enc_gru[l].b_hh, sizeof(float) * 192);
         h->dec_whh[l] = dev_upload(m.dec_gru[l].w_hh, sizeof(float) * 288 * 96);
         h->dec_bhh[l] = dev_upload(m.dec_gru[l].b_hh, sizeof(float) * 288);
+        if (m.dec_gru[l].s_hh && !getenv("RADE_NO_SCAN_MFMA")) {
+            unsigned short *pa = malloc(sizeof(unsigned short) * rd_packed16a_size(288, 96)); float *scl = malloc(sizeof(float) * 288);
+            const long nq = (pa && scl) ? rd_pack_weights_q16_a16(m.dec_gru[l].w_hh, m.dec_gru[l].s_hh, 288, 96, pa, scl) : -1;
+            if (nq > 0) { h->dec_whq[l] = dev_upload(pa, sizeof(unsigned short) * nq); h->dec_whs[l] = dev_upload(scl, sizeof(float) * 288); }
+            free(pa); free(scl);
+        }
         if (!h->enc_whh[l] || !h->enc_bhh[l] || !h->dec_whh[l] || !h->dec_bhh[l]) err = -1;
     }
     if (err) { fprintf(stderr, "rade: weight upload failed\n"); goto fail; }
@@ -322,8 +329,8 @@ void rade_batch_close(rade_batch *h)
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
         free_lin(&h->enc_gin[l]); free_lin(&h->dec_gin[l]); free_lin(&h->enc_conv[l]); free_lin(&h->dec_conv[l]); free_lin(&h->dec_glu[l]);
-        void *p[] = { h->enc_whh[l], h->enc_bhh[l], h->dec_whh[l], h->dec_bhh[l], h->enc_h[l], h->dec_h[l], h->dec2_h[l] };
-        for (int i = 0; i < 7; i++) if (p[i]) hipFree(p[i]);
+        void *p[] = { h->enc_whh[l], h->enc_bhh[l], h->dec_whh[l], h->dec_bhh[l], h->enc_h[l], h->dec_h[l], h->dec2_h[l], h->dec_whq[l], h->dec_whs[l] };
+        for (int i = 0; i < 9; i++) if (p[i]) hipFree(p[i]);
     }
     if (h->h_small) hipHostFree(h->h_small);
     if (h->enc_side) hipStreamDestroy(h->enc_side);
@@ -587,7 +594,8 @@ static void fill_dec_args(const rade_batch *h, rd_decs_args *d)
     d->B = h->B;
 #define LIN(dst, src) do { (dst).wp = (src).wp; (dst).bias = (src).bias; (dst).wp16 = (src).wp16; (dst).wa16 = (src).wa16; (dst).wscale = (src).wscale; (dst).N = (src).N; (dst).K = (src).K; } while (0)
     LIN(d->dense1, h->dec_dense1); LIN(d->output, h->dec_output);
-    for (int l = 0; l < 5; l++) { LIN(d->gin[l], h->dec_gin[l]); LIN(d->glu[l], h->dec_glu[l]); LIN(d->conv[l], h->dec_conv[l]); d->whh[l] = h->dec_whh[l]; d->bhh[l] = h->dec_bhh[l]; d->h[l] = h->dec_h[l]; }
+    for (int l = 0; l < 5; l++) { LIN(d->gin[l], h->dec_gin[l]); LIN(d->glu[l], h->dec_glu[l]); LIN(d->conv[l], h->dec_conv[l]); d->whh[l] = h->dec_whh[l]; d->bhh[l] = h->dec_bhh[l]; d->h[l] = h->dec_h[l];
+                                  d->whq[l] = (h->dec_whq[l] && h->dec_whs[l]) ? h->dec_whq[l] : NULL; d->whs[l] = h->dec_whs[l]; }
 #undef LIN
 }
 
@@ -628,7 +636,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
     sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
-    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd_t = h->wfwd_t; sa.variant = h->rx_variant;
+    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd_t = h->wfwd_t; sa.variant = h->rx_variant | (getenv("RADE_RX2_CENSUS") ? atoi(getenv("RADE_RX2_CENSUS")) << 8 : 0);   /* the mask only acts in -DRX2_CENSUS developer builds */
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
     sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only

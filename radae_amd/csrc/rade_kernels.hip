@@ -2711,7 +2711,7 @@ extern "C" int rd_launch_rx_sync2(const rd_sync_args *a, rd_stream_t s);      /*
 extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
 {
     if (a->B <= 0) return 0;
-    if (a->variant == 2) return rd_launch_rx_sync2(a, s);
+    if ((a->variant & 0xff) == 2) return rd_launch_rx_sync2(a, s);
     static int attr_set_dev[64];                     // the attribute is per device (one engine per GPU in a multi-GPU host process)
     int dev_ = 0; (void)hipGetDevice(&dev_);
     if (!attr_set_dev[dev_ & 63]) { (void)hipFuncSetAttribute((const void *)k_rx_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RxShared)); attr_set_dev[dev_ & 63] = 1; }
