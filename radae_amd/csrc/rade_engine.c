@@ -141,15 +141,17 @@ static void rx_reset_on(rade_batch *h, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     rd_launch_rx_reset(h->rx_st, h->d_lcg_seeds, (h->flags & RADE_FOFF_TEST) ? 10.0 : 0.0 /* rade_api.c:263-264 */, h->B, st);
-    for (int l = 0; l < 5; l++) hipMemsetAsync(h->dec_h[l], 0, sizeof(float) * h->B * 96, st);
-    hipMemsetAsync(h->dec_x, 0, sizeof(float) * (size_t)h->B * (1 + h->dec_rows) * RD_DEC_W, st);
+    hipMemsetAsync(h->dec_h[0], 0, sizeof(float) * 5 * h->B * 96, st);                         /* the five layers' states are one allocation */
+    /* only a stream's history row has to start from zero: every other row of dec_x is written before it is read */
+    hipMemset2DAsync(h->dec_x, sizeof(float) * (size_t)(1 + h->dec_rows) * RD_DEC_W, 0, sizeof(float) * RD_DEC_W, h->B, st);
     if (h->trace) { hipMemsetAsync(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap, st); hipMemsetAsync(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF, st); }
 }
 static void tx_reset_on(rade_batch *h, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    for (int l = 0; l < 5; l++) hipMemsetAsync(h->enc_h[l], 0, sizeof(float) * h->B * 64, st);
-    hipMemsetAsync(h->enc_x, 0, sizeof(float) * (size_t)h->B * (2 + h->Tcap) * RD_ENC_W, st);
+    hipMemsetAsync(h->enc_h[0], 0, sizeof(float) * 5 * h->B * 64, st);
+    /* the two history rows of each stream (conv taps before the first frame); rows 2.. are written layer by layer before they are read */
+    hipMemset2DAsync(h->enc_x, sizeof(float) * (size_t)(2 + h->Tcap) * RD_ENC_W, 0, sizeof(float) * 2 * RD_ENC_W, h->B, st);
 }
 
 void rade_batch_rx_reset(rade_batch *h) { ON_DEV(h); rx_reset_on(h, NULL); hipDeviceSynchronize(); }
@@ -255,7 +257,9 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
     h->eoo_bits = dev_zeros(sizeof(float) * B * RD_NEOOBITS);
     h->chan_scratch = dev_zeros(sizeof(double) * B * (cfg->max_tx_mf > 64 ? cfg->max_tx_mf : 64) * 2);
-    for (int l = 0; l < 5; l++) { h->enc_h[l] = dev_zeros(sizeof(float) * B * 64); h->dec_h[l] = dev_zeros(sizeof(float) * B * 96); if (!h->enc_h[l] || !h->dec_h[l]) goto fail; }
+    h->enc_h[0] = dev_zeros(sizeof(float) * 5 * B * 64); h->dec_h[0] = dev_zeros(sizeof(float) * 5 * B * 96);
+    if (!h->enc_h[0] || !h->dec_h[0]) goto fail;
+    for (int l = 1; l < 5; l++) { h->enc_h[l] = h->enc_h[0] + (size_t)l * B * 64; h->dec_h[l] = h->dec_h[0] + (size_t)l * B * 96; }
     h->rx_st = dev_zeros(sizeof(rd_rx_stream) * B);
     h->rx_round = dev_zeros(sizeof(rd_rx_round) * B);
     h->rx_avail = dev_zeros(sizeof(int) * B); h->rx_acc = dev_zeros(sizeof(int) * B * 4); h->rx_progress = dev_zeros(sizeof(int) * 4);
@@ -269,7 +273,9 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->dec2_x = dev_zeros(sizeof(float) * B * (1 + T) * RD_DEC_W);
     h->dec2_gi = dev_zeros(sizeof(float) * B * T * 288);
     h->dec2_hbuf = dev_zeros(sizeof(float) * B * T * 96);
-    for (int l = 0; l < 5; l++) { h->dec2_h[l] = dev_zeros(sizeof(float) * B * 96); if (!h->dec2_h[l]) goto fail; }
+    h->dec2_h[0] = dev_zeros(sizeof(float) * 5 * B * 96);
+    if (!h->dec2_h[0]) goto fail;
+    for (int l = 1; l < 5; l++) h->dec2_h[l] = h->dec2_h[0] + (size_t)l * B * 96;
     if (!h->dec2_x || !h->dec2_gi || !h->dec2_hbuf) goto fail;
     h->dtcache = dev_zeros(sizeof(float) * B * 2 * RD_NMF * RD_NFC);
     if (!h->enc_xin || !h->enc_x || !h->enc_gi || !h->enc_z || !h->eoo || !h->eoo_bits || !h->chan_scratch || !h->rx_st || !h->rx_round || !h->rx_avail ||
@@ -329,7 +335,7 @@ void rade_batch_close(rade_batch *h)
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
         free_lin(&h->enc_gin[l]); free_lin(&h->dec_gin[l]); free_lin(&h->enc_conv[l]); free_lin(&h->dec_conv[l]); free_lin(&h->dec_glu[l]);
-        void *p[] = { h->enc_whh[l], h->enc_bhh[l], h->dec_whh[l], h->dec_bhh[l], h->enc_h[l], h->dec_h[l], h->dec2_h[l], h->dec_whq[l], h->dec_whs[l] };
+        void *p[] = { h->enc_whh[l], h->enc_bhh[l], h->dec_whh[l], h->dec_bhh[l], l ? NULL : h->enc_h[0], l ? NULL : h->dec_h[0], l ? NULL : h->dec2_h[0], h->dec_whq[l], h->dec_whs[l] };
         for (int i = 0; i < 9; i++) if (p[i]) hipFree(p[i]);
     }
     if (h->h_small) hipHostFree(h->h_small);
@@ -605,7 +611,7 @@ int rade_batch_decode(rade_batch *h, const float *z_dev, int n_steps, float *fea
     if (!h || n_steps <= 0 || n_steps > h->Tcap || !features_out_dev) return -1;
     hipStream_t st = (hipStream_t)stream;
     if (reset_state) {
-        for (int l = 0; l < 5; l++) hipMemsetAsync(h->dec2_h[l], 0, sizeof(float) * h->B * 96, st);
+        hipMemsetAsync(h->dec2_h[0], 0, sizeof(float) * 5 * h->B * 96, st);
         hipMemsetAsync(h->dec2_x, 0, sizeof(float) * (size_t)h->B * (1 + h->Tcap) * RD_DEC_W, st);
     }
     int e = decoder_layers(h, z_dev, n_steps, n_steps, h->Tcap, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->dec2_h, NULL, NULL, features_out_dev, stream);
