@@ -1472,6 +1472,7 @@ struct RxScalars {
     int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
     float snr_est, mag; float2 bpf_phase;
     double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
+    double rph_th;                        // k_rx_sync2: the phase accumulator as an angle in [-pi, pi] (rph_r + j rph_i = e^{j rph_th})
 };
 
 struct RxShared {
