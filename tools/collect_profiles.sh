@@ -37,5 +37,11 @@ RADE_RX_VARIANT=2 python $R/tools/stream_cycles.py > $O/stream_cycles_rx2.json 2
 RADE_RX_VARIANT=1 python $R/tools/stream_cycles.py > $O/stream_cycles_rx1.json 2> /dev/null
 # 4. per-stream duration of the receiver launch (tail analysis) and the receiver's traffic by source
 RADE_RX_VARIANT=2 python $R/tools/stream_cycles.py > $O/stream_cycles.json 2> $O/stream_cycles.err
+# 5. developer-build runs (built here beforehand: tools/ab_build.sh census -DRX2_CENSUS ; tools/ab_build.sh timing -DRD_PHASE_TIMING): the per-phase
+#    instruction census of k_rx_sync2, its stall / LDS / instruction-cache counters at one and two workgroups per CU, and the per-phase cycle table
+if [ -f $R/gpu_ab/census.so ]; then bash $R/tools/rx2_census.sh > $O/rx2_census.txt 2>&1; cp $R/gpurun_out/census/census.json $O/rx2_census.json 2>/dev/null; fi
+bash $R/tools/rx2_counters.sh 2 > $O/rx2_counters.txt 2>&1; cp $R/gpurun_out/rxcnt/counters.json $O/rx2_counters.json 2>/dev/null
+cd /tmp
+if [ -f $R/gpu_ab/timing.so ]; then RADE_RX_VARIANT=2 RADE_LIBRADEHIP=$R/gpu_ab/timing.so python $R/tools/phase_timing2.py > $O/phase_timing_rx2.txt 2>/dev/null; fi
 find $O -name "*.csv" | head -30
 tail -c 400 $O/bench_line.json

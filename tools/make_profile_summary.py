@@ -17,6 +17,10 @@ for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line
     line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
 
+for name, ext in (("rx2_census", "json"), ("rx2_counters", "json"), ("phase_timing_rx2", "txt"), ("rx2_census", "txt")):
+    f = os.path.join(src, f"{name}.{ext}")
+    if os.path.exists(f): shutil.copy(f, os.path.join(dst, f"{tag}_{name}.{ext}"))
+
 def load(name):
     fs = glob.glob(os.path.join(src, name, "**", "pmc_counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(set)
