@@ -358,7 +358,8 @@ def test_rx_output_capacity_is_respected(Engine, torch_dev, golden):
     eng.close()
 
 
-def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_model):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync (FFT pilot search) / k_rx_sync2 (pilot search + GRU recurrence on the matrix cores)
+def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_model, rxflags, monkeypatch):
     """tools/parity_sweep.py as a test: random channel (AWGN / MPP / MPD / MPG), Eb/No -1..12 dB, offset +-40 Hz, noise prefix; the oracle makes
     the received samples, both receivers consume exactly those.  Every per-call discrete output must be equal and the features within 1e-4 RMS --
     except for the documented refine() near-tie: all discrete outputs equal, fmax apart by less than 0.05 Hz because two 0.1 Hz bins
@@ -366,6 +367,7 @@ def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_m
     import torch
     from radae_amd.channel_tools import multipath_g, synth_features
     from radae_amd.engine import sigma_from_EbNodB
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     rng = np.random.default_rng(2027)
     n_mf, bad, ties, N = 24, [], 0, 32
     for case in range(N):
@@ -383,7 +385,7 @@ def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_m
         e = oracle.channel_eoo(tx.eoo(), noise[n_pre + n_sig:n_pre + n_sig + 1152], sigma, fo, 0.0, fin)
         full = np.concatenate([sigma * noise[:n_pre], r, e, sigma * noise[-1152:]]).astype(np.complex64)
         d = oracle.run_rx_stream(oracle_model, full)
-        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
+        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
         fo_dev, st, _ = eng.rx(torch.tensor(full[None], device=torch_dev))
         t = eng.rx_trace(0); nv = st[0].n_valid
         eng.close()
@@ -595,8 +597,9 @@ def test_channel_sine_interferer_and_gain(Engine, torch_dev, golden):
     eng.close()
 
 
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync (FFT pilot search) / k_rx_sync2 (pilot search + GRU recurrence on the matrix cores)
 @pytest.mark.parametrize("kind", ["noise", "sine"])
-def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind):
+def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind, rxflags, monkeypatch):
     """The reference's acq_noise / acq_sine ctests (CMakeLists.txt:191-208): real-valued noise, or a 1 kHz sine in noise,
     converted with Q = 0 (int16tof32.py --zeropad), must never synchronise.  12 s per stream, 8 streams with different
     seeds; stream 0 is also checked call by call against the oracle."""
@@ -607,7 +610,8 @@ def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind):
     if kind == "sine":
         x += 0.25 * np.cos(2 * np.pi * 1000.0 / 8000.0 * np.arange(n))[None]
     rx = x.astype(np.float32).astype(np.complex64)                     # Q == 0
-    eng = Engine(B, max_tx_mf=1, rx_trace_calls=128)
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=128, flags=rxflags)
     f, st, _ = eng.rx(torch.tensor(rx, device=torch_dev))
     for b in range(B):
         assert st[b].n_calls == n // 960 and st[b].n_valid == 0 and st[b].sync == 0, (kind, b)
@@ -620,7 +624,8 @@ def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind):
     eng.close()
 
 
-def test_acquisition_statistics_mpp(Engine, torch_dev):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync (FFT pilot search) / k_rx_sync2 (pilot search + GRU recurrence on the matrix cores)
+def test_acquisition_statistics_mpp(Engine, torch_dev, rxflags, monkeypatch):
     """rx.py --acq_test in batch form (rx.py:163-195, ctest acq_mpp): 64 utterances at 0 dB Eb/No on the MPP channel with
     a +10 Hz offset.  Every stream must find sync, in less than 1.5 s of signal on average, with the entry timing inside
     the 2.5 ms window and the coarse frequency within 5 Hz of the truth for at least 80 % of the streams."""
@@ -630,7 +635,8 @@ def test_acquisition_statistics_mpp(Engine, torch_dev):
     B, n_mf, n_pre, fo = 64, 40, 4000, 10.0
     feats = np.stack([synth_features(300 + b, 12 * n_mf) for b in range(B)])
     G = np.stack([multipath_g("mpp", 8000, n_mf * 960, 900 + b) for b in range(B)])
-    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=64)
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
+    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=64, flags=rxflags)
     iq = eng.tx(torch.tensor(feats, device=torch_dev))
     rx = eng.channel(iq, sigma_from_EbNodB(0.0), fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=torch.tensor(G, device=torch_dev), seed=5)
     f, st, _ = eng.rx(rx)
