@@ -721,18 +721,19 @@ def test_core_level_boundary_config2(golden, tmp_path):
     assert ff.shape == (120, 36) and np.array_equal(ff[:, :21], fh) and not ff[:, 21:].any()
 
 
-def test_multi_gpu_c_host_single_device(tmp_path):
+@pytest.mark.parametrize("pipeline", [1, 3])
+def test_multi_gpu_c_host_single_device(tmp_path, pipeline):
     """The C multi-GPU host (hosts/rade_multi_bench over rade_multi_*: RCCL blob broadcast, sharded engines, RCCL all-reduce of the
     statistics) on the one GPU this box has, with the RCCL path forced: the communicator, the broadcast and the all-reduce really run."""
     import json, os, subprocess
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(repo, "hosts", "rade_multi_bench")
     env = dict(os.environ, RADE_MULTI_FORCE_RCCL="1")
-    p = subprocess.run([exe, "--gpus", "1", "--streams-per-gpu", "12", "--frames", "240", "--steps", "2", "--warmup", "1",
+    p = subprocess.run([exe, "--gpus", "1", "--streams-per-gpu", "12", "--frames", "240", "--steps", "4", "--warmup", "1", "--pipeline", str(pipeline),
                         os.path.join(repo, "weights", "model19_check3.bin")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["config"]["collectives"].startswith("rccl")
+    assert line["n_gpus"] == 1 and line["config"]["collectives"].startswith("rccl") and line["config"]["batches_in_flight_per_gpu"] == pipeline
     j = line["job_last_step"]
     assert j["offered_frames"] == 12 * 240 and 0 < j["decoded_frames"] <= j["offered_frames"] and j["rx_calls"] >= 12 * 20
     assert j["samples_consumed"] > 12 * 20 * 800 and line["value"] > 0
