@@ -597,6 +597,29 @@ def test_channel_sine_interferer_and_gain(Engine, torch_dev, golden):
     eng.close()
 
 
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
+def test_impulses_in_the_receive_buffer(Engine, torch_dev, golden, oracle, oracle_model, rxflags, monkeypatch):
+    """Dynamic range: check_pilots (both kernels) and the pilot search of k_rx_sync2 feed the matrix cores with rx_buf in two binary16 planes
+    under ONE power-of-two scale taken from the running maximum of the buffer, so a click 50 .. 90 dB above the signal costs the signal that many
+    bits of the 22.  The MPP golden input with two impulses of 300x / 30000x its RMS (in the noise prefix, and inside the synchronised part)
+    must still give the oracle's discrete outputs call by call and its features."""
+    import torch
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
+    base = golden("rxtrace_mpp")["rx_in"].astype(np.complex64)
+    r = float(np.sqrt(np.mean(np.abs(base) ** 2)))
+    for amp, pos in [(300.0, 5000), (300.0, 20000), (30000.0, 5000), (30000.0, 20000)]:
+        x = base.copy(); x[pos] += amp * r * (1 + 1j) / np.sqrt(2); x[pos + 700] -= amp * r
+        d = oracle.run_rx_stream(oracle_model, x)
+        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
+        fo, st, _ = eng.rx(torch.tensor(x[None], device=torch_dev))
+        t = eng.rx_trace(0); nv = st[0].n_valid
+        eng.close()
+        for k in INT_KEYS:
+            assert np.array_equal(t[k], d[k]), (amp, pos, k)
+        assert nv == len(d["features_out"]) and nv > 0
+        assert rms(fo.cpu().numpy()[0, :nv], d["features_out"]) < 1e-5, (amp, pos)
+
+
 @pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync (FFT pilot search) / k_rx_sync2 (pilot search + GRU recurrence on the matrix cores)
 @pytest.mark.parametrize("kind", ["noise", "sine"])
 def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind, rxflags, monkeypatch):
