@@ -59,6 +59,7 @@ typedef struct {
     int f_ind_max, dec_reset_pending, bpf_mem_len, n_out_frames;
     uint32_t lcg; int has_eoo, dt_valid, pad1;
     double fmax, foff_err, rx_phase[2];
+    double rx_theta;                 /* k_rx_sync2 keeps rx_phase as its angle (rx_phase = e^{j rx_theta}); carried exactly, so results do not depend on how calls are cut into launches */
     double Dthresh, Dtmax12, Dtmax12_eoo;
     float snr_est, bpf_phase[2], pad2;
     unsigned rxmax[4];                  /* float bits: largest |re|,|im| of the filtered samples of the last three calls (check_pilots operand scale) */

@@ -2729,7 +2729,7 @@ __global__ __launch_bounds__(256) void k_rx_reset(rd_rx_stream *st, const unsign
     __syncthreads();
     if (threadIdx.x == 0) {
         s->state = ST_SEARCH; s->nin = RD_NMF; s->mf = 1; s->bpf_mem_len = 100; s->lcg = seeds ? seeds[blockIdx.x] : 1u;
-        s->rx_phase[0] = 1.0; s->bpf_phase[0] = 1.0f; s->foff_err = foff_err;
+        s->rx_phase[0] = 1.0; s->rx_theta = 0.0; s->bpf_phase[0] = 1.0f; s->foff_err = foff_err;
     }
 }
 extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err, int B, rd_stream_t s)

@@ -151,12 +151,14 @@ def test_rx_trace_golden(Engine, torch_dev, golden, name, rxflags, monkeypatch):
     eng.close()
 
 
-def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
+def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden, rxflags, monkeypatch):
     """One do_radae_rx call per invocation (the rade_rx() usage) == the whole stream at once."""
     import torch
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     g = golden("rxtrace_slip_plus")
     x = torch.tensor(g["rx_in"][None], device=torch_dev)
-    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
     fa, sa, _ = eng.rx(x)
     ta = eng.rx_trace(0)
     eng.rx_reset()
@@ -175,7 +177,8 @@ def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden):
     eng.close()
 
 
-def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_model, monkeypatch):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
+def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_model, monkeypatch, rxflags):
     """The decoder stage runs inside the receiver kernel right before each unique-word decision
     (radae_rxe.py:220-224).  A RADE_FOFF_TEST frequency error and low SNR make windows fail.  The result must not
     depend on how the work is cut: one call per launch (RADE_ROUND_CALLS=1), a 3-row decoder buffer (the decoder runs
@@ -183,6 +186,7 @@ def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_mo
     other on everything, and with the oracle on the trace."""
     import torch
     from radae_amd.engine import sigma_from_EbNodB
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     n_mf = 40
     streams = []
     for seed, eb, fo in [(31, 20.0, 5.0), (32, -2.0, -20.0), (33, 1.0, 12.0)]:
@@ -195,7 +199,7 @@ def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_mo
         if mode == "rows3": monkeypatch.setenv("RADE_DEC_ROWS", "3"); monkeypatch.setenv("RADE_ROUND_CALLS", "7")
         out = []
         for i, (feats, G, n_pre, noise, sigma, fo) in enumerate(streams):
-            eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=64, flags=4 if i == 0 else 0)   # stream 0: clean signal, 10 Hz off after sync entry
+            eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=64, flags=rxflags | (4 if i == 0 else 0))   # stream 0: clean signal, 10 Hz off after sync entry
             iq = eng.tx(torch.tensor(feats[None], device=torch_dev))
             rx = eng.channel(iq, sigma, fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=torch.tensor(G[None], device=torch_dev),
                              noise=torch.tensor(noise[None], device=torch_dev))
@@ -338,13 +342,15 @@ def test_unbounded_operands_do_not_overflow(Engine, torch_dev, oracle, oracle_mo
     eng.close()
 
 
-def test_rx_output_capacity_is_respected(Engine, torch_dev, golden):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
+def test_rx_output_capacity_is_respected(Engine, torch_dev, golden, rxflags, monkeypatch):
     """features_out rows are a capacity: a stream that has filled them pauses (consumed < available) instead of writing on;
     continuing with a fresh buffer gives the same frames as one big call."""
     import torch
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     g = golden("rxtrace_awgn")
     x = torch.tensor(g["rx_in"][None], device=torch_dev)
-    eng = Engine(1, max_tx_mf=1)
+    eng = Engine(1, max_tx_mf=1, flags=rxflags)
     full, st, _ = eng.rx(x)
     nv = st[0].n_valid
     assert nv == len(g["features_out"]) and nv > 6
@@ -402,7 +408,8 @@ def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_m
     assert ties <= 3, ties
 
 
-def test_streams_are_independent_and_ragged(Engine, torch_dev, golden):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
+def test_streams_are_independent_and_ragged(Engine, torch_dev, golden, rxflags, monkeypatch):
     """Identical streams give bit-identical outputs whatever their slot; ragged / empty inputs are handled."""
     import torch
     g = golden("rxtrace_awgn")
@@ -412,7 +419,8 @@ def test_streams_are_independent_and_ragged(Engine, torch_dev, golden):
     avail = np.array([len(x), len(x), 5000, 0, 959], np.int32)
     for b in range(B):
         buf[b, :avail[b]] = x[:avail[b]]
-    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64)
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
     feats, st, _ = eng.rx(torch.tensor(buf, device=torch_dev), n_avail=avail)
     assert st[0].n_calls == len(g["ret"]) and st[1].n_calls == st[0].n_calls
     assert torch.equal(feats[0], feats[1])
