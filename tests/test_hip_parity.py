@@ -234,7 +234,8 @@ def _make_stream(seed, n_mf, EbNodB, fo, chan):
     return feats, G, n_pre, noise
 
 
-def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_model):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
+def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_model, rxflags, monkeypatch):
     """4 streams with different channels/offsets, inputs never seen by the golden generator."""
     import torch
     from radae_amd.engine import sigma_from_EbNodB
@@ -243,7 +244,8 @@ def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_mod
     for seed, eb, fo, chan in cases:           # one engine per case: channel parameters are per call, not per stream
         feats, G, n_pre, noise = _make_stream(seed, n_mf, eb, fo, chan)
         sigma = sigma_from_EbNodB(eb)
-        eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=48)
+        monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
+        eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=48, flags=rxflags)
         iq = eng.tx(torch.tensor(feats[None], device=torch_dev))
         Gd = torch.tensor(G[None], device=torch_dev) if G is not None else None
         rx = eng.channel(iq, sigma, fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=Gd, noise=torch.tensor(noise[None], device=torch_dev))
@@ -516,7 +518,8 @@ def test_single_stream_c_abi(golden):
     h.close()
 
 
-def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model):
+@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
+def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model, rxflags, monkeypatch):
     """BASELINE workload size (256 x 1008 frames): properties that do not need the oracle at full size,
     plus the oracle on two of the streams (loss delta < 1e-4)."""
     import torch
@@ -527,7 +530,8 @@ def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model):
     n_mf = T // 12
     base = [synth_features(3000 + u, T) for u in range(8)]
     feats = np.stack([base[b % 8] for b in range(B)])                 # 8 distinct utterances, replicated 32x
-    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=0)
+    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
+    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=0, flags=rxflags)
     iq = eng.tx(torch.tensor(feats, device=torch_dev))
     assert torch.equal(iq[:8], iq[248:256])                           # replicas bit-identical
     mag = iq.abs()
