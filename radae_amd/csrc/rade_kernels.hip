@@ -1500,9 +1500,13 @@ struct RxShared {
             double vm[8][RD_M];               // refine(), in-sync grid: ((n - 79.5) / 80)^m, m = 0..7 (rebuilt with wfwd)
             double rmom[4][2][64][4];         // refine(), in-sync grid: partial moment tiles [quarter of the samples][frame]
         };
-        struct {                          // search / candidate state: FFT pilot correlator
+        struct {                          // search / candidate state: FFT pilot correlator (-DRX1_SEARCH_FFT)
             float2 fftX[FFT_N];           // spectrum of the rx_buf window being correlated
             float fftscr[NT_RX / 64][FFT_SCR];
+        };
+        struct {                          // search / candidate state: pilot search on the matrix cores (rx_detect_mfma)
+            __attribute__((aligned(16))) _Float16 sA[2][5 * 2 * 64 * 8];   // the correlation table's A operands of one k-step, double-buffered
+            unsigned srxh[RD_RXBUF], srxl[RD_RXBUF];                        // rx_buf in two binary16 planes
         };
         };
       };
@@ -2128,6 +2132,156 @@ __device__ __forceinline__ void check_rows_tiles(RxShared *sh, const unsigned sh
 }
 
 #ifndef RADE_RX2_TU
+// ---- |Dt| surfaces on the matrix cores (the pilot search of k_rx_sync2, rade_rx2.inc: rx2_detect_mfma -- see there and DESIGN.md 3.9 for the method) in
+// this kernel's shape: wavefronts 0..3 (one per SIMD) own the 60 timing tiles exactly as there, wavefronts 4..7 only help staging the table fragments
+// and keep the barriers.  Same outputs as rx_detect_fft; the surfaces in the stream's HBM cache are in the writer lane's order.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rx_detect_mfma(RxShared *sh, const unsigned short *corr16_, float *cache_, int cached, int oldb, int newb, float rx_unsc,
+                                                float &best, int &bt, int &bfi)
+{
+    constexpr int RT = 5, NTF = 5, TPW = 15;
+    static_assert(TPW * 4 * 16 == RD_NMF && TPW % RT == 0, "timing tiles per wavefront");
+    typedef const __attribute__((address_space(1))) f16x8 glb_f16x8_t;
+    const int tid = rx_tid(), wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, g = lane >> 4;
+    const bool worker = wave < 4;                      // four wavefronts (one per SIMD) own the timing tiles; the other four only help staging the table
+    // chunk c = 128 nt + 64 plane + lane of a k-step (640 x 16 B): thread tid takes c = tid and (wavefronts 0 / 1) tid + 512
+    // Buffer loads (uniform descriptor + 32-bit lane offset + scalar offset): with plain pointers the compiler keeps one 64-bit address
+    // per (base, k-step) in VGPRs, spills them, and every k-step starts with scratch reloads under s_waitcnt vmcnt(0).
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corr16_), 0, 5 * 10 * 2048, 0x00020000);
+    const int vo = (((tid >> 7) * 10) * 128 + (tid & 127)) * 16;
+    const bool third = wave < 2;                       // wave-uniform
+    u32x4 stg[2];
+    auto stage_load = [&](int sidx) {
+        stg[0] = __builtin_amdgcn_raw_buffer_load_b128(crs, vo, sidx * 2048, 0);
+        if (third) stg[1] = __builtin_amdgcn_raw_buffer_load_b128(crs, vo, sidx * 2048 + 4 * 10 * 2048, 0);
+    };
+    auto stage_store = [&](int buf) {
+        _Float16 *d = &sh->sA[buf][tid * 8];
+        *(u32x4 *)d = stg[0];
+        if (third) *(u32x4 *)(d + 512 * 8) = stg[1];
+    };
+    float lbest = best; int lkey = 0x7fffffff;                      // (t << 6) | f of the best; callers start from best = -1, which the first sum replaces
+    stage_load(0); stage_store(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int pass = cached ? 1 : 0; pass < 2; pass++) {
+        const unsigned *ph = sh->srxh + pass * RD_NMF + i + 4 * g, *pl = sh->srxl + pass * RD_NMF + i + 4 * g;
+        const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(cache_ + (size_t)(pass ? newb : oldb) * RD_NFC * RD_NMF), 0, RD_NFC * RD_NMF * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(cache_ + (size_t)oldb * RD_NFC * RD_NMF), 0, RD_NFC * RD_NMF * 4, 0x00020000);
+        float *rowsum = pass ? sh->rowsum2 : sh->rowsum1;
+#pragma unroll 1
+        for (int grp = 0; grp < TPW / RT; grp++) {
+            const int T0 = wave * TPW + grp * RT;
+            f32x4 acc[RT][NTF];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                for (int q = 0; q < NTF; q++) acc[rt][q] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+            u32x4 wh[RT + 1], wl[RT + 1];
+            if (worker) {
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { wh[rt][j] = ph[16 * (T0 + rt) + j]; wl[rt][j] = pl[16 * (T0 + rt) + j]; }
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 10; sidx++) {
+                stage_load(sidx == 9 ? 0 : sidx + 1);
+                if (worker) {
+                if (sidx < 9) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { wh[RT][j] = ph[16 * (T0 + RT + sidx) + j]; wl[RT][j] = pl[16 * (T0 + RT + sidx) + j]; }
+                }
+                const _Float16 *Ab = &sh->sA[sidx & 1][lane * 8];
+                // the next frequency tile's fragments are in flight while this one's 15 instructions issue (left to itself the compiler
+                // reads each fragment right before its use and waits for it: ten exposed LDS latencies per k-step, half the phase)
+                f16x8 ch[2], cl[2];
+                ch[0] = *(const f16x8 *)(Ab); cl[0] = *(const f16x8 *)(Ab + 512);
+#pragma unroll
+                for (int q = 0; q < NTF; q++) {
+                    if (q + 1 < NTF) { ch[(q + 1) & 1] = *(const f16x8 *)(Ab + ((q + 1) * 2) * 512); cl[(q + 1) & 1] = *(const f16x8 *)(Ab + ((q + 1) * 2 + 1) * 512); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q & 1], __builtin_bit_cast(f16x8, wh[rt]), acc[rt][q], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q & 1], __builtin_bit_cast(f16x8, wl[rt]), acc[rt][q], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q & 1], __builtin_bit_cast(f16x8, wh[rt]), acc[rt][q], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; rt++) { wh[rt] = wh[rt + 1]; wl[rt] = wl[rt + 1]; }
+                }
+                stage_store((sidx & 1) ^ 1);
+                __syncthreads();
+            }
+            if (!worker) continue;                      // (wave-uniform; the helpers meet the workers again at the next k-step's barrier)
+            // C layout: column = lane & 15 (timing), rows 4 g + r = (re, im) of f = 8 q + 2 g and f + 1
+            const int tb = 16 * T0 + i;
+            // The surfaces in the stream's HBM cache are only ever read back by the lane that wrote them (|Dt2| of this call is |Dt1| of the
+            // next), so their layout is the lane's: per (wavefront, group) 64 lanes x 50 values (rt-major, then frequency tile, then the two
+            // frequencies) as twelve 16-byte vectors [k][lane] + one 8-byte vector [lane].  13 fully coalesced instructions per group and
+            // direction instead of 50 single dwords (store ISSUE was the epilogue: ~10 k cycles per group).
+            const int gb = (wave * (TPW / RT) + grp) * 64 * 2 * RT * NTF * 4;     // byte offset of the group's block
+            // all of the group's |Dt1| (HBM latency) are requested before any arithmetic; the accumulators turn into |Dt2| in place (4 -> 2
+            // registers per tile), which is what makes room for them
+            float pv[RT * 2 * NTF];
+            if (pass) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, gb + k * 1024, 0);
+                    pv[4 * k] = __uint_as_float(v[0]); pv[4 * k + 1] = __uint_as_float(v[1]); pv[4 * k + 2] = __uint_as_float(v[2]); pv[4 * k + 3] = __uint_as_float(v[3]);
+                }
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(prs, lane * 8, gb + 12 * 1024, 0);
+                pv[48] = __uint_as_float(v[0]); pv[49] = __uint_as_float(v[1]);
+            }
+            float dd[RT * 2 * NTF], rsum[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                float rs = 0.0f;
+#pragma unroll
+                for (int q = 0; q < NTF; q++) {
+                    const f32x4 c = acc[rt][q];
+                    const float d0 = rx_unsc * __builtin_amdgcn_sqrtf(fmaf(c[0], c[0], c[1] * c[1])), d1 = rx_unsc * __builtin_amdgcn_sqrtf(fmaf(c[2], c[2], c[3] * c[3]));
+                    rs += d0; rs += d1;
+                    dd[rt * 2 * NTF + 2 * q] = d0; dd[rt * 2 * NTF + 2 * q + 1] = d1;
+                }
+                {   // the other three lane groups hold the row's other frequencies: v_permlane16/32_swap (vector ALU, no LDS round trip)
+                    const auto p16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+                    rs = __uint_as_float(p16[0]) + __uint_as_float(p16[1]);
+                    const auto p32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+                    rs = __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
+                }
+                rsum[rt] = rs;
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){ __float_as_uint(dd[4 * k]), __float_as_uint(dd[4 * k + 1]), __float_as_uint(dd[4 * k + 2]), __float_as_uint(dd[4 * k + 3]) }, drs, lane * 16, gb + k * 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){ __float_as_uint(dd[48]), __float_as_uint(dd[49]) }, drs, lane * 8, gb + 12 * 1024, 0);
+            // every lane keeps its own best (t ascending, then f ascending, strict >: the earliest wins); block_argmax orders the lanes the same
+            // way.  Branch-free, (t, f) packed in one register: as conditional blocks the compiler kept the three in scratch memory and every
+            // one of the 50 updates was a store + load under s_waitcnt vmcnt(0).
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                const int t = tb + 16 * rt;
+                if (pass) {
+#pragma unroll
+                    for (int q = 0; q < NTF; q++) {
+                        const int k0 = (t << 6) | (8 * q + 2 * g);
+                        const float s0 = pv[rt * 2 * NTF + 2 * q] + dd[rt * 2 * NTF + 2 * q], s1 = pv[rt * 2 * NTF + 2 * q + 1] + dd[rt * 2 * NTF + 2 * q + 1];
+                        const bool c0 = s0 > lbest; lbest = c0 ? s0 : lbest; lkey = c0 ? k0 : lkey;
+                        const bool c1 = s1 > lbest; lbest = c1 ? s1 : lbest; lkey = c1 ? k0 + 1 : lkey;
+                    }
+                }
+                if (g == 0) rowsum[t] = rsum[rt];
+            }
+        }
+        __syncthreads();
+    }
+    best = lbest; bt = lkey >> 6; bfi = lkey & 63;
+}
+
+
 __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -2365,7 +2519,24 @@ __global__ __launch_bounds__(NT_RX) void k_rx_sync(rd_sync_args a)
             }
             __syncthreads();
             PH(16);
+#ifdef RX1_SEARCH_FFT
             rx_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb, best, bt, bfi);
+#else
+            {   // operand planes of the whole rx_buf (as for check_pilots in the synchronised state: one power-of-two scale from the running maximum)
+                const unsigned mb = max(max(S->rxmax_cur, S->rxmax_h0), S->rxmax_h1);
+                const int eb = min(max((int)((mb >> 23) & 0xffu), 32), 222);
+                const float rx_sc = __uint_as_float((unsigned)(127 + 7 - (eb - 127)) << 23);
+                const float rx_unsc = __uint_as_float((unsigned)(127 - 12 - 7 + (eb - 127)) << 23);
+                for (int i = tid; i < RD_RXBUF; i += NT_RX) {
+                    float2 v = sh->rxb[i]; v.x *= rx_sc; v.y *= rx_sc;
+                    const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y;
+                    const _Float16 l0 = (_Float16)(v.x - (float)h0), l1 = (_Float16)(v.y - (float)h1);
+                    sh->srxh[i] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+                    sh->srxl[i] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                }
+                rx_detect_mfma(sh, a.corr16, cache, cached ? 1 : 0, oldb, newb, rx_unsc, best, bt, bfi);
+            }
+#endif
             PH(17);
             PH(2);
             block_argmax(sh, best, bt, bfi);
