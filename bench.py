@@ -17,7 +17,7 @@ latency-bound by construction) and prints its own line.
 roofline block: `frac` prices the dominant kernel's work in its CHEAPEST known formulation (pilot search as one
 |Dt| surface by FFT convolution, decoder, in-sync DSP -- the constants below) at the f32 peak, over the time that kernel is busy in
 the TIMED configuration (launches of the batches in flight overlap); `alone` = one launch by itself, `whole_job` = every kernel's
-work x frames/s.  k_rx_sync2 actually evaluates the search surface as a split-binary16 GEMM on the matrix cores (49 MFLOP
+work x frames/s.  The receiver kernels actually evaluate the search surface as a split-binary16 GEMM on the matrix cores (49 MFLOP
 f32-equivalent per call instead of the FFT form's 5.1): pricing THAT would inflate the fraction ten-fold for the search calls, so
 the FFT count stays.  The reference-formulation figure (98 MFLOP of GEMM per search call) is reported separately as
 `equiv_ref_formulation` and is not a roofline.
@@ -48,7 +48,7 @@ SYNC_CALL_FLOP = (RX_SYNC_CMAC - 102400 + 40960) * 8.0 + 640 * 40.0     # 6.28 M
 ENC_STEP_FLOP = 2.0 * (96 * 64 + (64 + 224 + 384 + 544 + 704) * 192 + 2 * (128 + 288 + 448 + 608 + 768) * 96 + 864 * 80 + 5 * 64 * 192)   # CoreEncoder, one 40 ms step (4 feature frames): 1.87 MFLOP
 DEC_MF_FLOP = 3 * 904064 * 2.0                   # CoreDecoder, 3 steps per decoded modem frame (runs inside k_rx_sync): 5.42 MFLOP = 0.452 MFLOP per feature frame
 BPF_CALL_FLOP = 960 * 101 * 8.0                  # the BPF of a search / candidate call (it is inside SYNC_CALL_FLOP for synchronised ones): 0.78 MFLOP
-FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface by FFT convolution: 1 forward + 40 inverse 2048-point FFTs (5 N log2 N) + 40 spectral products: 5.11 MFLOP (what k_rx_sync executes; k_rx_sync2 runs the 49-MFLOP GEMM form on the matrix cores and is still priced at this figure)
+FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface by FFT convolution: 1 forward + 40 inverse 2048-point FFTs (5 N log2 N) + 40 spectral products: 5.11 MFLOP (the cheapest formulation; both receiver kernels now run the 49-MFLOP GEMM form on the matrix cores and are still priced at this figure)
 REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation of detect_pilots (two surfaces as GEMMs): 98.3 MFLOP -- NOT executed here
 ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
 RX_ALGO_BYTES_PER_FRAME = 640 + 144              # the receiver kernel's share: IQ in + features out
@@ -320,7 +320,7 @@ def roofline_leg(eng, step, steps, B, T, value, world):
                   "per_launch_counts": counts, "executed_flop_per_launch": fl, "algorithmic_bytes_per_launch": algo_bytes,
                   "flop_model": {"sync_call": SYNC_CALL_FLOP, "decoded_modem_frame": DEC_MF_FLOP, "search_call": FFT_SURFACE_FLOP + BPF_CALL_FLOP,
                                  "note": "executed work: in-sync DSP 781,120 cMAC x 8 (refine by moments: 40,960 cMAC instead of the reference formulation's 102,400) + polynomials per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
-                                         "search call = one |Dt| surface PRICED as FFT convolution (41 x 5 N log2 N + 40 x 6 N, N = 2048: the cheapest formulation; k_rx_sync2 evaluates it as a split-binary16 GEMM on the matrix cores, 49 MFLOP f32-equivalent, which is not counted) + BPF; priced at the f32 peak"},
+                                         "search call = one |Dt| surface PRICED as FFT convolution (41 x 5 N log2 N + 40 x 6 N, N = 2048: the cheapest formulation; the kernels evaluate it as a split-binary16 GEMM on the matrix cores, 49 MFLOP f32-equivalent, which is not counted) + BPF; priced at the f32 peak"},
                   "hbm_frac_kernel": algo_bytes / (r["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
                   "equiv_ref_formulation": {"tflops": (counts["sync_calls"] * REF_SYNC_CALL_FLOP + counts["decoded_modem_frames"] * DEC_MF_FLOP + counts["search_calls"] * REF_SEARCH_CALL_FLOP)
                                             / (r["avg_launch_ms"] * 1e-3) / 1e12,
