@@ -4,7 +4,7 @@ import numpy as np, torch
 from radae_amd.engine import BatchEngine, load_library, sigma_from_EbNodB
 from radae_amd.channel_tools import synth_features, multipath_g
 B, T = int(os.environ.get("PT_STREAMS", "256")), 1008; n_mf = T // 12
-eng = BatchEngine(B, max_tx_mf=n_mf, rx_trace_calls=128)
+eng = BatchEngine(B, max_tx_mf=n_mf, rx_trace_calls=int(os.environ.get("PT_TRACE", "128")))
 dev = torch.device('cuda')
 feats = torch.tensor(np.stack([synth_features(1000 + b, T) for b in range(B)]), device=dev)
 iq = eng.tx(feats)
