@@ -472,6 +472,29 @@ void rd_corr16_table_fill(const rd_tables *T, unsigned short *out /* [5][10][2][
                 }
 }
 
+/* The demodulator DFT of k_rx_sync2 on the f16 matrix cores (receiver_one, dsp.py:487-526: sym[s][c] = sum_n x_s[n] Wfwd[n][c]) as the real GEMM
+ * R[2c + part][2n + comp] = {wr, -wi; wi, wr}[part][comp] applied to (xr, xi) pairs, split in two binary16 planes and laid out as the A operands of
+ * v_mfma_f32_16x16x32_f16 like the pilot table above: out[tile][s][plane][lane][j] = plane(2^12 R[16 tile + lane%16][32 s + 8 (lane/16) + j]);
+ * rows 60..63 (carriers 30, 31) are zero. */
+void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out /* [4][10][2][64][8] */)
+{
+    for (int tile = 0; tile < 4; tile++)
+        for (int s = 0; s < 10; s++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int row = 16 * tile + (lane & 15), c = row >> 1, part = row & 1;
+                    const int k = 32 * s + 8 * (lane >> 4) + j, n = k >> 1, comp = k & 1;
+                    float v = 0.0f;
+                    if (c < RD_NC) {
+                        const float wr = T->Wfwd[n][c][0], wi = T->Wfwd[n][c][1];
+                        v = 4096.0f * (part == 0 ? (comp == 0 ? wr : -wi) : (comp == 0 ? wi : wr));
+                    }
+                    const unsigned short hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                    unsigned short *o = out + ((((size_t)tile * 10 + s) * 2) * 64 + lane) * 8 + j;
+                    o[0] = hi; o[64 * 8] = lo;
+                }
+}
+
 /* Tables of the FFT pilot correlator (k_rx_sync, search state).  Dt[t,f] = sum_m conj(rx[t+m]) p_w[m,f]
  * (dsp.py:207-208) is a correlation along t, so |Dt[.,f]| = |IDFT_2048(DFT_2048(rx) . G_f)| with
  * G_f[k] = (1/2048) sum_m conj(p_w[m,f]) e^{+j 2 pi k m/2048}, evaluated here in double from the float32 p_w the
