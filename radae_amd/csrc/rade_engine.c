@@ -210,8 +210,8 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         if (c16) { rd_corr16_table_fill(tab, c16); h->corr16 = dev_upload(c16, sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8); free(c16); }
     }
     {   /* the demodulator DFT matrix as matrix-core operands (k_rx_sync2) */
-        unsigned short *w16 = malloc(sizeof(unsigned short) * 4 * 10 * 2 * 64 * 8);
-        if (w16) { rd_wfwd16_table_fill(tab, w16); h->wfwd16 = dev_upload(w16, sizeof(unsigned short) * 4 * 10 * 2 * 64 * 8); free(w16); }
+        unsigned short *w16 = malloc(sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8);
+        if (w16) { rd_wfwd16_table_fill(tab, w16); h->wfwd16 = dev_upload(w16, sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8); free(w16); }
     }
     {   /* Wfwd carrier-major for k_rx_sync2 */
         float *wt = malloc(sizeof(float) * RD_NC * RD_M * 2);

@@ -472,23 +472,20 @@ void rd_corr16_table_fill(const rd_tables *T, unsigned short *out /* [5][10][2][
                 }
 }
 
-/* The demodulator DFT of k_rx_sync2 on the f16 matrix cores (receiver_one, dsp.py:487-526: sym[s][c] = sum_n x_s[n] Wfwd[n][c]) as the real GEMM
- * R[2c + part][2n + comp] = {wr, -wi; wi, wr}[part][comp] applied to (xr, xi) pairs, split in two binary16 planes and laid out as the A operands of
- * v_mfma_f32_16x16x32_f16 like the pilot table above: out[tile][s][plane][lane][j] = plane(2^12 R[16 tile + lane%16][32 s + 8 (lane/16) + j]);
- * rows 60..63 (carriers 30, 31) are zero. */
-void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out /* [4][10][2][64][8] */)
+/* The demodulator DFT of k_rx_sync2 on the f16 matrix cores (receiver_one, dsp.py:487-526: sym[s][c] = sum_n x_s[n] Wfwd[n][c]).  With the row
+ * R[c][2n + comp] = (wr, -wi)[comp] the real part is R . (xr, xi) and the imaginary part R . (xi, -xr): ONE 32-row operand (30 carriers) serves both, the two
+ * variants of the window are two groups of B columns.  Two binary16 planes in the A-operand order of v_mfma_f32_16x16x32_f16 like the pilot table above:
+ * out[tile][s][plane][lane][j] = plane(2^12 R[16 tile + lane%16][32 s + 8 (lane/16) + j]); rows 30, 31 are zero. */
+void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out /* [2][10][2][64][8] */)
 {
-    for (int tile = 0; tile < 4; tile++)
+    for (int tile = 0; tile < 2; tile++)
         for (int s = 0; s < 10; s++)
             for (int lane = 0; lane < 64; lane++)
                 for (int j = 0; j < 8; j++) {
-                    const int row = 16 * tile + (lane & 15), c = row >> 1, part = row & 1;
+                    const int c = 16 * tile + (lane & 15);
                     const int k = 32 * s + 8 * (lane >> 4) + j, n = k >> 1, comp = k & 1;
                     float v = 0.0f;
-                    if (c < RD_NC) {
-                        const float wr = T->Wfwd[n][c][0], wi = T->Wfwd[n][c][1];
-                        v = 4096.0f * (part == 0 ? (comp == 0 ? wr : -wi) : (comp == 0 ? wi : wr));
-                    }
+                    if (c < RD_NC) v = 4096.0f * (comp == 0 ? T->Wfwd[n][c][0] : -T->Wfwd[n][c][1]);
                     const unsigned short hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
                     unsigned short *o = out + ((((size_t)tile * 10 + s) * 2) * 64 + lane) * 8 + j;
                     o[0] = hi; o[64 * 8] = lo;

@@ -160,27 +160,28 @@ def test_host_tables_match_reference_constants(lib, golden):
 
 
 def test_demodulator_dft_matrix_as_matrix_core_operands(lib, golden):
-    """rd_wfwd16_table_fill: the realified forward DFT matrix in two binary16 planes, in the A-operand order of v_mfma_f32_16x16x32_f16 (k_rx_sync2's demodulator).
-    Un-permuting the table and applying it to a random window (on the CPU, in float64) must give the reference's Wfwd product to the planes' 22 bits."""
+    """rd_wfwd16_table_fill: the forward DFT matrix as rows (wr, -wi) in two binary16 planes, in the A-operand order of v_mfma_f32_16x16x32_f16 (k_rx_sync2's
+    demodulator).  Un-permuted and applied (on the CPU, in float64) to a random window as (xr, xi) it must give the real part of the reference's Wfwd product,
+    applied to (xi, -xr) the imaginary part, to the planes' 22 bits."""
     c = golden("consts")
     T = Tables()
     lib.rd_tables_fill.argtypes = [C.POINTER(Tables)]; lib.rd_tables_fill(C.byref(T))
-    out = np.zeros(4 * 10 * 2 * 64 * 8, np.uint16)
+    out = np.zeros(2 * 10 * 2 * 64 * 8, np.uint16)
     lib.rd_wfwd16_table_fill.argtypes = [C.POINTER(Tables), C.c_void_p]; lib.rd_wfwd16_table_fill.restype = None
     lib.rd_wfwd16_table_fill(C.byref(T), out.ctypes.data_as(C.c_void_p))
-    tab = out.view(np.float16).astype(np.float64).reshape(4, 10, 2, 64, 8)
-    R = np.zeros((64, 320))
-    for tile in range(4):
+    tab = out.view(np.float16).astype(np.float64).reshape(2, 10, 2, 64, 8)
+    R = np.zeros((32, 320))
+    for tile in range(2):
         for s in range(10):
             for lane in range(64):
                 R[16 * tile + (lane & 15), 32 * s + 8 * (lane >> 4):32 * s + 8 * (lane >> 4) + 8] = (tab[tile, s, 0, lane] + tab[tile, s, 1, lane]) / 4096.0
-    assert not R[60:].any()                                       # carriers 30, 31: padding
+    assert not R[30:].any()                                       # rows 30, 31: padding
     rng = np.random.default_rng(5)
     x = rng.standard_normal(160) + 1j * rng.standard_normal(160)
-    xr = np.empty(320); xr[0::2] = x.real; xr[1::2] = x.imag
-    y = R @ xr
+    v0 = np.empty(320); v0[0::2] = x.real; v0[1::2] = x.imag
+    v1 = np.empty(320); v1[0::2] = x.imag; v1[1::2] = -x.real
     ref = x @ c["Wfwd"].astype(np.complex128)                     # sym[c] = sum_n x[n] Wfwd[n][c] (dsp.py:501)
-    assert np.abs((y[0:60:2] + 1j * y[1:60:2]) - ref).max() < 3e-6 * np.abs(ref).max()
+    assert np.abs(((R @ v0)[:30] + 1j * (R @ v1)[:30]) - ref).max() < 3e-6 * np.abs(ref).max()
 
 
 class Lin(C.Structure):
