@@ -190,7 +190,6 @@ typedef struct {
     int *progress;                                       /* [4]: calls made by this launch, unused x3 */
     long long *wg_cycles;                                /* [B] shader-clock cycles each stream's workgroup spent in the launch (or NULL) */
     const unsigned short *wfwd16;                        /* [2][10][2][64][8] binary16: the forward DFT matrix (wr, -wi rows) as matrix-core A operands (rd_wfwd16_table_fill; k_rx_sync2's demodulator) */
-    const float *wfwd_t;                                 /* [30][160][2]: the forward DFT matrix carrier-major (k_rx_sync2's demodulator keeps a lane's slice of one column in registers) */
     const double *vm;                                    /* [8][160] ((n - 79.5) / 80)^m: refine()'s moment powers (k_rx_sync2 reads them from L2) */
     int variant;                                         /* 1: k_rx_sync (one stream per CU, 512 threads); 2: k_rx_sync2 (two streams per CU, 256 threads) */
     int B;

@@ -35,7 +35,7 @@ struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
     int unsync_off_after;                 /* int(disable_unsync * Fs / Nmf) or -1 */
-    float *fftG, *ffttw, *wfwd_t; unsigned short *corr16, *wfwd16; double *vm; int rx_variant;
+    float *fftG, *ffttw; unsigned short *corr16, *wfwd16; double *vm; int rx_variant;
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -213,10 +213,6 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         unsigned short *w16 = malloc(sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8);
         if (w16) { rd_wfwd16_table_fill(tab, w16); h->wfwd16 = dev_upload(w16, sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8); free(w16); }
     }
-    {   /* Wfwd carrier-major for k_rx_sync2 */
-        float *wt = malloc(sizeof(float) * RD_NC * RD_M * 2);
-        if (wt) { for (int c = 0; c < RD_NC; c++) for (int n = 0; n < RD_M; n++) { wt[(c * RD_M + n) * 2] = tab->Wfwd[n][c][0]; wt[(c * RD_M + n) * 2 + 1] = tab->Wfwd[n][c][1]; } h->wfwd_t = dev_upload(wt, sizeof(float) * RD_NC * RD_M * 2); free(wt); }
-    }
     free(tab);
     {   /* ((n - 79.5) / 80)^m, m = 0..7, by repeated multiplication (the order the kernels build their LDS copy in) */
         double vm[8][RD_M];
@@ -226,7 +222,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     /* receiver kernel: 1 = one stream per CU (k_rx_sync), 2 = two streams per CU (k_rx_sync2) */
     h->rx_variant = getenv("RADE_RX_VARIANT") ? atoi(getenv("RADE_RX_VARIANT")) : ((cfg->flags & RADE_BATCH_RX_TWO_PER_CU) ? 2 : 1);
     if (h->rx_variant != 2) h->rx_variant = 1;
-    if (!h->d_tab || !h->fftG || !h->ffttw || !h->corr16 || !h->vm || !h->wfwd_t || !h->wfwd16) goto fail;
+    if (!h->d_tab || !h->fftG || !h->ffttw || !h->corr16 || !h->vm || !h->wfwd16) goto fail;
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
@@ -334,7 +330,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16, h->vm, h->chan_mp, h->wfwd_t, h->wfwd16 };
+                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -646,7 +642,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
     sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
-    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd_t = h->wfwd_t; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_variant | (getenv("RADE_RX2_CENSUS") ? atoi(getenv("RADE_RX2_CENSUS")) << 8 : 0);   /* the mask only acts in -DRX2_CENSUS developer builds */
+    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_variant | (getenv("RADE_RX2_CENSUS") ? atoi(getenv("RADE_RX2_CENSUS")) << 8 : 0);   /* the mask only acts in -DRX2_CENSUS developer builds */
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
     sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only
