@@ -52,8 +52,8 @@ FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface b
 REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation of detect_pilots (two surfaces as GEMMs): 98.3 MFLOP -- NOT executed here
 ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
 RX_ALGO_BYTES_PER_FRAME = 640 + 144              # the receiver kernel's share: IQ in + features out
-RX_KERNEL_NAME = "k_rx_sync2"                     # set from --rx-kernel in main(): the PMC summary is looked up under the kernel that ran
-PROFILE_TAG = "r03"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
+RX_KERNEL_NAME = "k_rx_sync2"                     # the receiver kernel (rade_rx.hip): the PMC summary is looked up under this name
+PROFILE_TAG = "r04"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
 
 
 def executed_flop(search_calls, sync_calls, decoded_mf):
@@ -109,7 +109,6 @@ def main():
     ap.add_argument("--frames", type=int, default=1008, help="10 ms feature frames per utterance (multiple of 12)")
     ap.add_argument("--config", type=int, default=3, choices=(2, 3), help="3: the headline batch workload; 2: single-stream core encoder/decoder latency")
     ap.add_argument("--pipeline", type=int, default=3, help="batches in flight: engines + HIP streams + host threads that take the steps in turn (1 = one batch at a time)")
-    ap.add_argument("--rx-kernel", type=int, default=2, choices=(1, 2), help="receiver kernel: 2 = k_rx_sync2, two streams per CU (RADE_BATCH_RX_TWO_PER_CU: workgroups of two batches in flight share a CU); 1 = k_rx_sync, one stream per CU")
     ap.add_argument("--two-pass-channel", action="store_true", help="rade_batch_tx + rade_batch_channel as two calls (k_chan_power + k_chan_apply) instead of rade_batch_tx_channel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -148,10 +147,7 @@ def main():
     # encoder / channel kernels (and the head of its receiver launch) fill the CUs that the slowest streams of the previous batch's receiver
     # launch leave idle (a receiver launch lasts as long as its slowest stream; rade_batch_rx synchronises its stream, hence one thread each)
     depth = max(1, min(args.pipeline, args.steps))
-    global RX_KERNEL_NAME
-    RX_KERNEL_NAME = "k_rx_sync2" if args.rx_kernel == 2 else "k_rx_sync"
-    rx_flags = 0x200 if args.rx_kernel == 2 else 0                       # RADE_BATCH_RX_TWO_PER_CU
-    engs = [BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob, flags=rx_flags) for _ in range(depth)]
+    engs = [BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob) for _ in range(depth)]
     eng = engs[0]
     lanes = [torch.cuda.Stream(device=dev) for _ in range(depth)]
 
@@ -259,11 +255,11 @@ def main():
 
     if rank == 0 and not args.no_roofline:
         out["roofline"] = roofline_leg(eng, step, args.steps, B, T, value, world)
-        out["roofline"]["rx_kernel"] = "k_rx_sync2 (two streams per CU)" if args.rx_kernel == 2 else "k_rx_sync (one stream per CU)"
+        out["roofline"]["rx_kernel"] = "k_rx_sync2 (256 threads / at most 80 KB of LDS per stream: two streams per CU)"
         if depth > 1 and out["roofline"].get("kernel") == "rx_sync":
             pipelined_roofline(out["roofline"], engs, run_steps, min(args.steps, 24), dev)
     if rank == 0 and not args.no_parity:
-        out["parity_sample"] = parity_leg(feats_np, fo, st, rx_last, blob, local, B, rx_flags)
+        out["parity_sample"] = parity_leg(feats_np, fo, st, rx_last, blob, local, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(feats_np, T)
         out["cpu_baseline_allcores"] = cpu_baseline_allcores(T)
@@ -336,7 +332,7 @@ def roofline_leg(eng, step, steps, B, T, value, world):
     r["limiter"] = "latency (s_waitcnt/s_barrier) + valu-issue"
     r["traffic"] = None
     try:
-        tag = next(t for t in (PROFILE_TAG, "r02") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
+        tag = next(t for t in (PROFILE_TAG, "r03") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
         pm = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")))
         k = pm["kernels"][{"rx_sync": RX_KERNEL_NAME}.get(dom, dom)]
         raw = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
@@ -400,7 +396,7 @@ def pipelined_roofline(r, engs, run_steps, n, dev):
     r["avg_launch_ms_note"] = "busy time of the receiver kernel per launch in the timed (pipelined) configuration; alone.avg_launch_ms = one launch by itself; pipelined.avg_launch_ms_overlapped = event duration of a launch sharing the chip"
 
 
-def parity_leg(feats_np, fo, st, rx, blob, local, B, rx_flags=0):
+def parity_leg(feats_np, fo, st, rx, blob, local, B):
     """The oracle on the timed workload itself: the received samples of a few streams of the LAST timed step (device Philox noise
     included) are copied back and run through the CPU oracle; the same samples are replayed through a small traced engine, which
     must reproduce the timed engine's features bit for bit and the oracle's per-call discrete outputs exactly."""
@@ -411,7 +407,7 @@ def parity_leg(feats_np, fo, st, rx, blob, local, B, rx_flags=0):
     m = O.Model()
     idx = sorted({0, B // 3, (2 * B) // 3, B - 1})
     rx_host = rx[idx].cpu().numpy()
-    e2 = BatchEngine(len(idx), max_tx_mf=1, device=local, blob_bytes=blob, rx_trace_calls=128, flags=rx_flags)       # the same receiver kernel as the timed engines
+    e2 = BatchEngine(len(idx), max_tx_mf=1, device=local, blob_bytes=blob, rx_trace_calls=128)
     fo2, st2, _ = e2.rx(rx[idx].contiguous())
     torch.cuda.synchronize()
     keys = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]

@@ -5,8 +5,8 @@
  * broadcast over RCCL, statistics summed with one RCCL all-reduce (include/rade_batch.h: rade_multi_*).  Prints one JSON line.
  *
  * With --pipeline P (default 3, what bench.py times) every device keeps P batches in flight: P engines with their own state, each on its own
- * HIP stream and host thread, the steps dealt to them in turn, the receiver kernel with two streams per CU (RADE_BATCH_RX_TWO_PER_CU;
- * DESIGN.md 3.7).  --pipeline 1 is the plain one-engine-per-device loop on k_rx_sync.
+ * HIP stream and host thread, the steps dealt to them in turn (the receiver kernel takes half a CU per stream, so the workgroups of two
+ * batches share a CU: DESIGN.md 3.7).  --pipeline 1 is the plain one-engine-per-device loop.
  *
  * usage: rade_multi_bench [--gpus N | --mask HEX] [--streams-per-gpu B] [--frames T] [--steps K] [--warmup W] [--pipeline P] [weights.bin]
  */
@@ -197,7 +197,7 @@ int main(int argc, char **argv)
     j.low_ratio = 800; doppler_taps(1.0, 10.0, j.taps);         /* MPP: 1 Hz Doppler spread, lowFs = 10 Hz (multipath_samples.m:13) */
     if (j.pipeline < 1) j.pipeline = 1;
     if (j.pipeline > 16) j.pipeline = 16;
-    j.flags = j.pipeline > 1 ? RADE_BATCH_RX_TWO_PER_CU : 0; j.blob = blob;
+    j.flags = 0; j.blob = blob;
     rade_multi *m = rade_multi_open(blob, B * n_dev, j.n_mf, mask, j.flags);
     if (!m) return 1;
     n_dev = rade_multi_n_devices(m);

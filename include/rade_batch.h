@@ -29,16 +29,15 @@ extern "C" {
 
 typedef struct rade_batch rade_batch;
 #define RADE_BATCH_BOTTLENECK1 0x100
-/* receiver kernel with TWO streams per CU (k_rx_sync2: 256 threads and at most 80 KB of LDS per stream, so that workgroups of two
- * launches share a CU) instead of one (k_rx_sync: 512 threads, a whole CU).  Same results to rounding (summation orders of a few
- * sums differ); pays only with three or more batches in flight -- see DESIGN.md 3.7 for the measurements.  $RADE_RX_VARIANT=1|2 overrides. */
+/* Accepted and ignored since round 4: the receiver kernel (k_rx_sync2: 256 threads and at most 80 KB of LDS per stream, so that the
+ * workgroups of two launches share a CU) is the only one; rounds 2-3 selected it with this flag beside a one-stream-per-CU kernel. */
 #define RADE_BATCH_RX_TWO_PER_CU 0x200
 
 typedef struct {
     int n_streams;        /* B */
     int max_tx_mf;        /* largest n_mf a single rade_batch_tx call may carry */
     int device;           /* HIP device ordinal */
-    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm); RADE_BATCH_RX_TWO_PER_CU */
+    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm) */
     int rx_trace_calls;   /* >0: keep a per-call trace of this many do_radae_rx calls per stream (tests) */
     float disable_unsync; /* test mode of radae_rxe.py --disable_unsync (:277-281, :337): after this many seconds in sync the receiver no longer
                            * drops back to search (pilot loss, end-of-over, UW failure); 0 = normal operation */

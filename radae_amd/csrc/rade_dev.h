@@ -91,7 +91,7 @@ typedef struct {
     float snrdB_3k_est; float pad2;
 } rd_rx_trace;
 
-/* ---- launch shims (defined in rade_kernels.hip) -------------------------------------------- */
+/* ---- launch shims (defined in rade_kernels.hip / rade_rx.hip) -------------------------------------------- */
 typedef void *rd_stream_t;
 
 /* Y[r, n] = act(sum_k A[r,k] W[n,k] + bias[n]) on f32 MFMA; rows r = b*T + t.
@@ -181,7 +181,6 @@ typedef struct {
     float *features_out; long feat_stride;               /* [B][cap][432] */
     int feat_cap;                                        /* valid modem frames features_out holds per stream: a stream stops making calls once it has produced that many */
     const unsigned short *corr16;                        /* rd_corr16_table_fill(): [5][10][2][64][8] binary16 */
-    const float *fftG, *ffttw;                           /* rd_fft_tables_fill(): [RD_NFC][2048][2], [2048 + 64][2] */
     float *zrows;                                        /* [B][dec_rows][80] */
     float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */
     int *status;                                         /* [B][4]: nin, sync, snr_int, state */
@@ -191,10 +190,13 @@ typedef struct {
     long long *wg_cycles;                                /* [B] shader-clock cycles each stream's workgroup spent in the launch (or NULL) */
     const unsigned short *wfwd16;                        /* [2][10][2][64][8] binary16: the forward DFT matrix (wr, -wi rows) as matrix-core A operands (rd_wfwd16_table_fill; k_rx_sync2's demodulator) */
     const double *vm;                                    /* [8][160] ((n - 79.5) / 80)^m: refine()'s moment powers (k_rx_sync2 reads them from L2) */
-    int variant;                                         /* 1: k_rx_sync (one stream per CU, 512 threads); 2: k_rx_sync2 (two streams per CU, 256 threads) */
+    int variant;                                         /* bits 8..: phase mask of the -DRX2_CENSUS developer build (tools/rx2_census.sh); 0 otherwise */
+    int lds_bytes;                                       /* dynamic LDS of the launch: what rd_rx_sync_prepare() returned */
     int B;
 } rd_sync_args;
 int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
+/* once per device before the first launch (rade_batch_open): raises the kernel's dynamic-LDS limit; returns the bytes to launch with, < 0 on error */
+int rd_rx_sync_prepare(int solo);
 
 int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
 

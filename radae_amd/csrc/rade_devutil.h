@@ -1,0 +1,122 @@
+// rade_devutil.h -- device-side helpers shared by the HIP translation units (rade_kernels.hip: transmit side, channel, GEMMs, scans;
+// rade_rx.hip: the receiver).  gfx950 only: 64-lane wavefronts, DPP lane exchange, hardware exp2 / rcp.
+#ifndef RADE_DEVUTIL_H
+#define RADE_DEVUTIL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "rade_dev.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two IEEE fused multiply-adds per lane in one instruction (v_pk_fma_f32: the full-rate f32 path of the vector ALU)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define PI_D 3.14159265358979323846
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// e^{-j angle(c)} = conj(c)/|c| (np.exp(-1j*np.angle(c)) without atan2 / sincos); angle(0) = 0
+__device__ __forceinline__ float2 unit_conj(float2 c)
+{
+#ifdef RD_NO_UNITCONJ
+    { const float ang = atan2f(c.y, c.x); float sn, cs; sincosf(-ang, &sn, &cs); return make_float2(cs, sn); }
+#endif
+    const float n2 = c.x * c.x + c.y * c.y;
+    if (n2 == 0.0f) return make_float2(1.0f, 0.0f);
+    const float inv = 1.0f / sqrtf(n2);
+    return make_float2(c.x * inv, -c.y * inv);
+}
+// (cos, sin) of a double angle: reduced to [-pi, pi] in double, evaluated in float (the results are used as float32)
+__device__ __forceinline__ float2 cis_reduced(double ang)
+{
+#ifdef RD_NO_CIS
+    double sd, cd; sincos(ang, &sd, &cd); return make_float2((float)cd, (float)sd);
+#else
+    const double r = ang - 6.283185307179586476925 * rint(ang * 0.15915494309189533577);
+    float sn, cs; sincosf((float)r, &sn, &cs);
+    return make_float2(cs, sn);
+#endif
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// thread index through an opaque asm: inside the receiver's per-call loop this keeps the compiler from hoisting every
+// thread-derived address computation of every phase out of the loop (hundreds of registers live across all phases)
+__device__ __forceinline__ int rx_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+// lane exchange inside a quad on the DPP path (v_mov_b32_dpp quad_perm): __shfl / __shfl_xor go through ds_bpermute, an
+// LDS-pipe round trip on the serial chain of the recurrences
+template <int CTRL> __device__ __forceinline__ float quad_dpp(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
+#define QUAD_XOR1 0xB1   /* [1,0,3,2] */
+#define QUAD_XOR2 0x4E   /* [2,3,0,1] */
+#define QUAD_BC0  0x00   /* [0,0,0,0] */
+#define QUAD_BC1  0x55
+#define QUAD_BC2  0xAA
+#define ROW_ROR4  0x124  /* rotate right by 4 inside each row of 16 lanes */
+#define ROW_ROR8  0x128
+template <int CTRL> __device__ __forceinline__ int quad_dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = (unsigned)quad_dpp_i<CTRL>((int)(unsigned)b), hi = (unsigned)quad_dpp_i<CTRL>((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// sum over the wavefront, the same value in every lane: quad and row steps on DPP, the four row totals through readlane
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_f64<QUAD_XOR1>(v); v += dpp_f64<QUAD_XOR2>(v); v += dpp_f64<ROW_ROR4>(v); v += dpp_f64<ROW_ROR8>(v);
+    const long long b = __double_as_longlong(v);
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 16 * r), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 16 * r);
+        t += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return t;
+}
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += quad_dpp<QUAD_XOR1>(v); v += quad_dpp<QUAD_XOR2>(v); v += quad_dpp<ROW_ROR4>(v); v += quad_dpp<ROW_ROR8>(v);
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * r));
+    return t;
+}
+// max over the wavefront of non-negative values (lanes DPP cannot reach read 0), the same value in every lane
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = fmaxf(v, quad_dpp<QUAD_XOR1>(v)); v = fmaxf(v, quad_dpp<QUAD_XOR2>(v)); v = fmaxf(v, quad_dpp<ROW_ROR4>(v)); v = fmaxf(v, quad_dpp<ROW_ROR8>(v));
+    float t = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) t = fmaxf(t, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16 * r)));
+    return t;
+}
+__device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f), 1.0f); }
+// sqrt(-ln(P / 5)) of the Rayleigh thresholds (dsp.py:221, 318-320), P = 1e-4 / 1e-5: correctly rounded doubles, i.e. what the
+// reference's (and the oracle's) libm returns; the device log / sqrt on the single thread that sets the thresholds were a few hundred
+// f64 instructions on the serial path of every call
+#define RD_SQRT_NLOG_1EM4_5 3.2893431387452243
+#define RD_SQRT_NLOG_1EM5_5 3.622480279781289
+// gate activations of the GRU recurrences on the hardware exp2 / rcp units (about 1 ulp each): the recurrence is a
+// serial chain, so the libm-grade expf / tanhf / IEEE division sequences would dominate every time step
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
+__device__ __forceinline__ float2 ld2(const float (*p)[2], int i) { return make_float2(p[i][0], p[i][1]); }
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) _Float16 lds_half;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(1))) const unsigned short glb_u16;
+typedef __attribute__((address_space(1))) const float glb_cf32;
+typedef __attribute__((address_space(1))) float glb_f32;
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    return (T *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v));
+}
+#endif

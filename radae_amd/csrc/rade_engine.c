@@ -7,7 +7,7 @@
  * f32-MFMA GEMM with M = B*T rows, and only the 64/96-wide GRU recurrences run as serial scans.
  * The receiver runs one workgroup per stream for a whole rade_batch_rx call; the sync state machine consumes the
  * decoder's aux bits (UW errors, radae_rxe.py:220-224, :306-312), so the decoder runs inside that workgroup
- * right before every unique-word decision (k_rx_sync -> rx_decode_pending).
+ * right before every unique-word decision (k_rx_sync2 -> rx2_decode_pending, rade_rx.hip).
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -35,7 +35,7 @@ struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
     int unsync_off_after;                 /* int(disable_unsync * Fs / Nmf) or -1 */
-    float *fftG, *ffttw; unsigned short *corr16, *wfwd16; double *vm; int rx_variant;
+    unsigned short *corr16, *wfwd16; double *vm; int rx_lds, rx_census;   /* dynamic LDS of a receiver launch; phase mask of the -DRX2_CENSUS developer build */
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -203,9 +203,6 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     rd_tables_fill(tab);
     h->d_tab = dev_upload(tab, sizeof *tab);
     {
-        float *G = malloc(sizeof(float) * RD_NFC * 2048 * 2), *tw = malloc(sizeof(float) * (2048 + 64) * 2);
-        if (G && tw) { rd_fft_tables_fill(tab, G, tw); h->fftG = dev_upload(G, sizeof(float) * RD_NFC * 2048 * 2); h->ffttw = dev_upload(tw, sizeof(float) * (2048 + 64) * 2); }
-        free(G); free(tw);
         unsigned short *c16 = malloc(sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8);
         if (c16) { rd_corr16_table_fill(tab, c16); h->corr16 = dev_upload(c16, sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8); free(c16); }
     }
@@ -219,10 +216,12 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         for (int n = 0; n < RD_M; n++) { const double nu = ((double)n - 79.5) / 80.0; double v = 1.0; for (int m = 0; m < 8; m++) { vm[m][n] = v; v *= nu; } }
         h->vm = dev_upload(vm, sizeof vm);
     }
-    /* receiver kernel: 1 = one stream per CU (k_rx_sync), 2 = two streams per CU (k_rx_sync2) */
-    h->rx_variant = getenv("RADE_RX_VARIANT") ? atoi(getenv("RADE_RX_VARIANT")) : ((cfg->flags & RADE_BATCH_RX_TWO_PER_CU) ? 2 : 1);
-    if (h->rx_variant != 2) h->rx_variant = 1;
-    if (!h->d_tab || !h->fftG || !h->ffttw || !h->corr16 || !h->vm || !h->wfwd16) goto fail;
+    /* the receiver kernel asks for more dynamic LDS than the 64 KB default: raised here, once per engine and before any launch (the
+     * attribute belongs to the device's code object; setting it again from another engine's thread is harmless).  RADE_RX2_SOLO=1
+     * (developer switch) asks for more than half a CU's LDS, i.e. one workgroup per CU. */
+    h->rx_lds = rd_rx_sync_prepare(getenv("RADE_RX2_SOLO") != NULL);
+    h->rx_census = getenv("RADE_RX2_CENSUS") ? atoi(getenv("RADE_RX2_CENSUS")) : 0;      /* only acts in -DRX2_CENSUS builds */
+    if (!h->d_tab || !h->corr16 || !h->vm || !h->wfwd16 || h->rx_lds <= 0) goto fail;
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
@@ -330,7 +329,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->fftG, h->ffttw, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
+                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -641,8 +640,8 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
-    sa.fftG = h->fftG; sa.ffttw = h->ffttw; sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
-    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_variant | (getenv("RADE_RX2_CENSUS") ? atoi(getenv("RADE_RX2_CENSUS")) << 8 : 0);   /* the mask only acts in -DRX2_CENSUS developer builds */
+    sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+    sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_census << 8; sa.lds_bytes = h->rx_lds;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
     sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only

@@ -492,30 +492,3 @@ void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out /* [2][10][2][
                 }
 }
 
-/* Tables of the FFT pilot correlator (k_rx_sync, search state).  Dt[t,f] = sum_m conj(rx[t+m]) p_w[m,f]
- * (dsp.py:207-208) is a correlation along t, so |Dt[.,f]| = |IDFT_2048(DFT_2048(rx) . G_f)| with
- * G_f[k] = (1/2048) sum_m conj(p_w[m,f]) e^{+j 2 pi k m/2048}, evaluated here in double from the float32 p_w the
- * reference correlates with.  tw[q][l] = e^{-j 2 pi l q/2048} is the twiddle between the two radix passes. */
-#define RD_FFT_TW_FLOATS ((2048 + 64) * 2)
-void rd_fft_tables_fill(const rd_tables *T, float *G /* [RD_NFC][2048][2] */, float *tw /* [32][64][2] + [2][32][2] */)
-{
-    const double w0 = 2.0 * PI_D / 2048.0;
-    double cs[2048], sn[2048];
-    for (int k = 0; k < 2048; k++) { cs[k] = cos(w0 * k); sn[k] = sin(w0 * k); }
-    for (int f = 0; f < RD_NFC; f++)
-        for (int k = 0; k < 2048; k++) {
-            double ar = 0.0, ai = 0.0;
-            for (int m = 0; m < RD_M; m++) {
-                const int ph = (k * m) & 2047;
-                const double gr = T->p_w[m][f][0], gi = -(double)T->p_w[m][f][1];     /* conj(p_w) */
-                ar += gr * cs[ph] - gi * sn[ph]; ai += gr * sn[ph] + gi * cs[ph];
-            }
-            G[((size_t)f * 2048 + k) * 2] = (float)(ar / 2048.0); G[((size_t)f * 2048 + k) * 2 + 1] = (float)(ai / 2048.0);
-        }
-    for (int q = 0; q < 32; q++)
-        for (int l = 0; l < 64; l++) { tw[(q * 64 + l) * 2] = (float)cs[(l * q) & 2047]; tw[(q * 64 + l) * 2 + 1] = (float)-sn[(l * q) & 2047]; }
-    for (int l = 0; l < 32; l++) {          /* cross-lane radix-2 stage: lane h = 0 multiplies by 1, h = 1 by e^{-j 2 pi l/64} */
-        tw[(2048 + l) * 2] = 1.0f; tw[(2048 + l) * 2 + 1] = 0.0f;
-        tw[(2048 + 32 + l) * 2] = (float)cs[32 * l]; tw[(2048 + 32 + l) * 2 + 1] = (float)-sn[32 * l];
-    }
-}

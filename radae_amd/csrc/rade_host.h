@@ -27,7 +27,6 @@ void rd_tables_fill(rd_tables *T);
 int rd_model_parse(const void *blob, size_t len, rd_model *m);
 void rd_model_free(rd_model *m);
 
-void rd_fft_tables_fill(const rd_tables *T, float *G, float *tw);
 long rd_packed16_size(int N, int K);
 void rd_corr16_table_fill(const rd_tables *T, unsigned short *out);
 void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out);

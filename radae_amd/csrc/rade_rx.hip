@@ -1,16 +1,63 @@
-// rade_rx2.inc -- the receiver kernel in its TWO-STREAMS-PER-CU form (k_rx_sync2), included at the end of rade_kernels.hip.
+// rade_rx.hip -- THE receiver of the RADE hot path: do_radae_rx (radae_rxe.py:171-330) for one stream per workgroup, all of its calls in one launch.
 //
-// k_rx_sync (above) gives one stream a whole CU: 512 threads, 159 KB of LDS, the whole register file.  A stream's chain is serial
-// and most of its phases are latency-bound (46 % of wave-cycles parked on s_waitcnt / s_barrier, matrix pipes 8 % busy), so the CU
-// mostly waits.  Here a stream gets HALF a CU -- 256 threads (four wavefronts, one per SIMD, still 256 registers each) and at most
-// 80 KB of LDS -- so that two workgroups, i.e. two independent streams (the two batches in flight), share a CU and one stream's
-// stalls are filled with the other's work.  Same algorithm, same arithmetic per value as k_rx_sync except where noted
-// (summation orders of a few float / double sums); what changes is where things live:
-//   * Wfwd (38 KB) is not staged in LDS: the demodulator DFT keeps one carrier's column in registers (from L2) and applies it to the
-//     six symbols of the frame; the moment-power table of refine() (10 KB) is read from L2;
-//   * the decoder stage works on chunks of 12 rows (64 KB) and, while it runs, rx_buf and the |Dt| row sums are parked in the
-//     stream's HBM record (25 KB out and back every 8 frames);
-//   * pilot replicas and equaliser constants live in the synchronised-state area and are reloaded with it.
+//   k_rx_bpf      complex_bpf.bpf (dsp.py:63-102) for every sample of a rade_batch_rx invocation, ahead of the receiver kernel (round 4: the
+//                 band-pass filter does not depend on any sync decision, so it left the per-stream serial chain)
+//   k_rx_sync2    acquisition (detect_pilots / refine / check_pilots, dsp.py:178-320), sync state machine, frequency correction, OFDM demod +
+//                 3-pilot LS EQ (dsp.py:418-526), the CoreDecoder stage (radae_base.py:358-430) and UW accounting (rade_api.c:480-513): 256 threads
+//                 and at most 80 KB of LDS per stream, so that two streams share a CU
+//   k_rx_reset    radae_rxe.py:128-142
+//
+// Rounds 2-3 carried a second receiver kernel (k_rx_sync: 512 threads, one stream per CU) that this one was forked from; it is gone: one
+// receiver, every fix lands once.
+#include "rade_devutil.h"
+
+// ---- decoder stage inside the receiver: LDS layout helpers and product descriptors ----
+#define DQ_XB 96                 // 8-half blocks per x row
+#define DQ_HB 16                 // blocks per GRU-output row (12 used)
+#define DQ_PEND_MAX 64           // pending rows a stream can hold (engine: dec_rows <= 63)
+// half index of x[logical row t][col] inside a plane; the history row is logical -1 (swizzle key 15), the zero row needs no key
+__device__ __forceinline__ int dq_xoff(int t, int col) { return (t + 1) * (DQ_XB * 8) + ((((col >> 3) ^ (t & 15)) << 3) | (col & 7)); }
+__device__ __forceinline__ int dq_hoff(int t, int col) { return t * (DQ_HB * 8) + ((((col >> 3) ^ (t & 15)) << 3) | (col & 7)); }
+// v in [-1, 1] -> the two planes of 2^8 v
+__device__ __forceinline__ void dq_split(float v, _Float16 &hi, _Float16 &lo) { const float x = 256.0f * v; hi = (_Float16)x; lo = (_Float16)(x - (float)hi); }
+
+enum { DQ_OUT_X = 0, DQ_OUT_GI = 1, DQ_OUT_GLOBAL = 2 };
+struct DqGemm {
+    const unsigned short *wa; int nct;     // rd_pack_weights_f16x2_a16: [K/32][nct][2 planes][64 lanes][8]
+    const float *bias; int N;              // bias may be null; N = valid output columns
+    const float *wscale;                   // non-null: int8-exact layer, ONE plane of integers, wscale[n] = the column's scale; null: two planes of 2^10 w
+    int from_hb;                           // B operand: 0 = the x planes, 1 = the GRU-output planes
+    int ktap;                              // k-steps [0, ktap) read the PREVIOUS row (conv tap 0), the rest the row itself
+    int ks0, nks;                          // k-steps of the weight's K axis this product covers
+    int init_gi;                           // accumulators start from gi[t][n] (fix-up products) instead of zero
+    int out, ocol, act;                    // DQ_OUT_*; first x column (DQ_OUT_X); act 0 none, 1 tanh+clamp, 2 GLU
+    float *gout; int gstride;              // DQ_OUT_GLOBAL
+};
+
+enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
+struct RxScalars {
+    int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
+    uint32_t lcg;
+    unsigned rxmax_cur, rxmax_h0, rxmax_h1;   // float bits of max |re|,|im| of the filtered samples of this call / the two calls before (check_pilots operand scale)
+    int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
+    int pf_n;                 // samples of the NEXT call already mixed down into xm[102..] by the end of this (synchronised) call; 0 = none
+    int entry;                // this candidate call enters sync (decided by thread 0 before a barrier: see do_entry)
+    int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
+    float snr_est, mag; float2 bpf_phase;
+    double fmax, foff_err, rph_r, rph_i, Dthresh, Dtmax12, Dtmax12_eoo;
+    double rph_th;                        // k_rx_sync2: the phase accumulator as an angle in [-pi, pi] (rph_r + j rph_i = e^{j rph_th})
+};
+
+__device__ __forceinline__ float sigma_r_from_sums(double t1, double t2)
+{   // dsp.py:218-220: (mean|Dt1| + mean|Dt2|)/sqrt(pi/2)/2 in float32
+    const float k = (float)sqrt(PI_D / 2.0);
+    const float m1 = (float)(t1 / (RD_NMF * RD_NFC)) / k, m2 = (float)(t2 / (RD_NMF * RD_NFC)) / k;
+    return (m1 + m2) / 2.0f;
+}
+
+__device__ static constexpr uint32_t LCG_A[48] = { 1664525u, 389569705u, 2940799637u, 158984081u, 2862450781u, 3211393721u, 1851289957u, 3934847009u, 2184914861u, 246739401u, 1948736821u, 2941245873u, 4195587069u, 4088025561u, 980655621u, 2001863745u, 657792333u, 65284841u, 1282409429u, 3808694225u, 2968195997u, 2417331449u, 2878627493u, 307989601u, 504219373u, 1897564169u, 2574089845u, 3294562801u, 3478292285u, 2651335705u, 2523738949u, 666245249u, 4137395341u, 2604435753u, 1706708245u, 3963176977u, 3678957277u, 3530469177u, 3858799589u, 629287073u, 3146069549u, 3820924489u, 2403397557u, 2390444593u, 2593868413u, 4291139161u, 1705056389u, 3186638017u };
+__device__ static constexpr uint32_t LCG_C[48] = { 1013904223u, 1196435762u, 3519870697u, 2868466484u, 1649599747u, 2670642822u, 1476291629u, 2748932008u, 2180890343u, 2498801434u, 3421909937u, 3167820124u, 2636375307u, 3801544430u, 28987765u, 2210837584u, 3039689583u, 1338634754u, 1649346937u, 2768872580u, 2254235155u, 2326606934u, 1719328701u, 1061592568u, 53332215u, 1140036074u, 4224358465u, 2629538988u, 1946028059u, 573775550u, 1473591045u, 95141024u, 1592739711u, 1618554578u, 4257218569u, 2685635028u, 2617994019u, 740185638u, 4194465613u, 2426187848u, 967350023u, 366635194u, 2557108433u, 3503432700u, 353185579u, 706247310u, 408928405u, 1855199472u };
+
 #define NT2 256
 // thread index rebuilt from the lane counter and the wavefront's index (held in a scalar register): three instructions wherever it
 // is needed, instead of one value that stays live -- and gets spilled -- across the whole receive call (rx_tid() keeps threadIdx.x
@@ -481,12 +528,6 @@ struct RxShared2 {
               };
             };
           };
-#ifdef RX2_SEARCH_FFT
-          struct {                                              // search / candidate state: FFT pilot correlator (the BPF is done with xm by then)
-            float2 fftX[FFT_N];
-            float fftscr[NW2][FFT_SCR];
-          };
-#endif
           struct {                                              // search / candidate state: pilot correlator on the matrix cores (rx2_detect_mfma)
             __attribute__((aligned(16))) _Float16 sA[2][5 * 2 * 64 * 8];   // the correlation table's A operands of one k-step, double-buffered (2 x 10 KB)
             unsigned srxh[RD_RXBUF], srxl[RD_RXBUF];            // rx_buf in two binary16 planes (as rxh / rxl in the synchronised state)
@@ -552,96 +593,6 @@ __device__ float sigma_r_from_rowsums2(RxShared2 *sh)
     return sigma_r_from_sums(v[0], v[1]);
 }
 
-#ifdef RX2_SEARCH_FFT
-// ---- |Dt| surfaces by FFT convolution (rx_detect_fft on four wavefronts: ten frequencies each; kept for A/B: tools/ab_build.sh fft -DRX2_SEARCH_FFT)
-__device__ __forceinline__ void rx2_detect_fft(RxShared2 *sh, const float *G_, const float *tw_, float *cache_, int cached, int oldb, int newb,
-                                               float &best, int &bt, int &bfi)
-{
-    const glb_float *G = (const glb_float *)G_, *tw = (const glb_float *)tw_; glb_float *cache = (glb_float *)cache_;
-    const int tid = rx_tid(), wave = tid >> 6, lane = tid & 63, q2 = lane >> 1, h = lane & 1;
-    lds_float *scr = (lds_float *)&sh->fftscr[wave][0];
-    lds_float *rxf = (lds_float *)&sh->rxb[0], *Xf = (lds_float *)&sh->fftX[0];
-    constexpr int NFW = RD_NFC / NW2;                                         // frequencies per wave
-#pragma unroll 1
-    for (int pass = cached ? 1 : 0; pass < 2; pass++) {
-        lds_float *x = rxf + 2 * pass * RD_NMF;
-        glb_float *dst = cache + (size_t)(pass ? newb : oldb) * RD_NFC * RD_NMF;
-        const glb_float *prev = cache + (size_t)oldb * RD_NFC * RD_NMF;
-        float2 v[32];
-        float rs[15], mx[15]; unsigned long long argw = 0ull;
-#pragma unroll
-        for (int p = 0; p < 15; p++) { rs[p] = 0.0f; mx[p] = -1.0f; }
-        // fi = -1: forward transform of the window (every wave repeats it and writes the whole spectrum: identical values, so a wave
-        // only ever reads what its own lanes -- or another wave, equally -- stored: a wave barrier suffices); fi >= 0: inverse transforms
-#pragma unroll 1
-        for (int fi = -1; fi < NFW; fi++) {
-            const int f = wave * NFW + fi;
-            if (fi < 0) {
-#pragma unroll
-                for (int k2 = 0; k2 < 32; k2++) {
-                    const int n = lane + 64 * k2;
-                    v[k2] = (k2 < 18 && n < RD_NMF + RD_M - 1) ? make_float2(x[2 * n], x[2 * n + 1]) : make_float2(0.0f, 0.0f);
-                }
-            } else {
-                const glb_float *Gf = G + (size_t)f * FFT_N * 2;
-                float2 g[32];
-#pragma unroll
-                for (int u = 0; u < 32; u++) { const int k = lane + 64 * u; g[u] = make_float2(Gf[2 * k], Gf[2 * k + 1]); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 32; u++) { const int k = lane + 64 * u; const float2 y = cmul(make_float2(Xf[2 * k], Xf[2 * k + 1]), g[u]); v[u] = make_float2(y.y, y.x); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const int t0 = q2 + 32 * h;
-            float d1[15];
-#pragma unroll
-            for (int p = 0; p < 15; p++) d1[p] = (pass && fi >= 0) ? prev[(size_t)f * RD_NMF + t0 + 64 * p] : 0.0f;
-            __builtin_amdgcn_sched_barrier(0);
-            fft2048_wave(v, scr, tw, lane);
-            if (fi < 0) {
-#pragma unroll
-                for (int p = 0; p < 32; p++) { const int k = q2 + 64 * p + 32 * h; Xf[2 * k] = v[brev5(p)].x; Xf[2 * k + 1] = v[brev5(p)].y; }
-                __builtin_amdgcn_wave_barrier();
-            } else {
-#pragma unroll
-                for (int p = 0; p < 15; p++) {
-                    const float2 c = v[brev5(p)];
-                    const float d = __builtin_amdgcn_sqrtf(fmaf(c.x, c.x, c.y * c.y));
-                    dst[(size_t)f * RD_NMF + t0 + 64 * p] = d;
-                    rs[p] += d;
-                    if (pass) { const float s12 = d1[p] + d; if (s12 > mx[p]) { mx[p] = s12; argw = (argw & ~(15ull << (4 * p))) | ((unsigned long long)fi << (4 * p)); } }
-                }
-            }
-        }
-        {
-            const int t0 = q2 + 32 * h;
-#pragma unroll
-            for (int p = 0; p < 15; p++) { scr[t0 + 64 * p] = rs[p]; scr[RD_NMF + t0 + 64 * p] = mx[p]; }
-            scr[2 * RD_NMF + 2 * lane] = __uint_as_float((unsigned)argw); scr[2 * RD_NMF + 2 * lane + 1] = __uint_as_float((unsigned)(argw >> 32));
-        }
-        __syncthreads();
-        for (int t = tid; t < RD_NMF; t += NT2) {
-            const int ln = 2 * (t & 31) + ((t >> 5) & 1), sh4 = 4 * (t >> 6);
-            float sum = 0.0f, lmax = -1.0f; int larg = 0;
-#pragma unroll
-            for (int w = 0; w < NW2; w++) {
-                lds_float *sw = (lds_float *)&sh->fftscr[w][0];
-                sum += sw[t];
-                const float m = sw[RD_NMF + t];
-                if (m > lmax) {
-                    const unsigned lo = __float_as_uint(sw[2 * RD_NMF + 2 * ln]), hi = __float_as_uint(sw[2 * RD_NMF + 2 * ln + 1]);
-                    const unsigned long long aw = ((unsigned long long)hi << 32) | lo;
-                    lmax = m; larg = w * NFW + (int)((aw >> sh4) & 15);
-                }
-            }
-            if (pass) { sh->rowsum2[t] = sum; if (lmax > best) { best = lmax; bt = t; bfi = larg; } }
-            else sh->rowsum1[t] = sum;
-        }
-        __syncthreads();
-    }
-}
-
-#endif
 
 // ---- |Dt| surfaces on the matrix cores ----------------------------------------------------------------------------------------------
 // acquisition.detect_pilots (dsp.py:178-231): Dt[t, f] = sum_m conj(rx[t + m]) p_w[m, f] for all 960 timings x 40 frequencies of a frame.
@@ -1389,10 +1340,6 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
             __syncthreads();
             tid = rx2_tid(wv);
             PH2(6);
-#ifdef RX2_SEARCH_FFT
-            if (CENSUS(512)) { float b_ = -1.0f; int t_ = 0x7fffffff, f_ = 0; rx2_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb, b_, t_, f_); asm volatile("" :: "v"(b_), "v"(t_), "v"(f_)); __syncthreads(); }
-            rx2_detect_fft(sh, a.fftG, a.ffttw, cache, cached ? 1 : 0, oldb, newb, best, bt, bfi);
-#else
             float rx_unsc;
             {   // operand planes of the whole rx_buf (as for check_pilots in the synchronised state: one power-of-two scale from the running maximum)
                 const unsigned mb = max(max(S->rxmax_cur, S->rxmax_h0), S->rxmax_h1);
@@ -1409,7 +1356,6 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
             }
             if (CENSUS(512)) { float b_ = -1.0f; int t_ = 0x7fffffff, f_ = 0; rx2_detect_mfma(sh, a.corr16, cache, cached ? 1 : 0, oldb, newb, rx_unsc, b_, t_, f_); asm volatile("" :: "v"(b_), "v"(t_), "v"(f_)); }
             rx2_detect_mfma(sh, a.corr16, cache, cached ? 1 : 0, oldb, newb, rx_unsc, best, bt, bfi);
-#endif
             PH2(7);
             block_argmax2(sh, best, bt, bfi);
             const float Dmax = best; const int tbest = bt, fbest = bfi;
@@ -1771,4 +1717,39 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
         if (S->n_calls) atomicAdd(&a.progress[0], S->n_calls);
         if (S->calls_inv < a.max_calls && S->valid_inv < a.feat_cap && S->consumed_inv + S->nin <= avail) atomicAdd(&a.progress[1], 1);
     }
+}
+
+
+// (re)initialise every stream's receiver state on the device (radae_rxe.py:128-142)
+__global__ __launch_bounds__(256) void k_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err)
+{
+    rd_rx_stream *s = st + blockIdx.x;
+    float *raw = (float *)s;
+    for (int i = threadIdx.x; i < (int)(sizeof(rd_rx_stream) / 4); i += blockDim.x) raw[i] = 0.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s->state = ST_SEARCH; s->nin = RD_NMF; s->mf = 1; s->bpf_mem_len = 100; s->lcg = seeds ? seeds[blockIdx.x] : 1u;
+        s->rx_phase[0] = 1.0; s->rx_theta = 0.0; s->bpf_phase[0] = 1.0f; s->foff_err = foff_err;
+    }
+}
+extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err, int B, rd_stream_t s)
+{
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_rx_reset, dim3(B), dim3(256), 0, (hipStream_t)s, st, seeds, foff_err);
+    return (int)hipGetLastError();
+}
+
+
+extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
+{
+    if (a->B <= 0) return 0;
+    hipLaunchKernelGGL(k_rx_sync2, dim3(a->B), dim3(NT2), a->lds_bytes, (hipStream_t)s, *a);
+    return (int)hipGetLastError();
+}
+// dynamic LDS of the receiver kernel (above the 64 KB default): set once per device by rade_batch_open, before any launch
+extern "C" int rd_rx_sync_prepare(int solo)
+{
+    const int l = solo ? 100 * 1024 : (int)sizeof(RxShared2);          // solo (developer switch): more than half the LDS = one workgroup per CU
+    if (hipFuncSetAttribute((const void *)k_rx_sync2, hipFuncAttributeMaxDynamicSharedMemorySize, l) != hipSuccess) return -1;
+    return l;
 }

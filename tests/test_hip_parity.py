@@ -124,14 +124,12 @@ def test_channel_df_dt_golden(Engine, torch_dev, golden, name):
     eng.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync / k_rx_sync2 (RADE_BATCH_RX_TWO_PER_CU)
 @pytest.mark.parametrize("name", RX_CASES + ["dfdt", "nounsync"])
-def test_rx_trace_golden(Engine, torch_dev, golden, name, rxflags, monkeypatch):
+def test_rx_trace_golden(Engine, torch_dev, golden, name, monkeypatch):
     import torch
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     g = golden("rxtrace_" + name)
     du = float(g["disable_unsync"]) if "disable_unsync" in g else 0.0       # radae_rxe.py --disable_unsync (ctests radae_rx_mpp / _mpg)
-    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags | (4 if name == "foff" else 0), disable_unsync=du)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=(4 if name == "foff" else 0), disable_unsync=du)
     feats, st, eoo = eng.rx(torch.tensor(g["rx_in"][None], device=torch_dev))
     d = eng.rx_trace(0)
     for k in INT_KEYS:
@@ -151,14 +149,12 @@ def test_rx_trace_golden(Engine, torch_dev, golden, name, rxflags, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
-def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden, rxflags, monkeypatch):
+def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden, monkeypatch):
     """One do_radae_rx call per invocation (the rade_rx() usage) == the whole stream at once."""
     import torch
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     g = golden("rxtrace_slip_plus")
     x = torch.tensor(g["rx_in"][None], device=torch_dev)
-    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
     fa, sa, _ = eng.rx(x)
     ta = eng.rx_trace(0)
     eng.rx_reset()
@@ -177,8 +173,7 @@ def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden, rxflags, monke
     eng.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
-def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_model, monkeypatch, rxflags):
+def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_model, monkeypatch):
     """The decoder stage runs inside the receiver kernel right before each unique-word decision
     (radae_rxe.py:220-224).  A RADE_FOFF_TEST frequency error and low SNR make windows fail.  The result must not
     depend on how the work is cut: one call per launch (RADE_ROUND_CALLS=1), a 3-row decoder buffer (the decoder runs
@@ -186,7 +181,6 @@ def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_mo
     other on everything, and with the oracle on the trace."""
     import torch
     from radae_amd.engine import sigma_from_EbNodB
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     n_mf = 40
     streams = []
     for seed, eb, fo in [(31, 20.0, 5.0), (32, -2.0, -20.0), (33, 1.0, 12.0)]:
@@ -199,7 +193,7 @@ def test_uw_failures_and_launch_granularity(Engine, torch_dev, oracle, oracle_mo
         if mode == "rows3": monkeypatch.setenv("RADE_DEC_ROWS", "3"); monkeypatch.setenv("RADE_ROUND_CALLS", "7")
         out = []
         for i, (feats, G, n_pre, noise, sigma, fo) in enumerate(streams):
-            eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=64, flags=rxflags | (4 if i == 0 else 0))   # stream 0: clean signal, 10 Hz off after sync entry
+            eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=64, flags=(4 if i == 0 else 0))   # stream 0: clean signal, 10 Hz off after sync entry
             iq = eng.tx(torch.tensor(feats[None], device=torch_dev))
             rx = eng.channel(iq, sigma, fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=torch.tensor(G[None], device=torch_dev),
                              noise=torch.tensor(noise[None], device=torch_dev))
@@ -234,8 +228,7 @@ def _make_stream(seed, n_mf, EbNodB, fo, chan):
     return feats, G, n_pre, noise
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
-def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_model, rxflags, monkeypatch):
+def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_model, monkeypatch):
     """4 streams with different channels/offsets, inputs never seen by the golden generator."""
     import torch
     from radae_amd.engine import sigma_from_EbNodB
@@ -244,8 +237,7 @@ def test_full_chain_vs_oracle_fresh_inputs(Engine, torch_dev, oracle, oracle_mod
     for seed, eb, fo, chan in cases:           # one engine per case: channel parameters are per call, not per stream
         feats, G, n_pre, noise = _make_stream(seed, n_mf, eb, fo, chan)
         sigma = sigma_from_EbNodB(eb)
-        monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
-        eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=48, flags=rxflags)
+        eng = Engine(1, max_tx_mf=n_mf, rx_trace_calls=48)
         iq = eng.tx(torch.tensor(feats[None], device=torch_dev))
         Gd = torch.tensor(G[None], device=torch_dev) if G is not None else None
         rx = eng.channel(iq, sigma, fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=Gd, noise=torch.tensor(noise[None], device=torch_dev))
@@ -344,15 +336,13 @@ def test_unbounded_operands_do_not_overflow(Engine, torch_dev, oracle, oracle_mo
     eng.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
-def test_rx_output_capacity_is_respected(Engine, torch_dev, golden, rxflags, monkeypatch):
+def test_rx_output_capacity_is_respected(Engine, torch_dev, golden, monkeypatch):
     """features_out rows are a capacity: a stream that has filled them pauses (consumed < available) instead of writing on;
     continuing with a fresh buffer gives the same frames as one big call."""
     import torch
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     g = golden("rxtrace_awgn")
     x = torch.tensor(g["rx_in"][None], device=torch_dev)
-    eng = Engine(1, max_tx_mf=1, flags=rxflags)
+    eng = Engine(1, max_tx_mf=1)
     full, st, _ = eng.rx(x)
     nv = st[0].n_valid
     assert nv == len(g["features_out"]) and nv > 6
@@ -366,8 +356,7 @@ def test_rx_output_capacity_is_respected(Engine, torch_dev, golden, rxflags, mon
     eng.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync (FFT pilot search) / k_rx_sync2 (pilot search + GRU recurrence on the matrix cores)
-def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_model, rxflags, monkeypatch):
+def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_model, monkeypatch):
     """tools/parity_sweep.py as a test: random channel (AWGN / MPP / MPD / MPG), Eb/No -1..12 dB, offset +-40 Hz, noise prefix; the oracle makes
     the received samples, both receivers consume exactly those.  Every per-call discrete output must be equal and the features within 1e-4 RMS --
     except for the documented refine() near-tie: all discrete outputs equal, fmax apart by less than 0.05 Hz because two 0.1 Hz bins
@@ -375,7 +364,6 @@ def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_m
     import torch
     from radae_amd.channel_tools import multipath_g, synth_features
     from radae_amd.engine import sigma_from_EbNodB
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     rng = np.random.default_rng(2027)
     n_mf, bad, ties, N = 24, [], 0, 32
     for case in range(N):
@@ -393,7 +381,7 @@ def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_m
         e = oracle.channel_eoo(tx.eoo(), noise[n_pre + n_sig:n_pre + n_sig + 1152], sigma, fo, 0.0, fin)
         full = np.concatenate([sigma * noise[:n_pre], r, e, sigma * noise[-1152:]]).astype(np.complex64)
         d = oracle.run_rx_stream(oracle_model, full)
-        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
+        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
         fo_dev, st, _ = eng.rx(torch.tensor(full[None], device=torch_dev))
         t = eng.rx_trace(0); nv = st[0].n_valid
         eng.close()
@@ -410,8 +398,7 @@ def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_m
     assert ties <= 3, ties
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
-def test_streams_are_independent_and_ragged(Engine, torch_dev, golden, rxflags, monkeypatch):
+def test_streams_are_independent_and_ragged(Engine, torch_dev, golden, monkeypatch):
     """Identical streams give bit-identical outputs whatever their slot; ragged / empty inputs are handled."""
     import torch
     g = golden("rxtrace_awgn")
@@ -421,8 +408,7 @@ def test_streams_are_independent_and_ragged(Engine, torch_dev, golden, rxflags, 
     avail = np.array([len(x), len(x), 5000, 0, 959], np.int32)
     for b in range(B):
         buf[b, :avail[b]] = x[:avail[b]]
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
-    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64)
     feats, st, _ = eng.rx(torch.tensor(buf, device=torch_dev), n_avail=avail)
     assert st[0].n_calls == len(g["ret"]) and st[1].n_calls == st[0].n_calls
     assert torch.equal(feats[0], feats[1])
@@ -518,8 +504,7 @@ def test_single_stream_c_abi(golden):
     h.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
-def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model, rxflags, monkeypatch):
+def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model, monkeypatch):
     """BASELINE workload size (256 x 1008 frames): properties that do not need the oracle at full size,
     plus the oracle on two of the streams (loss delta < 1e-4)."""
     import torch
@@ -530,8 +515,7 @@ def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model, rxf
     n_mf = T // 12
     base = [synth_features(3000 + u, T) for u in range(8)]
     feats = np.stack([base[b % 8] for b in range(B)])                 # 8 distinct utterances, replicated 32x
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
-    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=0, flags=rxflags)
+    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=0)
     iq = eng.tx(torch.tensor(feats, device=torch_dev))
     assert torch.equal(iq[:8], iq[248:256])                           # replicas bit-identical
     mag = iq.abs()
@@ -609,20 +593,18 @@ def test_channel_sine_interferer_and_gain(Engine, torch_dev, golden):
     eng.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])
-def test_impulses_in_the_receive_buffer(Engine, torch_dev, golden, oracle, oracle_model, rxflags, monkeypatch):
+def test_impulses_in_the_receive_buffer(Engine, torch_dev, golden, oracle, oracle_model, monkeypatch):
     """Dynamic range: check_pilots (both kernels) and the pilot search of k_rx_sync2 feed the matrix cores with rx_buf in two binary16 planes
     under ONE power-of-two scale taken from the running maximum of the buffer, so a click 50 .. 90 dB above the signal costs the signal that many
     bits of the 22.  The MPP golden input with two impulses of 300x / 30000x its RMS (in the noise prefix, and inside the synchronised part)
     must still give the oracle's discrete outputs call by call and its features."""
     import torch
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     base = golden("rxtrace_mpp")["rx_in"].astype(np.complex64)
     r = float(np.sqrt(np.mean(np.abs(base) ** 2)))
     for amp, pos in [(300.0, 5000), (300.0, 20000), (30000.0, 5000), (30000.0, 20000)]:
         x = base.copy(); x[pos] += amp * r * (1 + 1j) / np.sqrt(2); x[pos + 700] -= amp * r
         d = oracle.run_rx_stream(oracle_model, x)
-        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64, flags=rxflags)
+        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
         fo, st, _ = eng.rx(torch.tensor(x[None], device=torch_dev))
         t = eng.rx_trace(0); nv = st[0].n_valid
         eng.close()
@@ -632,9 +614,8 @@ def test_impulses_in_the_receive_buffer(Engine, torch_dev, golden, oracle, oracl
         assert rms(fo.cpu().numpy()[0, :nv], d["features_out"]) < 1e-5, (amp, pos)
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync (FFT pilot search) / k_rx_sync2 (pilot search + GRU recurrence on the matrix cores)
 @pytest.mark.parametrize("kind", ["noise", "sine"])
-def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind, rxflags, monkeypatch):
+def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind, monkeypatch):
     """The reference's acq_noise / acq_sine ctests (CMakeLists.txt:191-208): real-valued noise, or a 1 kHz sine in noise,
     converted with Q = 0 (int16tof32.py --zeropad), must never synchronise.  12 s per stream, 8 streams with different
     seeds; stream 0 is also checked call by call against the oracle."""
@@ -645,8 +626,7 @@ def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind, rxflags
     if kind == "sine":
         x += 0.25 * np.cos(2 * np.pi * 1000.0 / 8000.0 * np.arange(n))[None]
     rx = x.astype(np.float32).astype(np.complex64)                     # Q == 0
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
-    eng = Engine(B, max_tx_mf=1, rx_trace_calls=128, flags=rxflags)
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=128)
     f, st, _ = eng.rx(torch.tensor(rx, device=torch_dev))
     for b in range(B):
         assert st[b].n_calls == n // 960 and st[b].n_valid == 0 and st[b].sync == 0, (kind, b)
@@ -659,8 +639,7 @@ def test_must_not_acquire(Engine, torch_dev, oracle, oracle_model, kind, rxflags
     eng.close()
 
 
-@pytest.mark.parametrize("rxflags", [0, 0x200], ids=["one_stream_per_cu", "two_streams_per_cu"])     # k_rx_sync (FFT pilot search) / k_rx_sync2 (pilot search + GRU recurrence on the matrix cores)
-def test_acquisition_statistics_mpp(Engine, torch_dev, rxflags, monkeypatch):
+def test_acquisition_statistics_mpp(Engine, torch_dev, monkeypatch):
     """rx.py --acq_test in batch form (rx.py:163-195, ctest acq_mpp): 64 utterances at 0 dB Eb/No on the MPP channel with
     a +10 Hz offset.  Every stream must find sync, in less than 1.5 s of signal on average, with the entry timing inside
     the 2.5 ms window and the coarse frequency within 5 Hz of the truth for at least 80 % of the streams."""
@@ -670,8 +649,7 @@ def test_acquisition_statistics_mpp(Engine, torch_dev, rxflags, monkeypatch):
     B, n_mf, n_pre, fo = 64, 40, 4000, 10.0
     feats = np.stack([synth_features(300 + b, 12 * n_mf) for b in range(B)])
     G = np.stack([multipath_g("mpp", 8000, n_mf * 960, 900 + b) for b in range(B)])
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
-    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=64, flags=rxflags)
+    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=64)
     iq = eng.tx(torch.tensor(feats, device=torch_dev))
     rx = eng.channel(iq, sigma_from_EbNodB(0.0), fo, n_pre=n_pre, n_post=1152, with_eoo=True, G=torch.tensor(G, device=torch_dev), seed=5)
     f, st, _ = eng.rx(rx)
@@ -926,7 +904,6 @@ def test_tx_channel_one_pass_equals_two_calls(Engine, torch_dev, oracle, oracle_
     e1.close(); e2.close()
 
 
-RX2 = 0x200          # RADE_BATCH_RX_TWO_PER_CU (include/rade_batch.h)
 
 
 def test_rx2_replicas_agree_when_two_workgroups_share_a_cu(Engine, torch_dev, golden, monkeypatch):
@@ -934,11 +911,10 @@ def test_rx2_replicas_agree_when_two_workgroups_share_a_cu(Engine, torch_dev, go
     for, and the one in which packed f32 FMAs in its band-pass filter corrupted lanes 48..63.  Bit-identical in every
     slot, three fresh launches, and equal to the one-stream-per-CU kernel's discrete outputs."""
     import torch
-    monkeypatch.delenv("RADE_RX_VARIANT", raising=False)
     g = golden("rxtrace_mpp")
     B = 300
     buf = torch.tensor(np.stack([g["rx_in"]] * B), device=torch_dev)
-    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64, flags=RX2)
+    eng = Engine(B, max_tx_mf=1, rx_trace_calls=64, flags=0)
     ref = Engine(1, max_tx_mf=1, rx_trace_calls=64)
     fr, sr, _ = ref.rx(buf[:1].contiguous()); tr = ref.rx_trace(0)
     for rep in range(3):
