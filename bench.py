@@ -39,15 +39,16 @@ F32_PEAK_TFLOPS = 157.3          # MI355X f32 matrix == f32 vector peak (MI355X_
 HBM_PEAK_GBS = 8000.0
 # ---- executed-work model of k_rx_sync (SURVEY.md 8d figures) --------------------------------------------
 PREWARM_SECONDS = 1.5                            # see main(): untimed, before the W warm-up steps (the clocks of an idle GPU take about a second of load to settle)
-# SURVEY 8d's 866,560 cMAC per modem frame include the modulator's 24,000-cMAC IDFT, which runs in k_ofdm_mod, not in the receiver kernel
-RX_SYNC_CMAC = 866560 - 24000                    # the receiver's share: BPF, refine, check_pilots, demodulator DFT
-REF_SYNC_CALL_FLOP = RX_SYNC_CMAC * 8.0          # in-sync DSP per modem frame as the reference formulates it (8 flop per cMAC): 6.74 MFLOP
+# SURVEY 8d's 866,560 cMAC per modem frame include the modulator's 24,000-cMAC IDFT (k_ofdm_mod) and the 96,960-cMAC band-pass filter (k_rx_bpf), neither in the receiver kernel
+BPF_CMAC_PER_SAMPLE = 101                        # complex_bpf: 101 real taps on a complex sample; runs in k_rx_bpf ahead of the receiver kernel since round 4
+RX_SYNC_CMAC = 866560 - 24000 - 960 * BPF_CMAC_PER_SAMPLE   # the receiver kernel's share: refine, check_pilots, demodulator DFT (745,600 cMAC)
+REF_SYNC_CALL_FLOP = RX_SYNC_CMAC * 8.0          # in-sync DSP of the receiver kernel per modem frame as the reference formulates it (8 flop per cMAC): 5.96 MFLOP
 # executed: refine() in sync runs as 8 moments x 16 timings x 2 frames x 160 samples (40,960 cMAC) + the polynomials (640 x ~40 flop)
 # instead of 20 frequencies x 16 x 2 x 160 (102,400 cMAC): 0.47 MFLOP less per call
-SYNC_CALL_FLOP = (RX_SYNC_CMAC - 102400 + 40960) * 8.0 + 640 * 40.0     # 6.28 MFLOP
+SYNC_CALL_FLOP = (RX_SYNC_CMAC - 102400 + 40960) * 8.0 + 640 * 40.0     # 5.50 MFLOP
 ENC_STEP_FLOP = 2.0 * (96 * 64 + (64 + 224 + 384 + 544 + 704) * 192 + 2 * (128 + 288 + 448 + 608 + 768) * 96 + 864 * 80 + 5 * 64 * 192)   # CoreEncoder, one 40 ms step (4 feature frames): 1.87 MFLOP
 DEC_MF_FLOP = 3 * 904064 * 2.0                   # CoreDecoder, 3 steps per decoded modem frame (runs inside k_rx_sync): 5.42 MFLOP = 0.452 MFLOP per feature frame
-BPF_CALL_FLOP = 960 * 101 * 8.0                  # the BPF of a search / candidate call (it is inside SYNC_CALL_FLOP for synchronised ones): 0.78 MFLOP
+BPF_SAMPLE_FLOP = BPF_CMAC_PER_SAMPLE * 8.0      # band-pass pre-pass (k_rx_bpf), every received sample whatever the sync state: counted in whole_job, not in the receiver kernel
 FFT_SURFACE_FLOP = 41 * 5.0 * 2048 * 11 + 40 * 2048 * 6.0   # one |Dt| surface by FFT convolution: 1 forward + 40 inverse 2048-point FFTs (5 N log2 N) + 40 spectral products: 5.11 MFLOP (the cheapest formulation; both receiver kernels now run the 49-MFLOP GEMM form on the matrix cores and are still priced at this figure)
 REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation of detect_pilots (two surfaces as GEMMs): 98.3 MFLOP -- NOT executed here
 ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
@@ -57,7 +58,7 @@ PROFILE_TAG = "r04"                              # profiles/<tag>_pmc_summary.js
 
 
 def executed_flop(search_calls, sync_calls, decoded_mf):
-    return sync_calls * SYNC_CALL_FLOP + decoded_mf * DEC_MF_FLOP + search_calls * (FFT_SURFACE_FLOP + BPF_CALL_FLOP)
+    return sync_calls * SYNC_CALL_FLOP + decoded_mf * DEC_MF_FLOP + search_calls * FFT_SURFACE_FLOP
 
 
 def launch_plan(gpus, env, n_visible, argv, port=None):
@@ -308,15 +309,16 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         fl = executed_flop(counts["search_calls"], counts["sync_calls"], counts["decoded_modem_frames"])
         achieved = fl / (r["avg_launch_ms"] * 1e-3) / 1e12
         algo_bytes = RX_ALGO_BYTES_PER_FRAME * B * T
-        step_flop = fl + ENC_STEP_FLOP * B * T / 4 + 8.0 * B * (T // 12) * 5 * 30 * 160          # receiver + encoder + modulator IDFT, as executed
+        n_rx_samples = 8000 + (T // 12) * NMF + 1152 + 1152                                       # per stream: noise prefix, signal, EOO frame, tail
+        step_flop = fl + ENC_STEP_FLOP * B * T / 4 + 8.0 * B * (T // 12) * 5 * 30 * 160 + BPF_SAMPLE_FLOP * B * n_rx_samples   # receiver + encoder + modulator IDFT + band-pass pre-pass, as executed
         r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS,
                   "whole_job": {"executed_flop_per_step": step_flop, "executed_flop_per_frame": step_flop / (B * T), "achieved": value / world * step_flop / (B * T) / 1e12,
                                 "frac": value / world * step_flop / (B * T) / 1e12 / F32_PEAK_TFLOPS,
                                 "note": "every kernel's executed work (receiver as above + CoreEncoder GEMMs / recurrences + modulator) x the timed frames/s, against the same f32 peak: the figure that does not depend on how the kernels overlap"},
                   "per_launch_counts": counts, "executed_flop_per_launch": fl, "algorithmic_bytes_per_launch": algo_bytes,
-                  "flop_model": {"sync_call": SYNC_CALL_FLOP, "decoded_modem_frame": DEC_MF_FLOP, "search_call": FFT_SURFACE_FLOP + BPF_CALL_FLOP,
-                                 "note": "executed work: in-sync DSP 781,120 cMAC x 8 (refine by moments: 40,960 cMAC instead of the reference formulation's 102,400) + polynomials per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
-                                         "search call = one |Dt| surface PRICED as FFT convolution (41 x 5 N log2 N + 40 x 6 N, N = 2048: the cheapest formulation; the kernels evaluate it as a split-binary16 GEMM on the matrix cores, 49 MFLOP f32-equivalent, which is not counted) + BPF; priced at the f32 peak"},
+                  "flop_model": {"sync_call": SYNC_CALL_FLOP, "decoded_modem_frame": DEC_MF_FLOP, "search_call": FFT_SURFACE_FLOP, "bpf_sample_whole_job_only": BPF_SAMPLE_FLOP,
+                                 "note": "executed work of the receiver kernel: in-sync DSP 684,160 cMAC x 8 (refine by moments: 40,960 cMAC instead of the reference formulation's 102,400; the 96,960-cMAC band-pass filter runs in k_rx_bpf and is priced in whole_job only) + polynomials per synchronised call, decoder 3 x 904,064 MAC x 2 per decoded modem frame, "
+                                         "search call = one |Dt| surface PRICED as FFT convolution (41 x 5 N log2 N + 40 x 6 N, N = 2048: the cheapest formulation; the kernels evaluate it as a split-binary16 GEMM on the matrix cores, 49 MFLOP f32-equivalent, which is not counted) ; priced at the f32 peak"},
                   "hbm_frac_kernel": algo_bytes / (r["avg_launch_ms"] * 1e-3) / (HBM_PEAK_GBS * 1e9),
                   "equiv_ref_formulation": {"tflops": (counts["sync_calls"] * REF_SYNC_CALL_FLOP + counts["decoded_modem_frames"] * DEC_MF_FLOP + counts["search_calls"] * REF_SEARCH_CALL_FLOP)
                                             / (r["avg_launch_ms"] * 1e-3) / 1e12,

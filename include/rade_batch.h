@@ -150,11 +150,14 @@ typedef struct {
 /* copies up to max_calls records + 240-float z_hat rows per call of stream b to host; returns #calls traced */
 int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls);
 
+/* test aid: the band-pass filtered samples (complex_bpf.bpf, dsp.py:63-102) the receiver of the most recent rade_batch_rx invocation read for
+ * stream b -> out_host [n] complex64 (host memory); returns the number copied, < 0 on error */
+int rade_batch_rx_filtered(rade_batch *h, int b, void *out_host, int n);
 /* measurement aid: shader-clock cycles each stream's workgroup spent in the most recent receiver launch -> out_host[B]; returns B */
 int rade_batch_rx_stream_cycles(rade_batch *h, long long *out_host);
 
 /* ---- measurement hook (bench.py): per-kernel-class HIP-event timing, off by default ---------- */
-enum { RADE_PROF_GEMM = 0, RADE_PROF_SCAN, RADE_PROF_MOD, RADE_PROF_CHAN, RADE_PROF_SYNC, RADE_PROF_POST, RADE_PROF_NCLASS };
+enum { RADE_PROF_GEMM = 0, RADE_PROF_SCAN, RADE_PROF_MOD, RADE_PROF_CHAN, RADE_PROF_SYNC, RADE_PROF_BPF, RADE_PROF_NCLASS };
 void rade_batch_profile(rade_batch *h, int enable);
 /* accumulated since enable: device milliseconds, algorithmic FLOPs, launches */
 int rade_batch_profile_get(rade_batch *h, int cls, double *ms, double *work, long *launches);

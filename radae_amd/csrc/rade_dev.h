@@ -53,18 +53,27 @@ typedef struct {
     float pad;
 } rd_tables;
 
+/* what complex_bpf carries from call to call (dsp.py:54-61, :96-99): one record per stream and filter (receiver input filter; transmit filter) */
+typedef struct {
+    int mem_len;                        /* samples of memory: Ntap - 1 = 100 before the first call, Ntap + 1 = 102 afterwards (dsp.py:55 against :96) */
+    int grid_off;                       /* receiver: the stream left the block grid of the invocation's pre-pass (a timing slip inside the invocation) and filters its own samples until the invocation ends */
+    float phase[2];                     /* the complex64 mixer phase after the last sample filtered */
+    float mem[102][2];                  /* the last mem_len baseband samples, oldest first */
+} rd_bpf_state;
+
 /* per-stream receiver state (HBM, one record per stream, touched by exactly one workgroup) */
 typedef struct {
     int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf;
-    int f_ind_max, dec_reset_pending, bpf_mem_len, n_out_frames;
-    uint32_t lcg; int has_eoo, dt_valid, pad1;
+    int f_ind_max, dec_reset_pending, n_out_frames, pad0;
+    uint32_t lcg; int has_eoo, dt_valid;
+    int pad1;
     double fmax, foff_err, rx_phase[2];
     double rx_theta;                 /* k_rx_sync2 keeps rx_phase as its angle (rx_phase = e^{j rx_theta}); carried exactly, so results do not depend on how calls are cut into launches */
     double Dthresh, Dtmax12, Dtmax12_eoo;
-    float snr_est, bpf_phase[2], pad2;
+    float snr_est, pad2[3];
     unsigned rxmax[4];                  /* float bits: largest |re|,|im| of the filtered samples of the last three calls (check_pilots operand scale) */
     long long consumed;                 /* samples consumed since reset */
-    float bpf_mem[102][2];
+    rd_bpf_state bpf;                   /* input band-pass filter (radae_rxe.py:104-109, :194-195) */
     float rx_buf[RD_RXBUF][2];
     float rowsum1[RD_NMF], rowsum2[RD_NMF];   /* sum_f |Dt1[t,f]|, |Dt2[t,f]|: all check_pilots ever reads back */
 } rd_rx_stream;
@@ -172,7 +181,9 @@ typedef struct {
 
 typedef struct {
     const rd_tables *tab; rd_rx_stream *st; rd_rx_round *round;
-    const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride */
+    const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride (raw input: the receiver only reads it to rebuild the filter memory) */
+    void *rxf; long rxf_stride;                          /* band-pass filtered samples of the invocation (k_rx_bpf), same indexing as rx */
+    const void *bpf_chain; int chain_stride;             /* [B][chain_stride] float2: (nin0, mem_len0) + the block phases of the pre-pass */
     int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
     int max_calls;                                       /* call budget per stream per invocation */
     int unsync_off_after;                                /* radae_rxe.py:277-281: synced_count beyond which the unsync paths are disabled; < 0 = never */
@@ -198,6 +209,10 @@ int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
 /* once per device before the first launch (rade_batch_open): raises the kernel's dynamic-LDS limit; returns the bytes to launch with, < 0 on error */
 int rd_rx_sync_prepare(int solo);
 
+/* complex_bpf.bpf (dsp.py:63-102) for every sample of a rade_batch_rx invocation, ahead of the receiver launches: chain [B][chain_stride] float2
+ * (chain_stride >= n_blocks + 3), rxf [B][rxf_stride] complex64; n_blocks = 1 + ceil(max(avail) / 800) covers every stream */
+int rd_launch_rx_bpf(rd_rx_stream *st, const rd_tables *tab, const void *rx, long rx_stride, const int *avail_dev, void *chain, int chain_stride,
+                     void *rxf, long rxf_stride, int n_blocks, int B, rd_stream_t s);
 int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
 
 /* ---- one core encoder / decoder step of ONE stream as one launch (rade_core_step.hip; include/rade_core.h) ----

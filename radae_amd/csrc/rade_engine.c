@@ -50,6 +50,7 @@ struct rade_batch {
     rd_rx_stream *rx_st; rd_rx_round *rx_round;
     int *rx_avail, *rx_acc, *rx_progress, *rx_status;
     float *zrows, *dec_x, *dec_gi, *dec_hbuf, *dec_h[5], *feat84, *dtcache;
+    void *rx_filt; float *bpf_chain; long filt_cap; int chain_stride;   /* band-pass pre-pass of an invocation: filtered samples [B][filt_cap] c64 and block phases [B][chain_stride] c64, grown on demand */
     rd_rx_trace *trace; float *trace_z;
     long long *wg_cycles;            /* [B] per-stream cycles of the last receiver launch */
     int *h_small;                    /* pinned host scratch */
@@ -80,7 +81,9 @@ static void *dev_zeros(size_t bytes)
 {
     void *d = NULL;
     if (hipMalloc(&d, bytes) != hipSuccess) return NULL;
-    if (hipMemset(d, 0, bytes) != hipSuccess) { hipFree(d); return NULL; }
+    /* complete before returning: the memset runs on the null stream, which is not ordered against a caller's non-blocking stream (buffers
+     * allocated on first use inside a stream-ordered call would otherwise be zeroed on top of what that call's kernels wrote) */
+    if (hipMemset(d, 0, bytes) != hipSuccess || hipStreamSynchronize(NULL) != hipSuccess) { hipFree(d); return NULL; }
     return d;
 }
 
@@ -329,7 +332,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
+                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -634,11 +637,32 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     const int B = h->B;
     hipStream_t st = (hipStream_t)stream;
     int *hs = h->h_small;
+    /* complex_bpf.bpf for every sample of this invocation, ahead of the receiver launches (rade_rx.hip: k_rx_bpf).  The buffers follow the
+     * largest invocation seen (a few times the input: 8 bytes per sample and stream); growing them waits for the device. */
+    int max_avail = 0;
+    for (int b = 0; b < B; b++) if (n_avail_host[b] > max_avail) max_avail = n_avail_host[b];
+    if (max_avail > 0 && !rx_dev) return -1;
+    const int n_blocks = max_avail > 0 ? 2 + (max_avail - 1) / 800 : 0;          /* blocks of >= 800 samples (a first block after a slip), the tail included */
+    if (max_avail > h->filt_cap || n_blocks + 3 > h->chain_stride) {
+        CHK(hipDeviceSynchronize());
+        if (h->rx_filt) hipFree(h->rx_filt);
+        if (h->bpf_chain) hipFree(h->bpf_chain);
+        h->filt_cap = ((long)max_avail + 1023) & ~1023L; h->chain_stride = (int)(h->filt_cap / 800) + 8;
+        /* (no memset: a hipMemset on the null stream is not ordered against the caller's non-blocking stream and could land on top of the
+         * pre-pass's results; every entry that is read is written by the pre-pass first) */
+        h->rx_filt = NULL; h->bpf_chain = NULL;
+        if (hipMalloc(&h->rx_filt, sizeof(float) * 2 * (size_t)B * h->filt_cap) != hipSuccess) h->rx_filt = NULL;
+        if (hipMalloc((void **)&h->bpf_chain, sizeof(float) * 2 * (size_t)B * h->chain_stride) != hipSuccess) h->bpf_chain = NULL;
+        if (!h->rx_filt || !h->bpf_chain) { h->filt_cap = 0; h->chain_stride = 0; fprintf(stderr, "rade: device allocation failed (receiver pre-pass buffers)\n"); return -1; }
+    }
     CHK(hipMemcpyAsync(h->rx_avail, n_avail_host, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    PROF_BEGIN(h, st);
+    if (rd_launch_rx_bpf(h->rx_st, h->d_tab, rx_dev, rx_stride, h->rx_avail, h->bpf_chain, h->chain_stride, h->rx_filt, h->filt_cap, n_blocks, B, st)) goto fail;
+    PROF_END(h, st, RADE_PROF_BPF, 8.0 * 101.0 * (double)B * max_avail);
     CHK(hipMemsetAsync(h->rx_acc, 0, sizeof(int) * B * 4, st));
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
-    sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
+    sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.rxf = h->rx_filt; sa.rxf_stride = h->filt_cap; sa.bpf_chain = h->bpf_chain; sa.chain_stride = h->chain_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
     sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_census << 8; sa.lds_bytes = h->rx_lds;
@@ -680,6 +704,17 @@ int rade_batch_rx_stream_cycles(rade_batch *h, long long *out_host)
     if (!h || !out_host || !h->wg_cycles) return -1;
     ON_DEV(h);
     return hipMemcpy(out_host, h->wg_cycles, sizeof(long long) * h->B, hipMemcpyDeviceToHost) == hipSuccess ? h->B : -1;
+}
+
+/* test / measurement aid: the band-pass filtered samples (complex_bpf.bpf, dsp.py:63-102) the most recent rade_batch_rx invocation's receiver read
+ * for stream b, first n of them -> out_host [n] complex64; returns the count copied */
+int rade_batch_rx_filtered(rade_batch *h, int b, void *out_host, int n)
+{
+    if (!h || b < 0 || b >= h->B || !out_host || !h->rx_filt) return -1;
+    ON_DEV(h);
+    if (n > h->filt_cap) n = (int)h->filt_cap;
+    if (n <= 0) return 0;
+    return hipMemcpy(out_host, (const char *)h->rx_filt + sizeof(float) * 2 * (size_t)b * h->filt_cap, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost) == hipSuccess ? n : -1;
 }
 
 int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls)

@@ -36,11 +36,11 @@ struct DqGemm {
 
 enum { ST_SEARCH = 0, ST_CANDIDATE = 1, ST_SYNC = 2 };
 struct RxScalars {
-    int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, bpf_mem_len, has_eoo;
+    int state, nin, tmax, tmax_candidate, valid_count, uw_errors, synced_count, mf, f_ind_max, dec_reset_pending, has_eoo;
     uint32_t lcg;
     unsigned rxmax_cur, rxmax_h0, rxmax_h1;   // float bits of max |re|,|im| of the filtered samples of this call / the two calls before (check_pilots operand scale)
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
-    int pf_n;                 // samples of the NEXT call already mixed down into xm[102..] by the end of this (synchronised) call; 0 = none
+    int bpf_grid, nin0;       // the stream's calls still follow the block grid of the invocation's band-pass pre-pass (k_rx_bpf); the grid's first block length
     int entry;                // this candidate call enters sync (decided by thread 0 before a barrier: see do_entry)
     int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
     float snr_est, mag; float2 bpf_phase;
@@ -498,8 +498,6 @@ __device__ void dq2_layers(DecShared2 *sh, const rd_decs_args &a, int b, const f
 // =====================================================================================================
 struct RxShared2 {
     RxScalars S;
-    float2 bmem[102];                     // BPF memory (dsp.py:55,96)
-    __attribute__((aligned(16))) float bpf_h[RD_NTAP + 3];
     double2 rq[4], rzc, rph[24], rrot[24]; double ral[24];   // refine(), in-sync grid: e^{-jw_c 40 q}, e^{-jw_c}, e^{-j(w_k - w_c) 79.5}, e^{-jw_k Nmf}, (w_k - w_c) 80
     int rows48[48];
     double redd[(NW2 + 1) * 10];
@@ -1089,10 +1087,64 @@ __device__ __forceinline__ void check2_rows_tiles(RxShared2 *sh, const unsigned 
     }
 }
 
-#ifdef RX2_DEBUG_SUMS
-__device__ float2 *g_rx2_dbg;          // [B][32][1120]: the filtered samples every call appended to rx_buf (developer aid)
-extern "C" void rd_debug_set_buf(void *p) { hipMemcpyToSymbol(HIP_SYMBOL(g_rx2_dbg), &p, sizeof p); }
-#endif
+// ---- band-pass filter (complex_bpf, dsp.py:39-102) ahead of the receiver -----------------------------------------------------------------
+// The filter is a stateful streaming FIR of the input: mix down with a running phase, 101 real taps, mix up.  Nothing in it depends on the sync
+// state machine, so it runs as a bulk pre-pass over all the samples of a rade_batch_rx invocation (k_rx_bpf_chain + k_rx_bpf) and the receiver
+// kernel reads filtered samples.  What the reference's arithmetic does depend on is how the stream is cut into calls: the phase is a complex64
+// carried from call to call (phase_vec = phase * phase_vec_exp[0:n], self.phase = phase_vec[-1]: dsp.py:70-71, :99).  The pre-pass therefore
+// follows the reference's own partition: block 0 = the nin the stream's next call will consume (from its state record), every later block Nmf
+// samples -- exact unless a timing slip changes nin INSIDE an invocation; from that call on the stream filters its own samples (rx2_bpf_own)
+// until the invocation ends, and the next invocation's pre-pass starts from the state it left.  Either way every output sample is what
+// complex_bpf.bpf would have produced for the stream's actual sequence of calls, value for value (taps in ascending order, one fused
+// multiply-add per component and tap), so cutting a stream into invocations differently cannot move a bit.
+//   chain[b] (float2 [chain_stride]): entry 0 = (nin0, mem_len0) as integer bits, entry 1 + k = the phase block k starts from.
+// Memory quirk kept (dsp.py:55 against :96): the memory holds Ntap - 1 = 100 samples before the first call and Ntap + 1 = 102 after it while the
+// strided window always starts at index 0, so outputs are delayed by two more samples from the second call on.
+
+// baseband sample q of the invocation (x[q] times the phase of its block), q >= -102: the filter memory a stream needs when it leaves the grid or
+// the launch ends; negative q reaches into the memory the invocation started with
+__device__ __forceinline__ float2 rx2_bpf_mem(const rd_sync_args &a, int b, int nin0, int q)
+{
+    const rd_rx_stream *st = a.st + b;
+    if (q < 0) return make_float2(st->bpf.mem[102 + q][0], st->bpf.mem[102 + q][1]);
+    const float2 *x = (const float2 *)a.rx + (size_t)b * a.rx_stride;
+    const float2 *chain = (const float2 *)a.bpf_chain + (size_t)b * a.chain_stride;
+    const int k = q < nin0 ? 0 : 1 + (q - nin0) / RD_NMF, sk = k ? nin0 + (k - 1) * RD_NMF : 0;
+    return cmul(x[q], cmul(chain[1 + k], ld2(a.tab->bpf_E, q - sk)));
+}
+
+// One call's filtering by the stream's own workgroup (off the grid).  Cold path: one output at a time per thread, memory in the stream record.
+__device__ __forceinline__ void rx2_bpf_own(RxShared2 *sh, const rd_sync_args &a, int b, float2 *rxf, int cons0, int nin, int calls0)
+{
+    RxScalars *S = &sh->S;
+    rd_rx_stream *st = a.st + b;
+    const rd_tables *tab = a.tab;
+    const float2 *x = (const float2 *)a.rx + (size_t)b * a.rx_stride;
+    const int tid = rx_tid();
+    float2 ph;
+    if (S->bpf_grid) {          // leaving the grid at this call: memory = the 102 baseband samples before it, phase = the chain's value at this block boundary
+        ph = ((const float2 *)a.bpf_chain)[(size_t)b * a.chain_stride + 1 + calls0];
+        for (int i = tid; i < 102; i += NT2) sh->xm[i] = rx2_bpf_mem(a, b, S->nin0, cons0 - 102 + i);
+    } else {
+        ph = S->bpf_phase;
+        for (int i = tid; i < 102; i += NT2) sh->xm[i] = make_float2(st->bpf.mem[i][0], st->bpf.mem[i][1]);
+    }
+    float *hl = (float *)&sh->xm[1224];                    // the taps, behind [memory | new] (102 + 1120 entries)
+    for (int i = tid; i < RD_NTAP; i += NT2) hl[i] = tab->bpf_h[i];
+    for (int i = tid; i < nin; i += NT2) sh->xm[102 + i] = cmul(x[cons0 + i], cmul(ph, ld2(tab->bpf_E, i)));
+    __syncthreads();
+#pragma unroll 1
+    for (int i = tid; i < nin; i += NT2) {
+        float ar = 0.0f, ai = 0.0f;
+#pragma unroll 4
+        for (int t = 0; t < RD_NTAP; t++) { const float2 v = sh->xm[i + t]; const float h = hl[t]; ar = fmaf(v.x, h, ar); ai = fmaf(v.y, h, ai); }
+        rxf[cons0 + i] = cmul(make_float2(ar, ai), cconj(cmul(ph, ld2(tab->bpf_E, i))));
+    }
+    for (int i = tid; i < 102; i += NT2) { const float2 m = sh->xm[nin + i]; st->bpf.mem[i][0] = m.x; st->bpf.mem[i][1] = m.y; }
+    if (tid == 0) { S->bpf_phase = cmul(ph, ld2(tab->bpf_E, nin - 1)); S->bpf_grid = 0; }
+    __syncthreads();
+}
+
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
 #define DPP_ROW_HALF_MIRROR 0x141   /* lane i <-> 7 - i inside every group of eight lanes */
 
@@ -1110,20 +1162,19 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
 
     // ---- load the stream's working set into LDS
     for (int i = tid; i < RD_RXBUF; i += NT2) sh->rxb[i] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]);
-    for (int i = tid; i < RD_NTAP; i += NT2) sh->bpf_h[i] = tab->bpf_h[i];
     for (int i = tid; i < RD_NMF; i += NT2) { sh->rowsum1[i] = st->rowsum1[i]; sh->rowsum2[i] = st->rowsum2[i]; }
-    for (int i = tid; i < 102; i += NT2) sh->bmem[i] = make_float2(st->bpf_mem[i][0], st->bpf_mem[i][1]);
     if (tid == 0) {
         S->state = st->state; S->nin = st->nin; S->tmax = st->tmax; S->tmax_candidate = st->tmax_candidate; S->valid_count = st->valid_count;
         S->uw_errors = st->uw_errors; S->synced_count = st->synced_count; S->mf = st->mf; S->f_ind_max = st->f_ind_max;
-        S->dec_reset_pending = st->dec_reset_pending; S->bpf_mem_len = st->bpf_mem_len; S->has_eoo = st->has_eoo; S->lcg = st->lcg;
+        S->dec_reset_pending = st->dec_reset_pending; S->has_eoo = st->has_eoo; S->lcg = st->lcg;
         S->rxmax_cur = st->rxmax[0]; S->rxmax_h0 = st->rxmax[1]; S->rxmax_h1 = st->rxmax[2];
         S->fmax = st->fmax; S->foff_err = st->foff_err; S->rph_th = st->rx_theta;     // rx_phase (radae_rxe.py:227-233) kept as its angle: see the corrected window
         S->Dthresh = st->Dthresh; S->Dtmax12 = st->Dtmax12; S->Dtmax12_eoo = st->Dtmax12_eoo; S->snr_est = st->snr_est;
-        S->bpf_phase = make_float2(st->bpf_phase[0], st->bpf_phase[1]);
+        S->bpf_phase = make_float2(st->bpf.phase[0], st->bpf.phase[1]);      // only used off the grid (rx2_bpf_own)
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
         S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0; S->pf_n = 0;
+        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0;
+        S->bpf_grid = st->bpf.grid_off == 0; S->nin0 = __float_as_int(((const float *)a.bpf_chain)[(size_t)b * a.chain_stride * 2]);
     }
     const int avail = a.avail[b];
     const long long wg_t0 = clock64();
@@ -1139,7 +1190,6 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
             const int go = (int)(calls_inv < a.max_calls) & (int)(n_calls < a.round_calls) & (int)(valid_inv < a.feat_cap) & (int)(consumed + nin_n <= avail);
             const int need = (int)(n_rows > 0) & ((go ^ 1) | ((int)(st_n == ST_SYNC) & (int)(((sc + 1) % 8) == 0)) | (int)(n_rows + 3 > a.dec_rows));
             S->need_decode = need; S->go = go;
-            if ((go ^ 1) | need) S->pf_n = 0;
             S->rxmax_h1 = go ? m0 : m2; S->rxmax_h0 = go ? m1 : m0; S->rxmax_cur = go ? 0u : m1;
             S->state_before = st_n; S->nin_before = nin_n;
             S->valid_output = 0; S->endofover = 0; S->uw_fail = 0; S->candidate = 0;
@@ -1152,7 +1202,7 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
         PH2(1);
         if (S->need_decode) { rx2_decode_pending(sh, a, b); PH2(2); }
         if (!S->go) break;
-        const int nin = S->nin, state = S->state, ml = S->bpf_mem_len;
+        const int nin = S->nin, state = S->state;
         const int mf0 = S->mf, n_rows0 = S->n_rows;
         auto state_update = [&](int entry, int valid_out, int eoo) {
             int next_state = state;
@@ -1185,141 +1235,46 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
             rnd->call_ret[nc] = ret; rnd->call_row_lo[nc] = S->uw_from_row; rnd->call_row_hi[nc] = S->n_rows; rnd->call_trace_idx[nc] = call_idx;
             S->n_calls = nc + 1; S->calls_inv++;
         };
-        const float2 bpf_phase = S->bpf_phase;
-        const int cons0 = S->consumed_inv;
-        const float2 *xin = rxin + cons0;
-        const bool staged = S->pf_n == nin && ml == 102;
-#ifdef RX2_DEBUG_SUMS
-        if (tid == 0) { sh->redi[13] = 0; sh->redi[14] = 0; sh->redi[12] = 0; }
-#endif
-        // ---- complex_bpf.bpf (dsp.py:63-102)
-        for (int i = tid; i < ml; i += NT2) sh->xm[i] = sh->bmem[i];
-        if (!staged) for (int i = tid; i < nin; i += NT2) { sh->xm[ml + i] = cmul(xin[i], cmul(bpf_phase, ld2(tab->bpf_E, i))); }
-        if (state == ST_SYNC && !S->lds_sync) {      // pilot replicas and equaliser constants share LDS with the FFT correlator and the decoder stage
+        const int cons0 = S->consumed_inv, calls0 = S->calls_inv;
+        // ---- complex_bpf.bpf (dsp.py:63-102) ran ahead of this kernel for every sample of the invocation (k_rx_bpf): the filter does not depend on
+        // any sync decision.  This call's nin filtered samples are rxf[cons0 ..) as long as the stream's calls follow the pre-pass's block grid (first
+        // block = the nin the invocation started with, then Nmf each: the reference's own call partition unless nin changes inside an invocation);
+        // after such a timing slip the stream filters the rest of the invocation's samples itself (rx2_bpf_own: same arithmetic, cold path).
+        float2 *rxf = (float2 *)a.rxf + (size_t)b * a.rxf_stride;
+        if (!(S->bpf_grid && nin == (calls0 ? RD_NMF : S->nin0))) { rx2_bpf_own(sh, a, b, rxf, cons0, nin, calls0); tid = rx2_tid(wv); }
+        constexpr int NNEW = (RD_NINMAX + NT2 - 1) / NT2;
+        float2 nv[NNEW];
+#pragma unroll
+        for (int q = 0; q < NNEW; q++) { const int i = tid + q * NT2; nv[q] = i < nin ? rxf[cons0 + i] : make_float2(0.0f, 0.0f); }
+        if (state == ST_SYNC && !S->lds_sync) {      // pilot replicas and equaliser constants share LDS with the pilot search and the decoder stage
             for (int i = tid; i < RD_M; i += NT2) { sh->pd[i] = make_double2(tab->p[i][0], tab->p[i][1]); sh->pendd[i] = make_double2(tab->pend[i][0], tab->pend[i][1]); }
             if (tid < RD_NC) { sh->eqP[tid] = tab->P[tid]; sh->eqrot[tid] = make_float2(tab->eq_rot[tid][0], tab->eq_rot[tid][1]); }
             if (tid < RD_NC * 6) { const int c = tid / 6, r = tid - 6 * c; sh->eqPmat[c][r / 3][r % 3] = make_float2(tab->Pmat[c][r / 3][r % 3][0], tab->Pmat[c][r / 3][r % 3][1]); }
             if (tid == 0) { sh->eq_pg = tab->pilot_gain; sh->eq_snrc1 = tab->snr_c1; sh->eq_snrc2 = tab->snr_c2; }
         }
-        __syncthreads();
-        tid = rx2_tid(wv);
-#ifdef RX2_DEBUG_SUMS
-        { unsigned v = 0; for (int i = tid; i < ml + nin; i += NT2) v ^= (__float_as_uint(sh->xm[i].x) * 31u + __float_as_uint(sh->xm[i].y)) * (unsigned)(i + 1); atomicXor((unsigned *)&sh->redi[14], v); }
-        { unsigned v = 0; for (int i = tid; i < RD_RXBUF; i += NT2) v ^= (__float_as_uint(sh->rxb[i].x) * 31u + __float_as_uint(sh->rxb[i].y)) * (unsigned)(i + 1); atomicXor((unsigned *)&sh->redi[12], v); }
-#endif
-        if (tid == 0 && state == ST_SYNC) S->lds_sync = 1;
-        const float2 e_last = ld2(tab->bpf_E, nin - 1);
-        // side jobs of the call (they only depend on last call's results)
-        // (all on the fourth wavefront, which has no part in the FIR: six outputs per thread cover 1152 >= nin_max samples on the other three)
-        if (state == ST_SYNC && tid >= NT2 - 64) { const double fm = S->fmax; refine2_tables_sync(sh, tid - (NT2 - 64), fm - 1.0, fm + 1.0, 0.1); }
-        if (state == ST_SYNC) {                       // check_pilots' 48 row draws: computed by everybody, stored by 48 threads (no work inside a partial-EXEC block)
-            const int k = min(tid & 63, 47);
-            const uint32_t x = LCG_A[k] * S->lcg + LCG_C[k];
-            const int row = (int)((x >> 8) % RD_NMF);
-            if (tid >= 192 && tid < 192 + 48) sh->rows48[k] = row;
-            if (tid == 192 + 47) sh->redi[15] = (int)x;
-        }
-        if (tid >= 192) {                             // first touch of the next call's samples (see k_rx_sync)
-            const int l = tid - 192, rem = min(avail - cons0 - nin, RD_NINMAX);
-            float t = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 2; q++) { const int i = (l + 64 * q) * 16; if (i < rem) t += xin[nin + i].x; }
-            asm volatile("" :: "v"(t));
-        }
         PH2(3);
-        // 101-tap FIR, six consecutive outputs per thread over a sliding register window; taps accumulate in ascending order.
-        // Plain v_fma_f32, NOT v_pk_fma_f32: with the packed form (what k_rx_sync uses) and a workgroup of ANOTHER launch on the same
-        // CU, one accumulator now and then came out wrong in lanes 48..63 of a wavefront -- identical inputs (checksummed), 5..40 of
-        // 300 replicated streams per run, never with one workgroup per CU, never with scalar FMAs (tools/replica_debug.py;
-        // DESIGN.md 3.7).  A packed FMA issues at half rate on this chip, so nothing is lost.
-        constexpr int NO = 6;
-        float2 filt[NO];
-        {
-            const int i0 = NO * tid;
-            float2 eup[NO];
-#pragma unroll
-            for (int j = 0; j < NO; j++) eup[j] = ld2(tab->bpf_E, min(i0 + j, RD_NINMAX - 1));
-            f32x2 acc[NO];
-#pragma unroll
-            for (int j = 0; j < NO; j++) acc[j] = (f32x2){ 0.0f, 0.0f };
-            for (int rep = CENSUS_REPS(4); rep > 0; rep--)
-            if (i0 < nin) {
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < NO; j++) acc[j] = (f32x2){ 0.0f, 0.0f };
-                const f32x2 *xm2 = (const f32x2 *)sh->xm;
-#pragma unroll 2
-                for (int kb = 0; kb < 96; kb += 8) {
-                    f32x2 x[8 + NO - 1]; float h[8];
-#pragma unroll
-                    for (int u = 0; u < 8 + NO - 1; u++) x[u] = xm2[i0 + kb + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) h[u] = sh->bpf_h[kb + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-#pragma unroll
-                        for (int j = 0; j < NO; j++) { acc[j][0] = fmaf(x[u + j][0], h[u], acc[j][0]); acc[j][1] = fmaf(x[u + j][1], h[u], acc[j][1]); }
-                    }
-                }
-                {
-                    f32x2 x[5 + NO - 1]; float h[5];
-#pragma unroll
-                    for (int u = 0; u < 5 + NO - 1; u++) x[u] = xm2[i0 + 96 + u];
-#pragma unroll
-                    for (int u = 0; u < 5; u++) h[u] = sh->bpf_h[96 + u];
-#pragma unroll
-                    for (int u = 0; u < 5; u++) {
-#pragma unroll
-                        for (int j = 0; j < NO; j++) { acc[j][0] = fmaf(x[u + j][0], h[u], acc[j][0]); acc[j][1] = fmaf(x[u + j][1], h[u], acc[j][1]); }
-                    }
-                }
-#ifdef RX2_CENSUS
-#pragma unroll
-                for (int j = 0; j < NO; j++) asm volatile("" :: "v"(acc[j][0]), "v"(acc[j][1]));
-#endif
-            }
-            float mloc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NO; j++) {
-                const int i = i0 + j;
-                filt[j] = make_float2(0.0f, 0.0f);
-                if (i < nin) filt[j] = cmul(make_float2(acc[j][0], acc[j][1]), cconj(cmul(bpf_phase, eup[j])));
-                mloc = fmaxf(mloc, fmaxf(fabsf(filt[j].x), fabsf(filt[j].y)));
-            }
-            mloc = wave_max_f32(mloc);
-            if ((tid & 63) == 0) atomicMax(&S->rxmax_cur, __float_as_uint(mloc));
-        }
-        PH2(4);
-        // new BPF memory = last 102 of [mem | new]; rx_buf shift (radae_rxe.py:196-197)
+        // rx_buf shift and append (radae_rxe.py:196-197); the largest component of the new samples sets the operand scale of the binary16 planes
         constexpr int NK = (RD_RXBUF + NT2 - 1) / NT2;
         float2 keep[NK];
 #pragma unroll
         for (int q = 0; q < NK; q++) { const int i = tid + q * NT2; keep[q] = (i + nin < RD_RXBUF) ? sh->rxb[i + nin] : make_float2(0.0f, 0.0f); }
-        float2 memv = make_float2(0.0f, 0.0f);
-        if (tid < 102) memv = sh->xm[ml + nin - 102 + tid];
+        float mloc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NNEW; q++) mloc = fmaxf(mloc, fmaxf(fabsf(nv[q].x), fabsf(nv[q].y)));
+        mloc = wave_max_f32(mloc);
         __syncthreads();
         tid = rx2_tid(wv);
 #pragma unroll
         for (int q = 0; q < NK; q++) { const int i = tid + q * NT2; if (i + nin < RD_RXBUF) sh->rxb[i] = keep[q]; }
 #pragma unroll
-        for (int j = 0; j < NO; j++) { const int i = NO * tid + j; if (i < nin) sh->rxb[RD_RXBUF - nin + i] = filt[j]; }
-#ifdef RX2_DEBUG_SUMS
-        if (g_rx2_dbg && mf0 - 1 < 32) {
-#pragma unroll
-            for (int j = 0; j < NO; j++) { const int i = NO * tid + j; if (i < nin) g_rx2_dbg[((size_t)b * 32 + (mf0 - 1)) * 1120 + i] = filt[j]; }
-        }
-#endif
-        if (tid < 102) sh->bmem[tid] = memv;
+        for (int q = 0; q < NNEW; q++) { const int i = tid + q * NT2; if (i < nin) sh->rxb[RD_RXBUF - nin + i] = nv[q]; }
+        if ((tid & 63) == 0) atomicMax(&S->rxmax_cur, __float_as_uint(mloc));
         if (tid == 0) {
-            S->bpf_phase = cmul(bpf_phase, e_last); S->pf_n = 0;
-            if (state == ST_SYNC) S->lcg = (uint32_t)sh->redi[15];
-            S->bpf_mem_len = 102; S->consumed_inv += nin; S->consumed_round += nin;
+            if (state == ST_SYNC) S->lds_sync = 1;
+            S->consumed_inv += nin; S->consumed_round += nin;
         }
         __syncthreads();
         tid = rx2_tid(wv);
-#ifdef RX2_DEBUG_SUMS
-        { unsigned v = 0; for (int i = tid; i < RD_RXBUF; i += NT2) v ^= (__float_as_uint(sh->rxb[i].x) * 31u + __float_as_uint(sh->rxb[i].y)) * (unsigned)(i + 1); atomicXor((unsigned *)&sh->redi[13], v); }
-#endif
 
         PH2(5);
         if (state == ST_SEARCH || state == ST_CANDIDATE) {
@@ -1381,8 +1336,24 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
                     const int eb = min(max((int)((mb >> 23) & 0xffu), 32), 222);
                     const float rx_sc = __uint_as_float((unsigned)(127 + 7 - (eb - 127)) << 23);
                     if (tid == 0) sh->redf[12] = __uint_as_float((unsigned)(127 - 12 - 7 + (eb - 127)) << 23);
+                    if (tid >= NT2 - 64) {
+                        // side jobs of the call on the fourth wavefront (they only depend on last call's results): the per-frequency constants of
+                        // refine()'s grid, check_pilots' 48 row draws, and the first touch of the NEXT call's filtered samples (HBM + address translation:
+                        // 256 streams read 256 separate regions; one load per 128-byte line, values dropped)
+                        const int l = tid - (NT2 - 64);
+                        refine2_tables_sync(sh, l, fm - 1.0, fm + 1.0, 0.1);
+                        const int k = min(l, 47);
+                        const uint32_t x = LCG_A[k] * S->lcg + LCG_C[k];
+                        if (l < 48) sh->rows48[k] = (int)((x >> 8) % RD_NMF);
+                        if (l == 47) sh->redi[15] = (int)x;
+                        const int rem = min(avail - cons0 - nin, RD_NINMAX);
+                        float t = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 2; q++) { const int i = (l + 64 * q) * 16; if (i < rem) t += rxf[cons0 + nin + i].x; }
+                        asm volatile("" :: "v"(t));
+                    } else
                     for (int rep = CENSUS_REPS(8); rep > 0; rep--)
-                    for (int i = tid; i < RD_RXBUF; i += NT2) {
+                    for (int i = tid; i < RD_RXBUF; i += NT2 - 64) {
                         asm volatile("" ::: "memory");
                         float2 v = sh->rxb[i]; v.x *= rx_sc; v.y *= rx_sc;
                         const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y;
@@ -1394,7 +1365,7 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
                 if (CENSUS(16)) { int t_ = tm; double f_ = fm; rx2_refine(sh, a.vm, &t_, &f_, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true); __syncthreads(); }
                 rx2_refine(sh, a.vm, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true);
                 tm_ref = tnew; fm_ref = 0.9 * fm + 0.1 * fhat;
-                if (tid == 0) { S->tmax = tm_ref; S->fmax = fm_ref; }
+                if (tid == 0) { S->tmax = tm_ref; S->fmax = fm_ref; S->lcg = (uint32_t)sh->redi[15]; }
             }
             PH2(9);
             // check_pilots (dsp.py:273-320): 48 pseudo-random rows x {Dt1, Dt2} x 40 frequencies on the f16 matrix cores, one
@@ -1473,19 +1444,6 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
             // end-of-over / slip, runs the state machine and advances the phase accumulator; the other three run the demodulator DFT
             // (none of the decisions feeds it: the corrected window was cut with the slip-adjusted timing above)
             const double w = 2.0 * PI_D * S->fmax / 8000.0;
-            // the NEXT call's input, fetched under the demodulator and the equaliser (see k_rx_sync)
-            constexpr int NP = (RD_NINMAX + NT2 - 1) / NT2;
-            float2 pfx[NP], pfe[NP];
-            {
-                const int lim = min(avail - S->consumed_inv, RD_NINMAX);
-                const float2 *xn = rxin + S->consumed_inv;
-#pragma unroll
-                for (int q = 0; q < NP; q++) {
-                    const int i = tid + q * NT2;
-                    pfx[q] = pfe[q] = make_float2(0.0f, 0.0f);
-                    if (i < lim) { pfx[q] = xn[i]; pfe[q] = ld2(tab->bpf_E, i); }
-                }
-            }
             if (tid >= NT2 - 64) {
                 const int l = tid - (NT2 - 64);
                 double r0 = 0.0, r1 = 0.0;
@@ -1567,16 +1525,6 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
             tid = rx2_tid(wv);
             PH2(12);
             const int endofover = S->endofover, n_rows = n_rows0;
-            int pf_n = 0;
-            {
-                const int nn = S->nin;
-                const bool go_n = !(S->calls_inv >= a.max_calls || S->n_calls >= a.round_calls || S->valid_inv >= a.feat_cap) && S->consumed_inv + nn <= avail;
-                const bool dec_n = S->n_rows > 0 && ((S->state == ST_SYNC && ((S->synced_count + 1) % 8) == 0) || S->n_rows + 3 > a.dec_rows);
-                if (go_n && !dec_n) pf_n = nn;
-#ifdef RX2_NO_STAGE
-                pf_n = 0;
-#endif
-            }
             float *zrow = a.zrows + ((size_t)b * a.dec_rows + n_rows) * RD_LATENT;
             float *eoo_dst = a.eoo_out ? a.eoo_out + (size_t)b * RD_NEOOBITS : nullptr;
             const int call_idx0 = mf0 - 1;
@@ -1654,12 +1602,6 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
                     if (a.trace_z && call_idx0 < a.trace_cap) { float *tz = a.trace_z + ((size_t)b * a.trace_cap + call_idx0) * RD_ZMF; tz[2 * tid] = v.x; tz[2 * tid + 1] = v.y; }
                 }
             }
-            if (pf_n) {
-                const float2 ph = S->bpf_phase;
-#pragma unroll
-                for (int q = 0; q < NP; q++) { const int i = tid + q * NT2; if (i < pf_n) sh->xm[102 + i] = cmul(pfx[q], cmul(ph, pfe[q])); }
-                if (tid == 0) S->pf_n = pf_n;
-            }
             __syncthreads();
             tid = rx2_tid(wv);
         }
@@ -1685,9 +1627,6 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
                 tr->state_before = S->state_before; tr->state_after = S->state; tr->nin_before = S->nin_before; tr->nin_after = S->nin; tr->ret = S->valid_output | (S->endofover << 1);
                 tr->tmax = S->tmax; tr->f_ind_max = S->f_ind_max; tr->valid_count = S->valid_count; tr->uw_errors = S->uw_errors; tr->synced_count = S->synced_count;
                 tr->snr_int = (int)S->snr_est; tr->fmax = S->fmax; tr->Dthresh = S->Dthresh; tr->Dtmax12 = S->Dtmax12; tr->Dtmax12_eoo = S->Dtmax12_eoo; tr->snrdB_3k_est = S->snr_est;
-#ifdef RX2_DEBUG_SUMS
-                tr->Dtmax12_eoo = (double)(unsigned)sh->redi[14]; tr->Dtmax12 = (double)(unsigned)sh->redi[13]; tr->snrdB_3k_est = (float)((unsigned)sh->redi[12] & 0xffffffu);   // checksums of rx1 / rx_buf / sym as this call saw them
-#endif
             }
         }
         if (tid == 0) prepare_next();
@@ -1700,15 +1639,22 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
     __syncthreads();
     for (int i = tid; i < RD_RXBUF; i += NT2) { st->rx_buf[i][0] = sh->rxb[i].x; st->rx_buf[i][1] = sh->rxb[i].y; }
     for (int i = tid; i < RD_NMF; i += NT2) { st->rowsum1[i] = sh->rowsum1[i]; st->rowsum2[i] = sh->rowsum2[i]; }
-    for (int i = tid; i < 102; i += NT2) { st->bpf_mem[i][0] = sh->bmem[i].x; st->bpf_mem[i][1] = sh->bmem[i].y; }
+    // band-pass state for the next invocation's pre-pass: on the grid the 102 baseband samples before the consumption point are rebuilt from the
+    // input and the block phases (what complex_bpf keeps: dsp.py:96-99); off the grid rx2_bpf_own has kept them in the stream record call by call
+    if (S->bpf_grid && S->consumed_inv > 0)
+        for (int i = tid; i < 102; i += NT2) { const float2 m = rx2_bpf_mem(a, b, S->nin0, S->consumed_inv - 102 + i); st->bpf.mem[i][0] = m.x; st->bpf.mem[i][1] = m.y; }
     if (tid == 0) {
         st->state = S->state; st->nin = S->nin; st->tmax = S->tmax; st->tmax_candidate = S->tmax_candidate; st->valid_count = S->valid_count;
         st->uw_errors = S->uw_errors; st->synced_count = S->synced_count; st->mf = S->mf; st->f_ind_max = S->f_ind_max;
-        st->dec_reset_pending = S->dec_reset_pending; st->bpf_mem_len = S->bpf_mem_len; st->has_eoo = S->has_eoo; st->lcg = S->lcg; st->dt_valid = S->dt_valid;
+        st->dec_reset_pending = S->dec_reset_pending; st->has_eoo = S->has_eoo; st->lcg = S->lcg; st->dt_valid = S->dt_valid;
         st->rxmax[0] = S->rxmax_cur; st->rxmax[1] = S->rxmax_h0; st->rxmax[2] = S->rxmax_h1;
         st->fmax = S->fmax; st->foff_err = S->foff_err; st->rx_theta = S->rph_th; { double s_, c_; sincos(S->rph_th, &s_, &c_); st->rx_phase[0] = c_; st->rx_phase[1] = s_; }
         st->Dthresh = S->Dthresh; st->Dtmax12 = S->Dtmax12; st->Dtmax12_eoo = S->Dtmax12_eoo; st->snr_est = S->snr_est;
-        st->bpf_phase[0] = S->bpf_phase.x; st->bpf_phase[1] = S->bpf_phase.y; st->consumed += S->consumed_round;
+        if (S->consumed_inv > 0) {
+            const float2 ph = S->bpf_grid ? ((const float2 *)a.bpf_chain)[(size_t)b * a.chain_stride + 1 + S->calls_inv] : S->bpf_phase;
+            st->bpf.phase[0] = ph.x; st->bpf.phase[1] = ph.y; st->bpf.mem_len = 102; st->bpf.grid_off = S->bpf_grid ? 0 : 1;
+        }
+        st->consumed += S->consumed_round;
         rnd->n_calls = S->n_calls; rnd->n_rows = S->n_rows; rnd->uw_from_row = S->uw_from_row; rnd->consumed = S->consumed_round;
         rnd->out_base = S->out_base;
         a.acc[b * 4 + 0] = S->consumed_inv; a.acc[b * 4 + 1] = S->calls_inv; a.acc[b * 4 + 2] = S->valid_inv; a.acc[b * 4 + 3] = S->eoo_inv;
@@ -1728,8 +1674,8 @@ __global__ __launch_bounds__(256) void k_rx_reset(rd_rx_stream *st, const unsign
     for (int i = threadIdx.x; i < (int)(sizeof(rd_rx_stream) / 4); i += blockDim.x) raw[i] = 0.0f;
     __syncthreads();
     if (threadIdx.x == 0) {
-        s->state = ST_SEARCH; s->nin = RD_NMF; s->mf = 1; s->bpf_mem_len = 100; s->lcg = seeds ? seeds[blockIdx.x] : 1u;
-        s->rx_phase[0] = 1.0; s->rx_theta = 0.0; s->bpf_phase[0] = 1.0f; s->foff_err = foff_err;
+        s->state = ST_SEARCH; s->nin = RD_NMF; s->mf = 1; s->bpf.mem_len = 100; s->lcg = seeds ? seeds[blockIdx.x] : 1u;
+        s->rx_phase[0] = 1.0; s->rx_theta = 0.0; s->bpf.phase[0] = 1.0f; s->foff_err = foff_err;
     }
 }
 extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err, int B, rd_stream_t s)
@@ -1739,6 +1685,107 @@ extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, doubl
     return (int)hipGetLastError();
 }
 
+
+// the block phases of an invocation, one thread per stream: P[0] = the phase the stream's last call left, P[k + 1] = P[k] E[len_k - 1] in complex64
+// as complex_bpf does from call to call; also resets the stream's off-grid flag (a new invocation starts on the grid)
+__global__ __launch_bounds__(64) void k_rx_bpf_chain(rd_rx_stream *st, const rd_tables *tab, const int *avail, float2 *chain, int chain_stride, int B)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    rd_rx_stream *s = st + b;
+    float2 *c = chain + (size_t)b * chain_stride;
+    const int nin0 = s->nin, av = avail[b];
+    c[0] = make_float2(__int_as_float(nin0), __int_as_float(s->bpf.mem_len));
+    s->bpf.grid_off = 0;
+    float2 P = make_float2(s->bpf.phase[0], s->bpf.phase[1]);
+    int start = 0, len = nin0;
+    for (int k = 0; k + 1 < chain_stride; k++) {
+        c[1 + k] = P;
+        if (start >= av) break;                            // P of the first block beyond the input: the phase after the last whole call
+        P = cmul(P, ld2(tab->bpf_E, len - 1));
+        start += len; len = RD_NMF;
+    }
+}
+
+// complex_bpf.bpf for block blockIdx.x of stream blockIdx.y: [102 earlier baseband samples | the block mixed down] in LDS, five consecutive
+// outputs per thread over a sliding register window, mix up, store.  Plain v_fma_f32 in tap order (see DESIGN.md 3.7 on the packed form).
+#define BPF_NT 256
+#define BPF_NO 5
+__global__ __launch_bounds__(BPF_NT) void k_rx_bpf(const rd_rx_stream *st, const rd_tables *tab, const float2 *rx, long rx_stride, const int *avail,
+                                                   const float2 *chain, int chain_stride, float2 *rxf, long rxf_stride)
+{
+    static_assert(BPF_NT * BPF_NO >= RD_NINMAX, "a block is at most RD_NINMAX samples");
+    __shared__ __attribute__((aligned(16))) float2 xs[102 + BPF_NT * BPF_NO + 104];
+    __shared__ __attribute__((aligned(16))) float hs[RD_NTAP + 3];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float2 *c = chain + (size_t)b * chain_stride;
+    const int nin0 = __float_as_int(c[0].x), ml0 = __float_as_int(c[0].y), av = avail[b];
+    const int sk = k ? nin0 + (k - 1) * RD_NMF : 0, len = k ? RD_NMF : nin0;
+    if (sk >= av || nin0 <= 0) return;
+    const int n = min(len, av - sk);                       // (a partial last block is filtered too; no call will consume it)
+    const float2 *x = rx + (size_t)b * rx_stride;
+    const float2 Pk = c[1 + k];
+    const float2 Pp = k ? c[k] : Pk;
+    const int sp = k > 1 ? sk - RD_NMF : 0;                // start of the block before this one
+    const rd_rx_stream *s = st + b;
+    for (int i = tid; i < RD_NTAP; i += BPF_NT) hs[i] = tab->bpf_h[i];
+    for (int i = tid; i < 102 + BPF_NT * BPF_NO + 104; i += BPF_NT) {
+        float2 v = make_float2(0.0f, 0.0f);
+        if (i >= 102) { if (i - 102 < n) v = cmul(x[sk + i - 102], cmul(Pk, ld2(tab->bpf_E, i - 102))); }
+        else if (k) { const int q = sk - 102 + i; v = cmul(x[q], cmul(Pp, ld2(tab->bpf_E, q - sp))); }
+        else { const int mi = ml0 - 102 + i; if (mi >= 0) v = make_float2(s->bpf.mem[mi][0], s->bpf.mem[mi][1]); }
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int i0 = BPF_NO * tid;
+    if (i0 >= n) return;
+    const int o = (k == 0 && ml0 == 100) ? 2 : 0;          // before the first call the memory is two samples shorter (dsp.py:55)
+    const f32x2 *xw = (const f32x2 *)xs + i0 + o;
+    f32x2 acc[BPF_NO];
+#pragma unroll
+    for (int j = 0; j < BPF_NO; j++) acc[j] = (f32x2){ 0.0f, 0.0f };
+#pragma unroll 2
+    for (int kb = 0; kb < 96; kb += 8) {
+        f32x2 xv[8 + BPF_NO - 1]; float h[8];
+#pragma unroll
+        for (int u = 0; u < 8 + BPF_NO - 1; u++) xv[u] = xw[kb + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) h[u] = hs[kb + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int j = 0; j < BPF_NO; j++) { acc[j][0] = fmaf(xv[u + j][0], h[u], acc[j][0]); acc[j][1] = fmaf(xv[u + j][1], h[u], acc[j][1]); }
+        }
+    }
+    {
+        f32x2 xv[5 + BPF_NO - 1]; float h[5];
+#pragma unroll
+        for (int u = 0; u < 5 + BPF_NO - 1; u++) xv[u] = xw[96 + u];
+#pragma unroll
+        for (int u = 0; u < 5; u++) h[u] = hs[96 + u];
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+#pragma unroll
+            for (int j = 0; j < BPF_NO; j++) { acc[j][0] = fmaf(xv[u + j][0], h[u], acc[j][0]); acc[j][1] = fmaf(xv[u + j][1], h[u], acc[j][1]); }
+        }
+    }
+    float2 *dst = rxf + (size_t)b * rxf_stride + sk;
+#pragma unroll
+    for (int j = 0; j < BPF_NO; j++) {
+        const int i = i0 + j;
+        if (i < n) dst[i] = cmul(make_float2(acc[j][0], acc[j][1]), cconj(cmul(Pk, ld2(tab->bpf_E, i))));
+    }
+}
+// the two launches of the pre-pass; n_blocks = blocks of the longest stream (the host knows every stream's avail)
+extern "C" int rd_launch_rx_bpf(rd_rx_stream *st, const rd_tables *tab, const void *rx, long rx_stride, const int *avail, void *chain, int chain_stride,
+                                void *rxf, long rxf_stride, int n_blocks, int B, rd_stream_t s)
+{
+    if (B <= 0 || n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(k_rx_bpf_chain, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)s, st, tab, avail, (float2 *)chain, chain_stride, B);
+    hipLaunchKernelGGL(k_rx_bpf, dim3(n_blocks, B), dim3(BPF_NT), 0, (hipStream_t)s, (const rd_rx_stream *)st, tab, (const float2 *)rx, rx_stride, avail,
+                       (const float2 *)chain, chain_stride, (float2 *)rxf, rxf_stride);
+    return (int)hipGetLastError();
+}
 
 extern "C" int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s)
 {

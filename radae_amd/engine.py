@@ -76,6 +76,7 @@ def load_library() -> C.CDLL:
     L.rade_batch_rx_set_lcg.argtypes = [vp, C.POINTER(C.c_uint)]
     L.rade_batch_rx_get_trace.argtypes = [vp, C.c_int, C.POINTER(RxTrace), vp, C.c_int]
     L.rade_batch_rx_stream_cycles.argtypes = [vp, vp]
+    L.rade_batch_rx_filtered.argtypes = [vp, C.c_int, vp, C.c_int]
     _lib = L
     return L
 
@@ -90,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_tx_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get", "rade_batch_profile_ref", "rade_batch_profile_intervals",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
-    "rade_batch_rx_stream_cycles",
+    "rade_batch_rx_stream_cycles", "rade_batch_rx_filtered",
     "rade_multi_open", "rade_multi_close", "rade_multi_n_devices", "rade_multi_transport", "rade_multi_engine", "rade_multi_shard", "rade_multi_foreach",
     "rade_multi_allreduce_sum",
 ]
@@ -142,7 +143,7 @@ class BatchEngine:
         """Stream-ordered reset of encoder and receiver state (a new batch of utterances)."""
         self.lib.rade_batch_reset(self.h, _stream_ptr())
 
-    PROF_CLASSES = ("gemm", "gru_scan", "ofdm_mod", "channel", "rx_sync", "rx_post")
+    PROF_CLASSES = ("gemm", "gru_scan", "ofdm_mod", "channel", "rx_sync", "rx_bpf")
 
     def profile(self, enable: bool):
         self.lib.rade_batch_profile(self.h, int(enable))
@@ -334,6 +335,14 @@ class BatchEngine:
         if r:
             raise RuntimeError("rade_batch_rx failed")
         return features_out, list(status), eoo
+
+    def rx_filtered(self, b: int, n: int) -> np.ndarray:
+        """The first n band-pass filtered samples stream b's receiver read in the most recent rx() invocation (complex_bpf.bpf output)."""
+        out = np.zeros(n, np.complex64)
+        got = self.lib.rade_batch_rx_filtered(self.h, b, out.ctypes.data_as(C.c_void_p), n)
+        if got < 0:
+            raise RuntimeError("rade_batch_rx_filtered failed")
+        return out[:got]
 
     def rx_stream_cycles(self) -> np.ndarray:
         """Shader-clock cycles each stream's workgroup spent in the most recent receiver launch."""

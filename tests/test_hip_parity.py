@@ -149,6 +149,53 @@ def test_rx_trace_golden(Engine, torch_dev, golden, name, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["slip_plus", "slip_minus", "mpp"])
+def test_bpf_prepass_matches_oracle_filter(Engine, torch_dev, golden, oracle, name):
+    """The band-pass filter runs ahead of the receiver kernel for a whole invocation (k_rx_bpf); a stream whose nin changes inside an invocation
+    (timing slips) filters the rest itself (rx2_bpf_own).  Either way the receiver must have read what complex_bpf.bpf (dsp.py:63-102) produces
+    for the stream's actual sequence of calls: compared with the oracle's filter driven with the traced call sizes (float32 rounding of a
+    101-term sum), and bit for bit with the same stream fed one call per invocation (where every call is on the pre-pass's grid)."""
+    import torch
+    g = golden("rxtrace_" + name)
+    x = g["rx_in"]
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=128)
+    eng.rx(torch.tensor(x[None], device=torch_dev))
+    sizes = eng.rx_trace(0)["nin_before"]
+    assert np.array_equal(sizes, g["nin_before"])
+    if name != "mpp":
+        assert (sizes != 960).any()                     # the case really leaves the grid
+    n = int(sizes.sum())
+    y = eng.rx_filtered(0, n)
+    bp = oracle.Bpf()
+    pos, ref = 0, []
+    for k in sizes:
+        ref.append(bp.run(x[pos:pos + k])); pos += int(k)
+    ref = np.concatenate(ref)
+    assert np.abs(y - ref).max() < 2e-6 * np.abs(ref).max()
+    eng.rx_reset()
+    pos, outs = 0, []
+    for k in sizes:
+        _, s, _ = eng.rx(torch.tensor(x[None, pos:pos + k], device=torch_dev), max_calls=1)
+        assert s[0].consumed == k
+        outs.append(eng.rx_filtered(0, int(k))); pos += int(k)
+    assert np.array_equal(np.concatenate(outs), y)
+    eng.close()
+
+
+def test_bpf_prepass_golden(Engine, torch_dev, golden):
+    """The pre-pass against the reference's own filter output (tests/golden/bpf.npz): the 960-sample calls a receiver in the search state makes."""
+    import torch
+    g = golden("bpf")
+    n = 3 * 960
+    assert list(g["sizes"][:3]) == [960, 960, 960]
+    eng = Engine(1, max_tx_mf=1)
+    _, s, _ = eng.rx(torch.tensor(g["x"][None, :n], device=torch_dev))
+    assert s[0].consumed == n
+    y = eng.rx_filtered(0, n)
+    assert np.abs(y - g["y"][:n]).max() < 2e-6 * np.abs(g["y"]).max()
+    eng.close()
+
+
 def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden, monkeypatch):
     """One do_radae_rx call per invocation (the rade_rx() usage) == the whole stream at once."""
     import torch

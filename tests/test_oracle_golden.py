@@ -25,6 +25,19 @@ def test_constants(oracle, golden):
         assert np.abs(got - ref).max() <= tol, name
 
 
+def test_bpf_golden(oracle, golden):
+    """orc_bpf_run against complex_bpf.bpf (dsp.py:63-102) driven call by call with 960 / 800 / 1120-sample calls (oracle/gen_golden_r4.py):
+    float32 sums of 101 terms in another order than NumPy's dot."""
+    g = golden("bpf")
+    bp = oracle.Bpf()
+    pos, out = 0, []
+    for k in g["sizes"]:
+        out.append(bp.run(g["x"][pos:pos + k])); pos += int(k)
+    y = np.concatenate(out)
+    assert len(y) == len(g["y"]) and set(g["sizes"].tolist()) == {800, 960, 1120}
+    assert np.abs(y - g["y"]).max() < 2e-6 * np.abs(g["y"]).max() and rms(y, g["y"]) < 3e-7 * np.abs(g["y"]).max()
+
+
 def test_blob_reader_matches_python_reader(oracle_model, golden):
     w = golden("weights_check")
     for k in w.files:
