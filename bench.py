@@ -25,6 +25,7 @@ the FFT count stays.  The reference-formulation figure (98 MFLOP of GEMM per sea
 import argparse
 import json
 import os
+import resource
 import sys
 import time
 
@@ -206,10 +207,13 @@ def main():
     reps = []
     for _ in range(max(1, args.repeats)):
         barrier()
+        ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         fo, st, _, rx_last = run_steps(args.steps, 1)
         barrier()
         dt_local = time.perf_counter() - t0
+        ru1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
         dt = dt_local
         per_rank_ms = [1e3 * dt_local / args.steps]
         if world > 1:
@@ -220,8 +224,8 @@ def main():
             allms = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
             dist.all_gather(allms, torch.tensor([1e3 * dt_local / args.steps], dtype=torch.float64, device=dev))
             per_rank_ms = [float(x.item()) for x in allms]
-        reps.append((dt, per_rank_ms))
-    dt, per_rank_ms = sorted(reps, key=lambda r: r[0])[(len(reps) - 1) // 2]      # median (lower middle for an even count)
+        reps.append((dt, per_rank_ms, cpu_s))
+    dt, per_rank_ms, cpu_s = sorted(reps, key=lambda r: r[0])[(len(reps) - 1) // 2]      # median (lower middle for an even count)
     ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
@@ -252,6 +256,13 @@ def main():
                           "search_calls": int(job[4]), "eoo_detected_streams": int(job[5])},
     }
     if rank == 0:
+        # host side of rank 0: CPU time its threads burnt per step (a spinning wait counts in full), the CPUs it may use, and how its engines waited
+        # (rade_batch_rx spins while engines <= CPUs, else sleeps on a blocking event: include/rade_batch.h; $RADE_SYNC overrides)
+        ncpu, quota = cpu_quota()
+        sc = [e.sync_counts() for e in engs]
+        out["host"] = {"cpu_s_per_step": cpu_s / args.steps, "cpu_cores_busy": cpu_s / dt, "logical_cpus": ncpu, "cgroup_cpu_quota": quota,
+                       "engines_in_process": depth, "rx_waits_blocking": sum(a for a, _ in sc), "rx_waits_spinning": sum(b for _, b in sc),
+                       "RADE_SYNC": os.environ.get("RADE_SYNC", "auto")}
         out["decoded_modem_frames_per_stream"] = {"min": int(nv.min()), "mean": float(nv.mean()), "max": int(nv.max())}
 
     if rank == 0 and not args.no_roofline:

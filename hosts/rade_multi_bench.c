@@ -15,6 +15,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <sys/resource.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -204,7 +205,11 @@ int main(int argc, char **argv)
     for (int i = 0; i < n_dev; i++) rade_multi_engine(m, i, &j.device[i], NULL, NULL);
     pthread_barrier_init(&j.bar, NULL, n_dev * j.pipeline);
     if (rade_multi_foreach(m, setup, &j) < 0) { fprintf(stderr, "rade_multi_bench: setup failed\n"); return 1; }
+    struct rusage ru0, ru1; getrusage(RUSAGE_SELF, &ru0);      /* (spans warm-up and timed steps of every device thread: CPU seconds per step below is an average over both) */
     if (rade_multi_foreach(m, run, &j) < 0) { fprintf(stderr, "rade_multi_bench: run failed\n"); return 1; }
+    getrusage(RUSAGE_SELF, &ru1);
+    const double cpu_s = (ru1.ru_utime.tv_sec - ru0.ru_utime.tv_sec) + 1e-6 * (ru1.ru_utime.tv_usec - ru0.ru_utime.tv_usec)
+                       + (ru1.ru_stime.tv_sec - ru0.ru_stime.tv_sec) + 1e-6 * (ru1.ru_stime.tv_usec - ru0.ru_stime.tv_usec);
     double flat[64 * 6], tot[6], tmax = 0.0;
     for (int i = 0; i < n_dev; i++) { memcpy(flat + 6 * i, j.stats[i], sizeof(double) * 6); if (j.t_step[i] > tmax) tmax = j.t_step[i]; }
     if (rade_multi_allreduce_sum(m, flat, 6, tot)) return 1;
@@ -213,7 +218,9 @@ int main(int argc, char **argv)
            "\"config\": {\"workload\": \"model19_check3, %d utterances x %d frames sharded over %d GPU(s) from one C host process (configs[3] recipe)\", \"batches_in_flight_per_gpu\": %d, \"collectives\": \"%s: 1 broadcast (blob), 1 all-reduce (statistics)\"}, "
            "\"per_device_ms_per_step\": [", tot[0] / tmax, n_dev, j.steps, j.warmup, 1e3 * tmax, B * n_dev, j.T, n_dev, j.pipeline, rade_multi_transport(m));
     for (int i = 0; i < n_dev; i++) printf("%s%.4f", i ? ", " : "", 1e3 * j.t_step[i]);
-    printf("], \"job_last_step\": {\"offered_frames\": %.0f, \"decoded_frames\": %.0f, \"rx_calls\": %.0f, \"sync_calls\": %.0f, \"eoo_detected_streams\": %.0f, \"samples_consumed\": %.0f}}\n",
+    printf("], \"host\": {\"cpu_s_per_step\": %.6f, \"cpu_quota\": %.2f, \"engines_in_process\": %d, \"rx_wait\": \"%s\"}",
+           cpu_s / (j.steps + j.warmup), rade_host_cpu_quota(), n_dev * j.pipeline, rade_sync_policy(n_dev * j.pipeline, rade_host_cpu_quota()) ? "blocking event" : "spin");
+    printf(", \"job_last_step\": {\"offered_frames\": %.0f, \"decoded_frames\": %.0f, \"rx_calls\": %.0f, \"sync_calls\": %.0f, \"eoo_detected_streams\": %.0f, \"samples_consumed\": %.0f}}\n",
            tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
     rade_multi_close(m);
     return 0;

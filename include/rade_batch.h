@@ -150,6 +150,13 @@ typedef struct {
 /* copies up to max_calls records + 240-float z_hat rows per call of stream b to host; returns #calls traced */
 int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_hat_out, int max_calls);
 
+/* Host-side wait policy of rade_batch_rx (the one call that waits for its stream): hipStreamSynchronize spins, which is right while every engine's
+ * host thread has a core; when more engines are open in the process than the process has CPUs (affinity mask and cgroup quota: 8 GPUs x 3 batches
+ * in flight = 24 threads under a 16-core quota) the wait sleeps on a hipEventBlockingSync event instead.  $RADE_SYNC=spin|block overrides.
+ * rade_sync_policy is the rule itself (1 = block); rade_host_cpu_quota what it is fed with; rade_batch_sync_counts what an engine did so far. */
+double rade_host_cpu_quota(void);
+int rade_sync_policy(int engines_open, double cpu_quota);
+void rade_batch_sync_counts(const rade_batch *h, long *blocking, long *spinning);
 /* test aid: the band-pass filtered samples (complex_bpf.bpf, dsp.py:63-102) the receiver of the most recent rade_batch_rx invocation read for
  * stream b -> out_host [n] complex64 (host memory); returns the number copied, < 0 on error */
 int rade_batch_rx_filtered(rade_batch *h, int b, void *out_host, int n);

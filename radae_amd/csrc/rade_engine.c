@@ -9,9 +9,11 @@
  * decoder's aux bits (UW errors, radae_rxe.py:220-224, :306-312), so the decoder runs inside that workgroup
  * right before every unique-word decision (k_rx_sync2 -> rx2_decode_pending, rade_rx.hip).
  */
+#define _GNU_SOURCE          /* sched_getaffinity / CPU_COUNT */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -22,6 +24,33 @@
 #include "rade_host.h"
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "rade: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); goto fail; } } while (0)
+
+/* ---- how rade_batch_rx waits for its stream (the one blocking call of the batched API) -----------------------------------------------------
+ * hipStreamSynchronize spins by default: right for one engine per core, wrong when the host has fewer cores than engines in flight -- 8 GPUs x 3
+ * batches in flight are 24 host threads, and a container's CPU quota may be 16 (seen on the 1-GPU lease) -- the spinning threads then take the
+ * cores the other engines' launch paths need.  Policy: spin while the engines open in this process fit the CPUs the process may use, otherwise
+ * wait on a hipEventBlockingSync event (the thread sleeps until the interrupt).  $RADE_SYNC=spin|block overrides. */
+static int g_engines_open;                 /* engines alive in this process (atomic) */
+double rade_host_cpu_quota(void)
+{   /* CPUs this process may use: the smaller of its affinity mask and the cgroup v2 quota (cpu.max = "quota period" or "max period") */
+    cpu_set_t set; double n = 1.0;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (double)CPU_COUNT(&set);
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[64]; double per = 0.0;
+        if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0.0) { const double c = atof(q) / per; if (c > 0.0 && c < n) n = c; }
+        fclose(f);
+    }
+    return n;
+}
+/* 1 = wait on a blocking event, 0 = spin: a pure function of the two counts (tests/test_host_cpu.py) */
+int rade_sync_policy(int engines_open, double cpu_quota) { return (double)engines_open > cpu_quota; }
+static int sync_blocking_now(void)
+{
+    static int mode = -1; static double quota;
+    if (mode < 0) { const char *e = getenv("RADE_SYNC"); quota = rade_host_cpu_quota(); mode = e && !strcmp(e, "block") ? 1 : (e && !strcmp(e, "spin") ? 0 : 2); }
+    return mode == 2 ? rade_sync_policy(__atomic_load_n(&g_engines_open, __ATOMIC_RELAXED), quota) : mode;
+}
 
 typedef struct { float *wp, *bias; unsigned short *wp16, *wa16; float *wscale, *wscale16; int N, K; } dev_lin;   /* wscale16: column scales when wp16 is one plane of integers */
 
@@ -64,6 +93,8 @@ struct rade_batch {
     long rx_calls_search, rx_calls_sync;
     /* encoder in two time chunks on two HIP streams (encode_core): the side stream and the events that order the chunks */
     int enc_chunks; hipStream_t enc_side; hipEvent_t ev_fork, ev_join, ev_scan[5];
+    hipEvent_t ev_block;             /* hipEventBlockingSync: what rade_batch_rx waits on when the host has fewer CPUs than engines (sync_blocking_now) */
+    long n_sync_block, n_sync_spin;  /* waits of either kind so far (rade_batch_sync_counts) */
 };
 
 static const int ENC_IN[5] = { 64, 224, 384, 544, 704 };    /* GRU input widths (radae_base.py:240-248) */
@@ -186,6 +217,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     if (rd_model_parse(blob, blob_len, &m)) return NULL;
     have_model = 1;
     h = calloc(1, sizeof *h);
+    __atomic_add_fetch(&g_engines_open, 1, __ATOMIC_RELAXED);
     h->B = cfg->n_streams; h->max_tx_mf = cfg->max_tx_mf; h->device = cfg->device; h->flags = cfg->flags;
     h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
     h->unsync_off_after = cfg->disable_unsync != 0.0f ? (int)((double)cfg->disable_unsync * 8000.0 / RD_NMF) : -1;    /* radae_rxe.py:279-280 */
@@ -295,6 +327,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->d_lcg_seeds = dev_upload(h->lcg_seeds, sizeof(unsigned) * B);
     if (!h->d_lcg_seeds) goto fail;
     for (int i = 0; i < 2 * RADE_PROF_MAXEV; i++) CHK(hipEventCreate(&h->prof_ev[i]));
+    CHK(hipEventCreateWithFlags(&h->ev_block, hipEventBlockingSync | hipEventDisableTiming));
     h->enc_chunks = getenv("RADE_ENC_CHUNKS") ? atoi(getenv("RADE_ENC_CHUNKS")) : 1;     /* measured (profiles/r03_tx_side_ab.json): 2 chunks gain 3 % with one batch in flight, lose 7 % with two (the default) */
     if (h->enc_chunks != 1) {
         h->enc_chunks = 2;
@@ -341,6 +374,8 @@ void rade_batch_close(rade_batch *h)
         for (int i = 0; i < 9; i++) if (p[i]) hipFree(p[i]);
     }
     if (h->h_small) hipHostFree(h->h_small);
+    if (h->ev_block) hipEventDestroy(h->ev_block);
+    __atomic_sub_fetch(&g_engines_open, 1, __ATOMIC_RELAXED);
     if (h->enc_side) hipStreamDestroy(h->enc_side);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -681,7 +716,8 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
             CHK(hipMemcpyAsync(hs + 8, h->rx_acc, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
             CHK(hipMemcpyAsync(hs + 8 + 4 * B, h->rx_status, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
         }
-        CHK(hipStreamSynchronize(st));
+        if (sync_blocking_now()) { CHK(hipEventRecord(h->ev_block, st)); CHK(hipEventSynchronize(h->ev_block)); h->n_sync_block++; }
+        else { CHK(hipStreamSynchronize(st)); h->n_sync_spin++; }
         if (hs[0] == 0 || hs[1] == 0) break;    /* nothing done, or no stream stopped at the per-launch limit */
     }
     if (status_host) {
@@ -696,6 +732,9 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
 fail:
     return -1;
 }
+
+/* how many of this engine's rade_batch_rx waits slept on the blocking event / spun (measurement aid) */
+void rade_batch_sync_counts(const rade_batch *h, long *blocking, long *spinning) { if (blocking) *blocking = h->n_sync_block; if (spinning) *spinning = h->n_sync_spin; }
 
 /* shader-clock cycles every stream's workgroup spent in the most recent receiver launch (measurement aid: the launch lasts as
  * long as its slowest stream) */

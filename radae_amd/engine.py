@@ -76,7 +76,12 @@ def load_library() -> C.CDLL:
     L.rade_batch_rx_set_lcg.argtypes = [vp, C.POINTER(C.c_uint)]
     L.rade_batch_rx_get_trace.argtypes = [vp, C.c_int, C.POINTER(RxTrace), vp, C.c_int]
     L.rade_batch_rx_stream_cycles.argtypes = [vp, vp]
-    L.rade_batch_rx_filtered.argtypes = [vp, C.c_int, vp, C.c_int]
+    if hasattr(L, "rade_sync_policy"):
+        L.rade_host_cpu_quota.restype = C.c_double; L.rade_host_cpu_quota.argtypes = []
+        L.rade_sync_policy.argtypes = [C.c_int, C.c_double]
+        L.rade_batch_sync_counts.argtypes = [vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]; L.rade_batch_sync_counts.restype = None
+    if hasattr(L, "rade_batch_rx_filtered"):      # (absent from older A/B builds loaded through $RADE_LIBRADEHIP)
+        L.rade_batch_rx_filtered.argtypes = [vp, C.c_int, vp, C.c_int]
     _lib = L
     return L
 
@@ -91,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_tx_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get", "rade_batch_profile_ref", "rade_batch_profile_intervals",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
-    "rade_batch_rx_stream_cycles", "rade_batch_rx_filtered",
+    "rade_batch_rx_stream_cycles", "rade_batch_rx_filtered", "rade_host_cpu_quota", "rade_sync_policy", "rade_batch_sync_counts",
     "rade_multi_open", "rade_multi_close", "rade_multi_n_devices", "rade_multi_transport", "rade_multi_engine", "rade_multi_shard", "rade_multi_foreach",
     "rade_multi_allreduce_sum",
 ]
@@ -343,6 +348,14 @@ class BatchEngine:
         if got < 0:
             raise RuntimeError("rade_batch_rx_filtered failed")
         return out[:got]
+
+    def sync_counts(self):
+        """(waits that slept on the blocking event, waits that spun) of this engine's rx() calls so far"""
+        a, b = C.c_long(0), C.c_long(0)
+        if not hasattr(self.lib, "rade_batch_sync_counts"):      # (older A/B builds loaded through $RADE_LIBRADEHIP)
+            return 0, 0
+        self.lib.rade_batch_sync_counts(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def rx_stream_cycles(self) -> np.ndarray:
         """Shader-clock cycles each stream's workgroup spent in the most recent receiver launch."""

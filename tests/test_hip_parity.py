@@ -595,6 +595,55 @@ def test_full_size_batch_properties(Engine, torch_dev, oracle, oracle_model, mon
     eng.close()
 
 
+def test_config3_full_size_mpp_vs_oracle(Engine, torch_dev, oracle, oracle_model):
+    """BASELINE.json configs[2] at full size inside `pytest -m gpu`, through the call bench.py times (rade_batch_tx_channel, one pass): 256 streams x 1008
+    frames, MPP Doppler-spread two-path channel (G resident on the device), AWGN at Eb/No = 3 dB, -11 Hz, 1 s of noise in front, EOO frame + 1152 samples behind.
+    The noise is an explicit tensor here (bench.py: device Philox), so that the oracle can be run on two of the streams: per-call discrete outputs equal,
+    features < 1e-4 RMS, loss.py delta < 1e-4."""
+    import torch
+    from radae_amd.channel_tools import multipath_g, synth_features
+    from radae_amd.engine import sigma_from_EbNodB
+    from radae_amd.loss import find_loss
+    B, T = 256, 1008
+    n_mf = T // 12; n_sig = n_mf * 960; n_pre, n_post = 8000, 1152
+    nd = 8                                                            # distinct utterances / channels / noises, replicated 32x
+    feats = np.stack([synth_features(1000 + (b % nd), T) for b in range(B)])
+    Gs = [multipath_g("mpp", 8000, n_sig, 5000 + u) for u in range(nd)]
+    G = torch.tensor(np.stack([Gs[b % nd] for b in range(B)]), device=torch_dev)
+    rng = np.random.default_rng(2026)
+    n_tot = n_pre + n_sig + 1152 + n_post
+    nz = ((rng.standard_normal((nd, n_tot)) + 1j * rng.standard_normal((nd, n_tot))) / np.sqrt(2)).astype(np.complex64)
+    noise = torch.tensor(np.concatenate([nz] * (B // nd)), device=torch_dev)
+    sigma = sigma_from_EbNodB(3.0)
+    eng = Engine(B, max_tx_mf=n_mf, rx_trace_calls=128)
+    rx, iq = eng.tx_channel(torch.tensor(feats, device=torch_dev), sigma, -11.0, n_pre=n_pre, n_post=n_post, with_eoo=True, G=G, noise=noise, want_iq=True)
+    fo, st, _ = eng.rx(rx)
+    nv = np.array([s.n_valid for s in st])
+    assert torch.equal(rx[:nd], rx[B - nd:]) and torch.equal(fo[:nd], fo[B - nd:])          # replicas bit-identical
+    assert nv.mean() > 0.8 * n_mf                                     # MPP at 3 dB: most frames are decoded (fades cost a few)
+    keys = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
+    for b in (1, 6):
+        tx = oracle.Tx(oracle_model)
+        sig = np.concatenate([tx.frame(feats[b, 12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+        assert np.abs(iq[b].cpu().numpy() - sig).max() < 5e-5
+        r, fin = oracle.channel(sig, Gs[b], nz[b, n_pre:n_pre + n_sig], sigma, -11.0)
+        e = oracle.channel_eoo(tx.eoo(), nz[b, n_pre + n_sig:n_pre + n_sig + 1152], sigma, -11.0, 0.0, fin)
+        full = np.concatenate([sigma * nz[b, :n_pre], r, e, sigma * nz[b, -n_post:]]).astype(np.complex64)
+        got_rx = rx[b].cpu().numpy()
+        assert rms(got_rx, full) < 2e-5
+        d = oracle.run_rx_stream(oracle_model, got_rx)               # the receiver on the SAME samples the device receiver read
+        t = eng.rx_trace(b)
+        for k in keys:
+            assert np.array_equal(t[k][:len(d[k])], d[k]), (b, k)
+        assert len(d["features_out"]) == nv[b] and nv[b] > 60
+        got = fo[b, :nv[b]].cpu().numpy()
+        assert rms(got, d["features_out"]) < 1e-4
+        l_o, s_o = find_loss(feats[b], d["features_out"].reshape(-1, 36))
+        l_g, s_g = find_loss(feats[b], got.reshape(-1, 36))
+        assert s_o == s_g and abs(l_o - l_g) < 1e-4                   # loss.py delta vs the oracle < 1e-4
+    eng.close()
+
+
 def test_device_multipath_generator(Engine, torch_dev):
     """the Watterson / Doppler-spread generator on the device.  With the host generator's own low-rate
     noise as input it reproduces radae_amd.channel_tools.multipath_g (FIR, interpolation, hf_gain); from its Philox noise

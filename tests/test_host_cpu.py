@@ -327,6 +327,21 @@ def test_host_blob_reader_rejects_hostile_headers(lib):
         lib.rd_model_parse(bytes(b), len(b), C.byref(Model()))
 
 
+def test_host_wait_policy_switches_to_blocking_sync_under_a_cpu_quota(lib):
+    """rade_batch_rx spins on its stream while every engine's host thread has a CPU and sleeps on a blocking event otherwise: 8 GPUs x 3 batches
+    in flight = 24 engines under the 16-core quota seen on the GPU lease must block; one GPU x 3 must not.  rade_host_cpu_quota reads what
+    bench.py's cpu_quota() reads (affinity mask, cgroup cpu.max)."""
+    import ctypes as C
+    lib.rade_host_cpu_quota.restype = C.c_double
+    lib.rade_sync_policy.argtypes = [C.c_int, C.c_double]
+    assert lib.rade_sync_policy(24, 16.0) == 1 and lib.rade_sync_policy(3, 16.0) == 0 and lib.rade_sync_policy(16, 16.0) == 0 and lib.rade_sync_policy(17, 16.0) == 1
+    assert lib.rade_sync_policy(2, 1.5) == 1 and lib.rade_sync_policy(1, 1.5) == 0
+    import bench
+    ncpu, quota = bench.cpu_quota()
+    q = lib.rade_host_cpu_quota()
+    assert abs(q - min(ncpu, quota if quota else ncpu)) < 1e-9 and q >= 1.0 - 1e-9
+
+
 def test_loss_tool_matches_reference(golden):
     from radae_amd.loss import distortion_loss, find_loss
     g = golden("dec_loss")
