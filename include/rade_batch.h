@@ -33,11 +33,15 @@ typedef struct rade_batch rade_batch;
  * workgroups of two launches share a CU) is the only one; rounds 2-3 selected it with this flag beside a one-stream-per-CU kernel. */
 #define RADE_BATCH_RX_TWO_PER_CU 0x200
 
+/* Tx band-pass filter + magnitude clip on every transmitted frame and the end-of-over frame: radae_tx(..., txbpf_en=True) / `radae_tx.py --txbpf`
+ * (radae_txe.py:74-83, :130-132, :141-143; ctest radae_tx_basic).  Off by default, as in the reference. */
+#define RADE_BATCH_TX_BPF 0x400
+
 typedef struct {
     int n_streams;        /* B */
     int max_tx_mf;        /* largest n_mf a single rade_batch_tx call may carry */
     int device;           /* HIP device ordinal */
-    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm) */
+    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm); RADE_BATCH_TX_BPF */
     int rx_trace_calls;   /* >0: keep a per-call trace of this many do_radae_rx calls per stream (tests) */
     float disable_unsync; /* test mode of radae_rxe.py --disable_unsync (:277-281, :337): after this many seconds in sync the receiver no longer
                            * drops back to search (pilot loss, end-of-over, UW failure); 0 = normal operation */

@@ -61,6 +61,7 @@ def lib():
         L.orc_ofdm_mod.argtypes = [vp, vp]
         L.orc_tx_set_eoo_bits.argtypes = [vp, vp]
         L.orc_tx_eoo.argtypes = [vp, vp]
+        L.orc_tx_set_txbpf.argtypes = [vp, C.c_int]
         L.orc_channel.argtypes = [vp, vp, C.c_int, vp, vp, C.c_float, C.c_float, C.c_float, vp]
         L.orc_channel_eoo.argtypes = [vp, vp, C.c_int, vp, C.c_float, C.c_float, C.c_float, C32]
         L.orc_sigma_from_EbNodB.restype = C.c_float; L.orc_sigma_from_EbNodB.argtypes = [C.c_float]
@@ -148,6 +149,9 @@ class Tx:
 
     def set_eoo_bits(self, bits):
         b = f32(bits); lib().orc_tx_set_eoo_bits(self.h, _p(b))
+
+    def set_txbpf(self, enable=True):
+        lib().orc_tx_set_txbpf(self.h, int(enable))
 
     def eoo(self):
         out = np.zeros(1152, np.complex64); lib().orc_tx_eoo(self.h, _p(out)); return out

@@ -222,7 +222,7 @@ static struct {
     orc_c32 eoo[ORC_NEOO];
     orc_c32 Pmat[ORC_NC][2][3];
     orc_c32 eq_rot[ORC_NC];                 /* exp(-1j*w[c]*a), a = 20 samples (dsp.py:433) */
-    float bpf_h[ORC_NTAP]; float bpf_alpha; float bpf_B; orc_c32 bpf_pv[ORC_NIN_MAX];
+    float bpf_h[ORC_NTAP]; float bpf_alpha; float bpf_B; orc_c32 bpf_pv[ORC_NEOO];   /* 1152 entries: the transmit filter also takes the end-of-over frame */
     orc_c32 p_w[ORC_M][ORC_NFCOARSE]; double fcoarse[ORC_NFCOARSE];
 } K;
 
@@ -299,7 +299,7 @@ static void consts_init(void)
         float s = (float)sin((double)y) / y;
         K.bpf_h[i] = K.bpf_B * s;
     }
-    for (int k = 0; k < ORC_NIN_MAX; k++) {
+    for (int k = 0; k < ORC_NEOO; k++) {
         float arg = (float)((double)K.bpf_alpha * (double)(k + 1));
         K.bpf_pv[k] = c32((float)cos((double)arg), (float)-sin((double)arg));
     }
@@ -457,13 +457,15 @@ void orc_core_decoder(const orc_model *m, orc_dec_state *s, float features[84], 
 /* ============================================================================================
  * 4. transmitter -- radae_txe.py:108-144, dsp.py:340-378, radae.py:441-455
  * ==========================================================================================*/
-struct orc_tx { const orc_model *m; orc_enc_state enc; orc_c32 eoo[ORC_NEOO]; };
+struct orc_bpf { orc_c32 mem[102]; int mem_len; orc_c32 phase; };     /* complex_bpf's state (section 6) */
+struct orc_tx { const orc_model *m; orc_enc_state enc; orc_c32 eoo[ORC_NEOO]; int txbpf_en; struct orc_bpf txbpf; };
 
 orc_tx *orc_tx_new(const orc_model *m)
 {
     consts_init();
     orc_tx *t = calloc(1, sizeof *t);
     t->m = m; memcpy(t->eoo, K.eoo, sizeof K.eoo);
+    t->txbpf.mem_len = 100; t->txbpf.phase = c32(1, 0);
     return t;
 }
 void orc_tx_free(orc_tx *t) { free(t); }
@@ -491,6 +493,20 @@ void orc_ofdm_mod(orc_c32 tx_out[960], const float z[240])
     for (int n = 0; n < ORC_NMF; n++) tx_out[n] = pa_limit(tx_out[n]);                 /* :376-377 */
 }
 
+/* radae_txe.py:74-83, :130-132, :141-143 (--txbpf): the transmit samples through the same complex_bpf the receiver uses on its input, then
+ * np.clip(abs(tx), 0, 1) * np.exp(1j * np.angle(tx)) */
+void orc_tx_set_txbpf(orc_tx *t, int enable) { t->txbpf_en = enable; }
+static void tx_bpf_clip(orc_tx *t, orc_c32 *tx, int n)
+{
+    orc_c32 y[ORC_NEOO];
+    orc_bpf_run(&t->txbpf, y, tx, n);
+    for (int i = 0; i < n; i++) {
+        const float mag = (float)hypot((double)y[i].re, (double)y[i].im), ang = atan2f(y[i].im, y[i].re);
+        const float m = mag > 1.0f ? 1.0f : mag;
+        tx[i] = c32(m * cosf(ang), m * sinf(ang));
+    }
+}
+
 void orc_tx_frame(orc_tx *t, orc_c32 tx_out[960], const float features_in[432], float *z_out)
 {
     float z[240], feat[84];
@@ -503,6 +519,7 @@ void orc_tx_frame(orc_tx *t, orc_c32 tx_out[960], const float features_in[432], 
     }
     if (z_out) memcpy(z_out, z, sizeof z);
     orc_ofdm_mod(tx_out, z);
+    if (t->txbpf_en) tx_bpf_clip(t, tx_out, ORC_NMF);                                 /* radae_txe.py:130-132 */
 }
 
 void orc_tx_set_eoo_bits(orc_tx *t, const float bits[180])
@@ -512,7 +529,7 @@ void orc_tx_set_eoo_bits(orc_tx *t, const float bits[180])
     ofdm_symbols_to_time(td, (const orc_c32(*)[ORC_NC])sym, ORC_NS - 1);
     for (int n = 0; n < (ORC_NS - 1) * ORC_SYM; n++) t->eoo[2 * ORC_SYM + n] = pa_limit(cscalef(td[n], K.pilot_gain_f));
 }
-void orc_tx_eoo(orc_tx *t, orc_c32 out[1152]) { memcpy(out, t->eoo, sizeof t->eoo); }
+void orc_tx_eoo(orc_tx *t, orc_c32 out[1152]) { memcpy(out, t->eoo, sizeof t->eoo); if (t->txbpf_en) tx_bpf_clip(t, out, ORC_NEOO); }   /* radae_txe.py:138-144 */
 
 /* ============================================================================================
  * 5. channel -- radae.py:529-589 with batch 1 (global mean == per utterance), inference.py:263-275
@@ -577,13 +594,12 @@ void orc_channel_eoo(orc_c32 *rx, const orc_c32 *eoo, int n, const orc_c32 *nois
  * ==========================================================================================*/
 /* ---- complex_bpf.bpf, dsp.py:63-102.  Quirk kept: memory is Ntap-1 = 100 samples on the first
  *      call and Ntap+1 = 102 afterwards (:55 vs :96) while the window always starts at index 0. */
-struct orc_bpf { orc_c32 mem[102]; int mem_len; orc_c32 phase; };
 orc_bpf *orc_bpf_new(void) { consts_init(); orc_bpf *b = calloc(1, sizeof *b); b->mem_len = 100; b->phase = c32(1, 0); return b; }
 void orc_bpf_free(orc_bpf *b) { free(b); }
 
 void orc_bpf_run(orc_bpf *b, orc_c32 *out, const orc_c32 *in, int n)
 {
-    orc_c32 xm[102 + ORC_NIN_MAX], pv[ORC_NIN_MAX];
+    orc_c32 xm[102 + ORC_NEOO], pv[ORC_NEOO];
     int ml = b->mem_len;
     memcpy(xm, b->mem, sizeof(orc_c32) * ml);
     for (int i = 0; i < n; i++) { pv[i] = cmulf(b->phase, K.bpf_pv[i]); xm[ml + i] = cmulf(in[i], pv[i]); }

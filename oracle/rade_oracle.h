@@ -65,6 +65,7 @@ void orc_tx_free(orc_tx *t);
 void orc_tx_frame(orc_tx *t, orc_c32 tx_out[960], const float features_in[432], float *z_out);
 void orc_ofdm_mod(orc_c32 tx_out[960], const float z[240]);
 void orc_tx_set_eoo_bits(orc_tx *t, const float bits[180]);
+void orc_tx_set_txbpf(orc_tx *t, int enable);      /* radae_tx(..., txbpf_en=True): Tx band-pass filter + magnitude clip on every frame and the EOO frame */
 void orc_tx_eoo(orc_tx *t, orc_c32 out[1152]);
 
 /* ---- channel simulator (radae.py:529-589, inference.py:155-171,263-284), batch of one ------ */

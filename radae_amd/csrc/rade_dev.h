@@ -45,7 +45,7 @@ typedef struct {
     float Pmat[RD_NC][2][3][2];        /* dsp.py:400-412 */
     float eq_rot[RD_NC][2];            /* exp(-1j*w[c]*20), dsp.py:433 */
     float bpf_h[RD_NTAP + 3];          /* dsp.py:46-49 */
-    float bpf_E[RD_NINMAX][2];         /* phase_vec_exp, dsp.py:61 */
+    float bpf_E[RD_NEOO][2];           /* phase_vec_exp, dsp.py:61: exp(-j alpha (i + 1)); 1152 entries (the transmit filter also takes the end-of-over frame) */
     float p_w[RD_M][RD_NFC][2];        /* acquisition.p_w, dsp.py:166-173 */
     double fcoarse[RD_NFC];            /* dsp.py:163 */
     float pilot_gain;                  /* radae.py:196-199 */
@@ -183,6 +183,7 @@ typedef struct {
     const rd_tables *tab; rd_rx_stream *st; rd_rx_round *round;
     const void *rx; long rx_stride; const int *avail;   /* [B] samples readable at rx + b*stride (raw input: the receiver only reads it to rebuild the filter memory) */
     void *rxf; long rxf_stride;                          /* band-pass filtered samples of the invocation (k_rx_bpf), same indexing as rx */
+    const unsigned short *bpf16;                         /* rd_bpf16_table_fill(): [4][2][64][8] binary16, the band-pass taps as matrix-core A operands */
     const void *bpf_chain; int chain_stride;             /* [B][chain_stride] float2: (nin0, mem_len0) + the block phases of the pre-pass */
     int *acc;                                            /* [B][4] this invocation: consumed, calls, valid, eoo */
     int max_calls;                                       /* call budget per stream per invocation */
@@ -209,10 +210,23 @@ int rd_launch_rx_sync(const rd_sync_args *a, rd_stream_t s);
 /* once per device before the first launch (rade_batch_open): raises the kernel's dynamic-LDS limit; returns the bytes to launch with, < 0 on error */
 int rd_rx_sync_prepare(int solo);
 
-/* complex_bpf.bpf (dsp.py:63-102) for every sample of a rade_batch_rx invocation, ahead of the receiver launches: chain [B][chain_stride] float2
- * (chain_stride >= n_blocks + 3), rxf [B][rxf_stride] complex64; n_blocks = 1 + ceil(max(avail) / 800) covers every stream */
-int rd_launch_rx_bpf(rd_rx_stream *st, const rd_tables *tab, const void *rx, long rx_stride, const int *avail_dev, void *chain, int chain_stride,
-                     void *rxf, long rxf_stride, int n_blocks, int B, rd_stream_t s);
+/* complex_bpf.bpf (dsp.py:63-102) over n samples of every stream in one pass (rade_rx.hip: k_bpf_chain + k_bpf_fir [+ k_bpf_advance]): the receiver's
+ * input filter ahead of the receiver launches of an invocation, and the transmitter's optional output filter (radae_txe.py:74-83).  Streams are cut into
+ * blocks as the reference cuts them into calls: the first block len0 samples, every later one 960. */
+typedef struct {
+    rd_bpf_state *state; long state_stride;      /* record of stream b at (char *)state + b * state_stride */
+    const int *len0; long len0_stride;           /* first block length of stream b at (char *)len0 + b * len0_stride (the receiver: its nin), or NULL: len0_const */
+    int len0_const;
+    const int *avail; int avail_const;           /* samples of stream b: device array, or NULL: avail_const for every stream */
+    const rd_tables *tab; const unsigned short *bpf16;   /* rd_bpf16_table_fill(): the taps as matrix-core operands */
+    const void *x; long x_stride; void *y; long y_stride;   /* complex64 in / out, stream b at + b * stride (samples); must not overlap */
+    void *chain; int chain_stride;               /* [B][chain_stride] float2 scratch, chain_stride >= n_blocks + 3: (len0, mem_len) + the block phases */
+    int n_blocks;                                /* blocks of the longest stream */
+    int B;
+    int clip;                                    /* 1: magnitude limited to 1 after the filter (radae_txe.py:132) */
+    int advance;                                 /* 1: every sample is consumed -- leave the state complex_bpf would hold (the receiver kernel does that itself, by what it consumed) */
+} rd_bpf_args;
+int rd_launch_bpf(const rd_bpf_args *a, rd_stream_t s);
 int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
 
 /* ---- one core encoder / decoder step of ONE stream as one launch (rade_core_step.hip; include/rade_core.h) ----

@@ -20,6 +20,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define PI_D 3.14159265358979323846
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// the same product with every operation rounded on its own (no fused multiply-add: contraction switched off for this function, whatever the
+// command line says -- HIP's __fmul_rn / __fadd_rn are plain operators and contract like any other): what NumPy's complex64 multiply does, and,
+// unlike cmul, whose contraction the compiler decides per call site, the same bits in every kernel that uses it
+__device__ __forceinline__ float2 cmul_nc(float2 a, float2 b)
+{
+#pragma clang fp contract(off)
+    const float rr = a.x * b.x, ii = a.y * b.y, ri = a.x * b.y, ir = a.y * b.x;
+    return make_float2(rr - ii, ri + ir);
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // e^{-j angle(c)} = conj(c)/|c| (np.exp(-1j*np.angle(c)) without atan2 / sincos); angle(0) = 0

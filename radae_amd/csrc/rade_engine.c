@@ -64,7 +64,7 @@ struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
     int unsync_off_after;                 /* int(disable_unsync * Fs / Nmf) or -1 */
-    unsigned short *corr16, *wfwd16; double *vm; int rx_lds, rx_census;   /* dynamic LDS of a receiver launch; phase mask of the -DRX2_CENSUS developer build */
+    unsigned short *corr16, *wfwd16, *bpf16; double *vm; int rx_lds, rx_census;   /* dynamic LDS of a receiver launch; phase mask of the -DRX2_CENSUS developer build */
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -74,6 +74,8 @@ struct rade_batch {
     unsigned short *dec_whq[5]; float *dec_whs[5];      /* decoder W_hh as matrix-core fragments (int8-exact) + row scales; NULL when the blob's recurrent weights are not int8 x scale */
     /* transmit side */
     float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
+    /* optional Tx band-pass filter + clip (RADE_BATCH_TX_BPF; radae_txe.py:74-83): filter state per stream, its initial value, the modulator's raw output, block phases */
+    rd_bpf_state *tx_bpf, *tx_bpf_init; void *tx_raw; float *tx_chain;
     void *chan_scratch; void *chan_mp;        /* chan_mp [B][max_tx_mf * 960] c64: multipath output of the fused modulator (rade_batch_tx_channel), allocated on first use */
     /* receive side */
     rd_rx_stream *rx_st; rd_rx_round *rx_round;
@@ -183,6 +185,7 @@ static void rx_reset_on(rade_batch *h, void *stream)
 static void tx_reset_on(rade_batch *h, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    if (h->tx_bpf) hipMemcpyAsync(h->tx_bpf, h->tx_bpf_init, sizeof(rd_bpf_state) * h->B, hipMemcpyDeviceToDevice, st);
     hipMemsetAsync(h->enc_h[0], 0, sizeof(float) * 5 * h->B * 64, st);
     /* the two history rows of each stream (conv taps before the first frame); rows 2.. are written layer by layer before they are read */
     hipMemset2DAsync(h->enc_x, sizeof(float) * (size_t)(2 + h->Tcap) * RD_ENC_W, 0, sizeof(float) * 2 * RD_ENC_W, h->B, st);
@@ -245,6 +248,10 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         unsigned short *w16 = malloc(sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8);
         if (w16) { rd_wfwd16_table_fill(tab, w16); h->wfwd16 = dev_upload(w16, sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8); free(w16); }
     }
+    {   /* the band-pass taps as matrix-core operands (k_rx_bpf) */
+        unsigned short *b16 = malloc(sizeof(unsigned short) * 4 * 2 * 64 * 8);
+        if (b16) { rd_bpf16_table_fill(tab, b16); h->bpf16 = dev_upload(b16, sizeof(unsigned short) * 4 * 2 * 64 * 8); free(b16); }
+    }
     free(tab);
     {   /* ((n - 79.5) / 80)^m, m = 0..7, by repeated multiplication (the order the kernels build their LDS copy in) */
         double vm[8][RD_M];
@@ -256,7 +263,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
      * (developer switch) asks for more than half a CU's LDS, i.e. one workgroup per CU. */
     h->rx_lds = rd_rx_sync_prepare(getenv("RADE_RX2_SOLO") != NULL);
     h->rx_census = getenv("RADE_RX2_CENSUS") ? atoi(getenv("RADE_RX2_CENSUS")) : 0;      /* only acts in -DRX2_CENSUS builds */
-    if (!h->d_tab || !h->corr16 || !h->vm || !h->wfwd16 || h->rx_lds <= 0) goto fail;
+    if (!h->d_tab || !h->corr16 || !h->vm || !h->wfwd16 || !h->bpf16 || h->rx_lds <= 0) goto fail;
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
@@ -290,6 +297,17 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->enc_z = dev_zeros(sizeof(float) * B * T * RD_LATENT);
     h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
     h->eoo_bits = dev_zeros(sizeof(float) * B * RD_NEOOBITS);
+    if (cfg->flags & RADE_BATCH_TX_BPF) {
+        const long nraw = (long)(cfg->max_tx_mf > 2 ? cfg->max_tx_mf : 2) * RD_NMF;          /* (>= the 1152-sample end-of-over frame) */
+        rd_bpf_state *init = calloc(B, sizeof *init);
+        if (!init) goto fail;
+        for (size_t b = 0; b < B; b++) { init[b].mem_len = 100; init[b].phase[0] = 1.0f; }    /* complex_bpf.__init__: dsp.py:54-60 */
+        h->tx_bpf_init = dev_upload(init, sizeof(rd_bpf_state) * B); h->tx_bpf = dev_upload(init, sizeof(rd_bpf_state) * B);
+        free(init);
+        h->tx_raw = dev_zeros(sizeof(float) * 2 * B * nraw);
+        h->tx_chain = dev_zeros(sizeof(float) * 2 * B * (cfg->max_tx_mf + 8));
+        if (!h->tx_bpf_init || !h->tx_bpf || !h->tx_raw || !h->tx_chain) goto fail;
+    }
     h->chan_scratch = dev_zeros(sizeof(double) * B * (cfg->max_tx_mf > 64 ? cfg->max_tx_mf : 64) * 2);
     h->enc_h[0] = dev_zeros(sizeof(float) * 5 * B * 64); h->dec_h[0] = dev_zeros(sizeof(float) * 5 * B * 96);
     if (!h->enc_h[0] || !h->dec_h[0]) goto fail;
@@ -365,7 +383,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
+                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -495,6 +513,21 @@ static int encode_core(rade_batch *h, int T, float *z, void *stream)
     return e;
 }
 
+/* the optional Tx band-pass filter + magnitude clip (radae_txe.py:130-132, :141-143) over the n samples the modulator left in tx_raw: the receiver's
+ * filtering pass with frames as blocks (len0 = the first frame: 960, or the 1152-sample end-of-over frame), every sample consumed */
+static int tx_bpf_pass(rade_batch *h, int n, int len0, void *out, long out_stride, void *stream)
+{
+    rd_bpf_args ba;
+    memset(&ba, 0, sizeof ba);
+    ba.state = h->tx_bpf; ba.state_stride = sizeof(rd_bpf_state); ba.len0_const = len0; ba.avail_const = n;
+    ba.tab = h->d_tab; ba.bpf16 = h->bpf16; ba.x = h->tx_raw; ba.x_stride = (long)(h->max_tx_mf > 2 ? h->max_tx_mf : 2) * RD_NMF; ba.y = out; ba.y_stride = out_stride;
+    ba.chain = h->tx_chain; ba.chain_stride = h->max_tx_mf + 8; ba.n_blocks = 1 + (n > len0 ? (n - len0 + RD_NMF - 1) / RD_NMF : 0); ba.B = h->B; ba.clip = 1; ba.advance = 1;
+    PROF_BEGIN(h, stream);
+    const int rc = rd_launch_bpf(&ba, stream);
+    PROF_END(h, stream, RADE_PROF_BPF, 8.0 * 101.0 * (double)h->B * n);
+    return rc;
+}
+
 /* ---- transmit (radae_txe.py:108-135 for n_mf modem frames and B streams at once) -------------- */
 int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, float *z_out_dev, void *stream)
 {
@@ -505,7 +538,9 @@ int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_o
     int e = 0;
     e |= rd_launch_enc_pack(features_dev, h->enc_xin, B, T, stream);
     e |= encode_core(h, T, z, stream);
-    PROF_BEGIN(h, stream); e |= rd_launch_ofdm_mod(h->d_tab, z, iq_out_dev, iq_stride, B, n_mf, stream); PROF_END(h, stream, RADE_PROF_MOD, 8.0 * B * n_mf * 5 * 30 * 160);
+    void *mod_out = h->tx_bpf ? h->tx_raw : iq_out_dev; const long mod_stride = h->tx_bpf ? (long)(h->max_tx_mf > 2 ? h->max_tx_mf : 2) * RD_NMF : iq_stride;
+    PROF_BEGIN(h, stream); e |= rd_launch_ofdm_mod(h->d_tab, z, mod_out, mod_stride, B, n_mf, stream); PROF_END(h, stream, RADE_PROF_MOD, 8.0 * B * n_mf * 5 * 30 * 160);
+    if (h->tx_bpf) e |= tx_bpf_pass(h, n_mf * RD_NMF, RD_NMF, iq_out_dev, iq_stride, stream);
     return e ? -1 : n_mf * RD_NMF;
 }
 
@@ -530,7 +565,10 @@ int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host)
 int rade_batch_tx_eoo(rade_batch *h, void *iq_out_dev, long iq_stride, void *stream)
 {
     ON_DEV(h);
-    return rd_launch_copy_eoo(h->eoo, iq_out_dev, iq_stride, h->B, stream) ? -1 : RD_NEOO;
+    if (!h->tx_bpf) return rd_launch_copy_eoo(h->eoo, iq_out_dev, iq_stride, h->B, stream) ? -1 : RD_NEOO;
+    int e = rd_launch_copy_eoo(h->eoo, h->tx_raw, (long)(h->max_tx_mf > 2 ? h->max_tx_mf : 2) * RD_NMF, h->B, stream);
+    e |= tx_bpf_pass(h, RD_NEOO, RD_NEOO, iq_out_dev, iq_stride, stream);
+    return e ? -1 : RD_NEOO;
 }
 
 /* ---- channel ----------------------------------------------------------------------------------- */
@@ -563,7 +601,7 @@ int rade_batch_tx_channel(rade_batch *h, const float *features_dev, int n_mf, vo
 {
     ON_DEV(h);
     if (!h || !p || n_mf <= 0 || n_mf > h->max_tx_mf || h->feat_in != 84 || p->n_sig != n_mf * RD_NMF || !rx_out_dev) return -1;
-    if (!p->G_dev) {
+    if (!p->G_dev || h->tx_bpf) {          /* (the Tx band-pass filter sits between the modulator and the channel: the two calls back to back) */
         if (!iq_out_dev) return -1;
         if (rade_batch_tx(h, features_dev, n_mf, iq_out_dev, iq_stride, NULL, stream) != p->n_sig) return -1;
         return rade_batch_channel(h, iq_out_dev, iq_stride, rx_out_dev, rx_stride, p, stream);
@@ -692,12 +730,19 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     }
     CHK(hipMemcpyAsync(h->rx_avail, n_avail_host, sizeof(int) * B, hipMemcpyHostToDevice, st));
     PROF_BEGIN(h, st);
-    if (rd_launch_rx_bpf(h->rx_st, h->d_tab, rx_dev, rx_stride, h->rx_avail, h->bpf_chain, h->chain_stride, h->rx_filt, h->filt_cap, n_blocks, B, st)) goto fail;
+    {
+        rd_bpf_args ba;
+        memset(&ba, 0, sizeof ba);
+        ba.state = &h->rx_st->bpf; ba.state_stride = sizeof(rd_rx_stream); ba.len0 = &h->rx_st->nin; ba.len0_stride = sizeof(rd_rx_stream); ba.avail = h->rx_avail;
+        ba.tab = h->d_tab; ba.bpf16 = h->bpf16; ba.x = rx_dev; ba.x_stride = rx_stride; ba.y = h->rx_filt; ba.y_stride = h->filt_cap;
+        ba.chain = h->bpf_chain; ba.chain_stride = h->chain_stride; ba.n_blocks = n_blocks; ba.B = B;
+        if (rd_launch_bpf(&ba, st)) goto fail;
+    }
     PROF_END(h, st, RADE_PROF_BPF, 8.0 * 101.0 * (double)B * max_avail);
     CHK(hipMemsetAsync(h->rx_acc, 0, sizeof(int) * B * 4, st));
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
-    sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.rxf = h->rx_filt; sa.rxf_stride = h->filt_cap; sa.bpf_chain = h->bpf_chain; sa.chain_stride = h->chain_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
+    sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.rxf = h->rx_filt; sa.rxf_stride = h->filt_cap; sa.bpf16 = h->bpf16; sa.bpf_chain = h->bpf_chain; sa.chain_stride = h->chain_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
     sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_census << 8; sa.lds_bytes = h->rx_lds;

@@ -89,7 +89,7 @@ void rd_tables_fill(rd_tables *T)
         const float y = (float)PI_D * (x == 0.0f ? 1.0e-20f : x);
         T->bpf_h[i] = Bn * ((float)sin((double)y) / y);
     }
-    for (int k = 0; k < RD_NINMAX; k++) {
+    for (int k = 0; k < RD_NEOO; k++) {
         const float arg = (float)((double)alpha * (double)(k + 1));
         T->bpf_E[k][0] = (float)cos((double)arg); T->bpf_E[k][1] = (float)-sin((double)arg);
     }
@@ -492,3 +492,18 @@ void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out /* [2][10][2][
                 }
 }
 
+/* complex_bpf's 101 real taps (dsp.py:46-49) as the A operands of the matrix-core FIR (rade_rx.hip: bpf_fir_tile): the Toeplitz rows
+ * T[r][m] = 2^10 h[m - r] (0 outside 0 <= m - r <= 100), r = 0..15 outputs of a group, m = 0..127 window positions, in two binary16 planes
+ * and the A-operand order of v_mfma_f32_16x16x32_f16: out[ks][plane][lane][j] = plane(T[lane % 16][32 ks + 8 (lane / 16) + j]) */
+void rd_bpf16_table_fill(const rd_tables *T, unsigned short *out /* [4][2][64][8] */)
+{
+    for (int ks = 0; ks < 4; ks++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 8; j++) {
+                const int r = lane & 15, m = 32 * ks + 8 * (lane >> 4) + j, t = m - r;
+                const float v = (t >= 0 && t < RD_NTAP) ? 1024.0f * T->bpf_h[t] : 0.0f;
+                const unsigned short hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                unsigned short *o = out + (((size_t)ks * 2) * 64 + lane) * 8 + j;
+                o[0] = hi; o[64 * 8] = lo;
+            }
+}

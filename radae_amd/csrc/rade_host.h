@@ -30,6 +30,7 @@ void rd_model_free(rd_model *m);
 long rd_packed16_size(int N, int K);
 void rd_corr16_table_fill(const rd_tables *T, unsigned short *out);
 void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out);
+void rd_bpf16_table_fill(const rd_tables *T, unsigned short *out);   /* [4][2][64][8] */
 long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out);
 /* int8-exact layers for k_gemm16: ONE plane of integers in the B-operand order of v_mfma_f32_32x32x16_f16, out[K/16][ceil(N/32)][64][8];
  * scale_out[32 ceil(N/32)].  Returns the size in halfs or -1 when W is not q * row_scale with integer |q| <= 127. */

@@ -1095,11 +1095,84 @@ __device__ __forceinline__ void check2_rows_tiles(RxShared2 *sh, const unsigned 
 // follows the reference's own partition: block 0 = the nin the stream's next call will consume (from its state record), every later block Nmf
 // samples -- exact unless a timing slip changes nin INSIDE an invocation; from that call on the stream filters its own samples (rx2_bpf_own)
 // until the invocation ends, and the next invocation's pre-pass starts from the state it left.  Either way every output sample is what
-// complex_bpf.bpf would have produced for the stream's actual sequence of calls, value for value (taps in ascending order, one fused
-// multiply-add per component and tap), so cutting a stream into invocations differently cannot move a bit.
+// complex_bpf.bpf would have produced for the stream's actual sequence of calls, from ONE arithmetic (bpf_stage_planes + bpf_fir_tile, shared by
+// the pre-pass kernel and rx2_bpf_own; mixers without fused multiply-adds: cmul_nc), so cutting a stream into invocations differently cannot move a bit.
+// The same kernels filter the transmit side (radae_txe.py:74-83, :130-132: the optional Tx band-pass filter, there followed by the magnitude clip).
 //   chain[b] (float2 [chain_stride]): entry 0 = (nin0, mem_len0) as integer bits, entry 1 + k = the phase block k starts from.
 // Memory quirk kept (dsp.py:55 against :96): the memory holds Ntap - 1 = 100 samples before the first call and Ntap + 1 = 102 after it while the
 // strided window always starts at index 0, so outputs are delayed by two more samples from the second call on.
+
+// ---- the 101-tap FIR on the matrix cores (shared by the pre-pass kernel and the receiver's own off-grid filtering: one arithmetic) -----------
+// y[i] = sum_t h[t] w[i + t] over a window w of baseband samples is the product of the Toeplitz matrix T[r][m] = h[m - r] (16 x 128, taps padded
+// with zeros) with the Hankel matrix U[m][q] = w[16 q + m]: Y[r][q] = y[16 q + r], one 16 x 16 tile = 256 consecutive outputs.  On
+// v_mfma_f32_16x16x32_f16: T is the A operand (two binary16 planes of 2^10 h, a constant table: rd_bpf16_table_fill), U the B operand -- its
+// fragment for (column q, k-group g, k-step ks) is EIGHT CONSECUTIVE window samples starting at 16 q + 32 ks + 8 g, one aligned 16-byte LDS read
+// from a plane -- real and imaginary parts as separate planes, each split hi + lo (22 bits, one power-of-two scale per block from its largest
+// component): hi hi + hi lo + lo hi in f32, 24 matrix instructions per tile against 51,712 vector FMAs.  The vector FIR was bound by LDS reads
+// (every thread re-read its sliding window); this form reads each plane entry 8 times instead of 101.
+#define BPF_NPL 1408                   /* halfs per plane: five tiles of 256 outputs + the 127 samples the last rows reach beyond */
+#define BPF_TILES(n) (((n) + 255) >> 8)
+struct BpfLds {                        // 11,264 B: exactly the receiver's xm work area
+    __attribute__((aligned(16))) _Float16 rh[BPF_NPL], rl[BPF_NPL], ih[BPF_NPL], il[BPF_NPL];
+};
+// The window [memory (102) | block (n)] into the four planes, entry i of it at plane index i - o (o = 2 before a stream's first call, whose memory is two
+// samples shorter: dsp.py:55; entries below o are dropped): thread tid brings head = entry tid (tid < 102) and body[q] = entry 102 + tid + 256 q, ZERO
+// beyond the block -- all loaded by the caller in one batch, so that a workgroup pays one memory round trip for its window and not one per entry.
+// Returns the factor that undoes the operand scales.  Every thread of the 256-thread workgroup calls this (two barriers inside); maxw is an LDS word.
+#define BPF_NQ 5                       /* body entries per thread: 5 x 256 >= the longest block (1152, the end-of-over frame on the transmit side) */
+__device__ __forceinline__ float bpf_stage_planes(BpfLds *pl, unsigned *maxw, int tid, float2 head, const float2 (&body)[BPF_NQ], int o)
+{
+    float m = tid < 102 ? fmaxf(fabsf(head.x), fabsf(head.y)) : 0.0f;
+#pragma unroll
+    for (int q = 0; q < BPF_NQ; q++) m = fmaxf(m, fmaxf(fabsf(body[q].x), fabsf(body[q].y)));
+    if (tid == 0) *maxw = 0u;
+    __syncthreads();
+    m = wave_max_f32(m);
+    if ((tid & 63) == 0) atomicMax(maxw, __float_as_uint(m));
+    __syncthreads();
+    const int eb = min(max((int)((*maxw >> 23) & 0xffu), 32), 222);
+    const float sc = __uint_as_float((unsigned)(127 + 7 - (eb - 127)) << 23);          // the largest component lands in [2^7, 2^8)
+    auto put = [&](int w, float2 v) {
+        const float xr = v.x * sc, xi = v.y * sc;
+        const _Float16 h0 = (_Float16)xr, h1 = (_Float16)xi;
+        pl->rh[w] = h0; pl->rl[w] = (_Float16)(xr - (float)h0); pl->ih[w] = h1; pl->il[w] = (_Float16)(xi - (float)h1);
+    };
+    if (tid < 102 && tid >= o) put(tid - o, head);
+#pragma unroll
+    for (int q = 0; q < BPF_NQ; q++) put(102 - o + tid + 256 * q, body[q]);
+    if (tid < BPF_NPL - (102 + 256 * BPF_NQ)) put(102 + 256 * BPF_NQ + tid, make_float2(0.0f, 0.0f));      // the tail the last tile's rows reach into
+    if (tid < o) put(BPF_NPL - o + tid, make_float2(0.0f, 0.0f));
+    __syncthreads();
+    return __uint_as_float((unsigned)(eb - 7 - 10) << 23);                            // 2^(E - 7) from the samples, 2^-10 from the taps
+}
+// outputs 256 tile + 16 (lane & 15) + 4 (lane >> 4) + r, r = 0..3, of the staged window: (re[r], im[r]), still in operand scale
+struct BpfTaps { f16x8 h[4], l[4]; };          // the lane's A fragments (rd_bpf16_table_fill): loaded once, ahead of the staging
+__device__ __forceinline__ void bpf_load_taps(BpfTaps &t, const unsigned short *tab16, int lane)
+{
+    typedef const __attribute__((address_space(1))) f16x8 glb_f16x8_t;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { t.h[ks] = *(glb_f16x8_t *)(tab16 + (((size_t)ks * 2) * 64 + lane) * 8); t.l[ks] = *(glb_f16x8_t *)(tab16 + (((size_t)ks * 2 + 1) * 64 + lane) * 8); }
+}
+__device__ __forceinline__ void bpf_fir_tile(const BpfLds *pl, const BpfTaps &t, int tile, int lane, f32x4 &re, f32x4 &im)
+{
+    const f16x8 (&Ah)[4] = t.h, (&Al)[4] = t.l;
+    const int w0 = 256 * tile + 16 * (lane & 15) + 8 * (lane >> 4);
+    f32x4 a[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a[k] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        const f16x8 brh = *(const f16x8 *)&pl->rh[w0 + 32 * ks], brl = *(const f16x8 *)&pl->rl[w0 + 32 * ks];
+        const f16x8 bih = *(const f16x8 *)&pl->ih[w0 + 32 * ks], bil = *(const f16x8 *)&pl->il[w0 + 32 * ks];
+        a[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[ks], brh, a[0], 0, 0, 0);
+        a[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ks], brl, a[1], 0, 0, 0);
+        a[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ks], brh, a[2], 0, 0, 0);
+        a[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al[ks], bih, a[3], 0, 0, 0);
+        a[4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ks], bil, a[4], 0, 0, 0);
+        a[5] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[ks], bih, a[5], 0, 0, 0);
+    }
+    re = (a[0] + a[1]) + a[2]; im = (a[3] + a[4]) + a[5];
+}
 
 // baseband sample q of the invocation (x[q] times the phase of its block), q >= -102: the filter memory a stream needs when it leaves the grid or
 // the launch ends; negative q reaches into the memory the invocation started with
@@ -1110,38 +1183,50 @@ __device__ __forceinline__ float2 rx2_bpf_mem(const rd_sync_args &a, int b, int 
     const float2 *x = (const float2 *)a.rx + (size_t)b * a.rx_stride;
     const float2 *chain = (const float2 *)a.bpf_chain + (size_t)b * a.chain_stride;
     const int k = q < nin0 ? 0 : 1 + (q - nin0) / RD_NMF, sk = k ? nin0 + (k - 1) * RD_NMF : 0;
-    return cmul(x[q], cmul(chain[1 + k], ld2(a.tab->bpf_E, q - sk)));
+    return cmul_nc(x[q], cmul_nc(chain[1 + k], ld2(a.tab->bpf_E, q - sk)));
 }
 
-// One call's filtering by the stream's own workgroup (off the grid).  Cold path: one output at a time per thread, memory in the stream record.
+// One call's filtering by the stream's own workgroup (off the grid): the pre-pass's arithmetic on the stream's actual call.  Cold path; the filter
+// memory lives in the stream record between calls.
 __device__ __forceinline__ void rx2_bpf_own(RxShared2 *sh, const rd_sync_args &a, int b, float2 *rxf, int cons0, int nin, int calls0)
 {
+    static_assert(sizeof(BpfLds) <= sizeof(sh->xm), "the planes overlay the xm work area");
     RxScalars *S = &sh->S;
     rd_rx_stream *st = a.st + b;
     const rd_tables *tab = a.tab;
     const float2 *x = (const float2 *)a.rx + (size_t)b * a.rx_stride;
     const int tid = rx_tid();
-    float2 ph;
-    if (S->bpf_grid) {          // leaving the grid at this call: memory = the 102 baseband samples before it, phase = the chain's value at this block boundary
-        ph = ((const float2 *)a.bpf_chain)[(size_t)b * a.chain_stride + 1 + calls0];
-        for (int i = tid; i < 102; i += NT2) sh->xm[i] = rx2_bpf_mem(a, b, S->nin0, cons0 - 102 + i);
-    } else {
-        ph = S->bpf_phase;
-        for (int i = tid; i < 102; i += NT2) sh->xm[i] = make_float2(st->bpf.mem[i][0], st->bpf.mem[i][1]);
-    }
-    float *hl = (float *)&sh->xm[1224];                    // the taps, behind [memory | new] (102 + 1120 entries)
-    for (int i = tid; i < RD_NTAP; i += NT2) hl[i] = tab->bpf_h[i];
-    for (int i = tid; i < nin; i += NT2) sh->xm[102 + i] = cmul(x[cons0 + i], cmul(ph, ld2(tab->bpf_E, i)));
+    const bool leaving = S->bpf_grid != 0;     // leaving the grid at this call: memory = the 102 baseband samples before it, phase = the chain's value at this block boundary
+    const float2 ph = leaving ? ((const float2 *)a.bpf_chain)[(size_t)b * a.chain_stride + 1 + calls0] : S->bpf_phase;
+    const int nin0 = S->nin0;
+    BpfLds *pl = (BpfLds *)&sh->xm[0];
+    const int wave = tid >> 6, lane = tid & 63;
+    BpfTaps taps; bpf_load_taps(taps, a.bpf16, lane);
+    auto mixed = [&](int j) { return cmul_nc(x[cons0 + j], cmul_nc(ph, ld2(tab->bpf_E, j))); };       // baseband sample j of this call
+    float2 head = make_float2(0.0f, 0.0f), body[BPF_NQ];
+    if (tid < 102) head = leaving ? rx2_bpf_mem(a, b, nin0, cons0 - 102 + tid) : make_float2(st->bpf.mem[tid][0], st->bpf.mem[tid][1]);
+#pragma unroll
+    for (int q = 0; q < BPF_NQ; q++) { const int j = tid + 256 * q; body[q] = mixed(min(j, nin - 1)); if (j >= nin) body[q] = make_float2(0.0f, 0.0f); }
+    const float2 memv = mixed(nin - 102 + min(tid, 101));      // new memory = the last 102 of [memory | new] (nin >= 800: all of them new samples)
+    const float unsc = bpf_stage_planes(pl, (unsigned *)&sh->redi[14], tid, head, body, 0);
+    // The outputs go to the stream's slice of the pre-pass buffer (what rade_batch_rx_filtered shows) AND, through LDS, to the caller: the caller's threads
+    // read samples other lanes produced, and a plain global load may hit the vector L1 line the previous call's first-touch loads left there (stale
+    // pre-pass values) -- stores go through to L2 without refreshing it.  xm is free once every wavefront is done with the planes.
+    f32x4 re[2], im[2];
+    for (int u = 0; u < 2; u++) { const int tile = wave + (NT2 / 64) * u; if (tile < BPF_TILES(nin)) bpf_fir_tile(pl, taps, tile, lane, re[u], im[u]); }
     __syncthreads();
-#pragma unroll 1
-    for (int i = tid; i < nin; i += NT2) {
-        float ar = 0.0f, ai = 0.0f;
-#pragma unroll 4
-        for (int t = 0; t < RD_NTAP; t++) { const float2 v = sh->xm[i + t]; const float h = hl[t]; ar = fmaf(v.x, h, ar); ai = fmaf(v.y, h, ai); }
-        rxf[cons0 + i] = cmul(make_float2(ar, ai), cconj(cmul(ph, ld2(tab->bpf_E, i))));
+    for (int u = 0; u < 2; u++) {
+        const int tile = wave + (NT2 / 64) * u;
+        if (tile >= BPF_TILES(nin)) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = 256 * tile + 16 * (lane & 15) + 4 * (lane >> 4) + r;
+            if (i < nin) { const float2 y = cmul_nc(make_float2(re[u][r] * unsc, im[u][r] * unsc), cconj(cmul_nc(ph, ld2(tab->bpf_E, i)))); rxf[cons0 + i] = y; sh->xm[i] = y; }
+        }
     }
-    for (int i = tid; i < 102; i += NT2) { const float2 m = sh->xm[nin + i]; st->bpf.mem[i][0] = m.x; st->bpf.mem[i][1] = m.y; }
-    if (tid == 0) { S->bpf_phase = cmul(ph, ld2(tab->bpf_E, nin - 1)); S->bpf_grid = 0; }
+    __syncthreads();
+    if (tid < 102) { st->bpf.mem[tid][0] = memv.x; st->bpf.mem[tid][1] = memv.y; }
+    if (tid == 0) { S->bpf_phase = cmul_nc(ph, ld2(tab->bpf_E, nin - 1)); S->bpf_grid = 0; }
     __syncthreads();
 }
 
@@ -1241,11 +1326,12 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
         // block = the nin the invocation started with, then Nmf each: the reference's own call partition unless nin changes inside an invocation);
         // after such a timing slip the stream filters the rest of the invocation's samples itself (rx2_bpf_own: same arithmetic, cold path).
         float2 *rxf = (float2 *)a.rxf + (size_t)b * a.rxf_stride;
-        if (!(S->bpf_grid && nin == (calls0 ? RD_NMF : S->nin0))) { rx2_bpf_own(sh, a, b, rxf, cons0, nin, calls0); tid = rx2_tid(wv); }
+        const bool on_grid = S->bpf_grid && nin == (calls0 ? RD_NMF : S->nin0);
+        if (!on_grid) { rx2_bpf_own(sh, a, b, rxf, cons0, nin, calls0); tid = rx2_tid(wv); }
         constexpr int NNEW = (RD_NINMAX + NT2 - 1) / NT2;
         float2 nv[NNEW];
 #pragma unroll
-        for (int q = 0; q < NNEW; q++) { const int i = tid + q * NT2; nv[q] = i < nin ? rxf[cons0 + i] : make_float2(0.0f, 0.0f); }
+        for (int q = 0; q < NNEW; q++) { const int i = tid + q * NT2; nv[q] = i < nin ? (on_grid ? rxf[cons0 + i] : sh->xm[i]) : make_float2(0.0f, 0.0f); }
         if (state == ST_SYNC && !S->lds_sync) {      // pilot replicas and equaliser constants share LDS with the pilot search and the decoder stage
             for (int i = tid; i < RD_M; i += NT2) { sh->pd[i] = make_double2(tab->p[i][0], tab->p[i][1]); sh->pendd[i] = make_double2(tab->pend[i][0], tab->pend[i][1]); }
             if (tid < RD_NC) { sh->eqP[tid] = tab->P[tid]; sh->eqrot[tid] = make_float2(tab->eq_rot[tid][0], tab->eq_rot[tid][1]); }
@@ -1686,104 +1772,145 @@ extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, doubl
 }
 
 
+__device__ __forceinline__ rd_bpf_state *bpf_state_of(const rd_bpf_args &a, int b) { return (rd_bpf_state *)((char *)a.state + (size_t)b * a.state_stride); }
+__device__ __forceinline__ int bpf_len0_of(const rd_bpf_args &a, int b) { return a.len0 ? *(const int *)((const char *)a.len0 + (size_t)b * a.len0_stride) : a.len0_const; }
+__device__ __forceinline__ int bpf_avail_of(const rd_bpf_args &a, int b) { return a.avail ? a.avail[b] : a.avail_const; }
 // the block phases of an invocation, one thread per stream: P[0] = the phase the stream's last call left, P[k + 1] = P[k] E[len_k - 1] in complex64
 // as complex_bpf does from call to call; also resets the stream's off-grid flag (a new invocation starts on the grid)
-__global__ __launch_bounds__(64) void k_rx_bpf_chain(rd_rx_stream *st, const rd_tables *tab, const int *avail, float2 *chain, int chain_stride, int B)
+__global__ __launch_bounds__(64) void k_bpf_chain(rd_bpf_args a)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
-    rd_rx_stream *s = st + b;
-    float2 *c = chain + (size_t)b * chain_stride;
-    const int nin0 = s->nin, av = avail[b];
-    c[0] = make_float2(__int_as_float(nin0), __int_as_float(s->bpf.mem_len));
-    s->bpf.grid_off = 0;
-    float2 P = make_float2(s->bpf.phase[0], s->bpf.phase[1]);
-    int start = 0, len = nin0;
-    for (int k = 0; k + 1 < chain_stride; k++) {
+    if (b >= a.B) return;
+    rd_bpf_state *s = bpf_state_of(a, b);
+    float2 *c = (float2 *)a.chain + (size_t)b * a.chain_stride;
+    const int nin0 = bpf_len0_of(a, b), av = bpf_avail_of(a, b);
+    c[0] = make_float2(__int_as_float(nin0), __int_as_float(s->mem_len));
+    s->grid_off = 0;
+    float2 P = make_float2(s->phase[0], s->phase[1]);
+    // the two step factors in registers: a load inside the loop waits for the store before it as well (one counter, in order), i.e. a full
+    // memory round trip per block on a serial chain of ~100
+    const float2 e0 = ld2(a.tab->bpf_E, min(max(nin0, 1), RD_NEOO) - 1), e1 = ld2(a.tab->bpf_E, RD_NMF - 1);
+    int start = 0;
+    for (int k = 0; k + 1 < a.chain_stride; k++) {
         c[1 + k] = P;
         if (start >= av) break;                            // P of the first block beyond the input: the phase after the last whole call
-        P = cmul(P, ld2(tab->bpf_E, len - 1));
-        start += len; len = RD_NMF;
+        P = cmul_nc(P, k ? e1 : e0);
+        start += k ? RD_NMF : nin0;
     }
+}
+// baseband sample q >= 0 of an invocation: x[q] times the phase of its block
+__device__ __forceinline__ float2 bpf_baseband(const float2 *x, const float2 *chain, const rd_tables *tab, int nin0, int q)
+{
+    const int k = q < nin0 ? 0 : 1 + (q - nin0) / RD_NMF, sk = k ? nin0 + (k - 1) * RD_NMF : 0;
+    return cmul_nc(x[q], cmul_nc(chain[1 + k], ld2(tab->bpf_E, q - sk)));
+}
+// after a whole invocation was filtered and consumed (the transmit side: every sample is): the state complex_bpf would hold now (dsp.py:96-99)
+__global__ __launch_bounds__(128) void k_bpf_advance(rd_bpf_args a)
+{
+    const int b = blockIdx.x, tid = threadIdx.x;
+    rd_bpf_state *s = bpf_state_of(a, b);
+    const float2 *c = (const float2 *)a.chain + (size_t)b * a.chain_stride;
+    const int nin0 = __float_as_int(c[0].x), n = bpf_avail_of(a, b);
+    if (n < 102 || nin0 <= 0) return;                    // (blocks are whole modem / end-of-over frames)
+    const float2 *x = (const float2 *)a.x + (size_t)b * a.x_stride;
+    if (tid < 102) { const float2 m = bpf_baseband(x, c, a.tab, nin0, n - 102 + tid); s->mem[tid][0] = m.x; s->mem[tid][1] = m.y; }
+    if (tid == 0) { const int nb = n <= nin0 ? 1 : 1 + (n - nin0 + RD_NMF - 1) / RD_NMF; s->phase[0] = c[1 + nb].x; s->phase[1] = c[1 + nb].y; s->mem_len = 102; }
 }
 
-// complex_bpf.bpf for block blockIdx.x of stream blockIdx.y: [102 earlier baseband samples | the block mixed down] in LDS, five consecutive
-// outputs per thread over a sliding register window, mix up, store.  Plain v_fma_f32 in tap order (see DESIGN.md 3.7 on the packed form).
+// complex_bpf.bpf for BPF_BPW consecutive blocks of stream blockIdx.y: the window [102 earlier baseband samples | the block mixed down] staged as binary16
+// planes in LDS, one 256-output tile per wavefront on the matrix cores (bpf_fir_tile), mix up, store.  HBM-bound by design (8 bytes in, 8 out per
+// sample), so the loop is built around the memory system: the NEXT block's samples are requested before this block is staged (the round trip hides under
+// the staging, the matrix instructions and the stores), the block's last 102 baseband samples are handed to the next block through LDS (they are its
+// filter memory: nothing is read twice), and the phase-table entries a thread needs are the same for every block (loaded once).
 #define BPF_NT 256
-#define BPF_NO 5
-__global__ __launch_bounds__(BPF_NT) void k_rx_bpf(const rd_rx_stream *st, const rd_tables *tab, const float2 *rx, long rx_stride, const int *avail,
-                                                   const float2 *chain, int chain_stride, float2 *rxf, long rxf_stride)
+#define BPF_BPW 8
+__global__ __launch_bounds__(BPF_NT) void k_bpf_fir(rd_bpf_args a)
 {
-    static_assert(BPF_NT * BPF_NO >= RD_NINMAX, "a block is at most RD_NINMAX samples");
-    __shared__ __attribute__((aligned(16))) float2 xs[102 + BPF_NT * BPF_NO + 104];
-    __shared__ __attribute__((aligned(16))) float hs[RD_NTAP + 3];
-    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const rd_tables *tab = a.tab; const unsigned short *tab16 = a.bpf16;
+    const float2 *rx = (const float2 *)a.x; const long rx_stride = a.x_stride; float2 *rxf = (float2 *)a.y; const long rxf_stride = a.y_stride;
+    const float2 *chain = (const float2 *)a.chain; const int chain_stride = a.chain_stride;
+    __shared__ BpfLds pl;
+    __shared__ unsigned maxw;
+    __shared__ float2 tailbuf[102];
+    const int k0 = blockIdx.x * BPF_BPW, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float2 *c = chain + (size_t)b * chain_stride;
-    const int nin0 = __float_as_int(c[0].x), ml0 = __float_as_int(c[0].y), av = avail[b];
-    const int sk = k ? nin0 + (k - 1) * RD_NMF : 0, len = k ? RD_NMF : nin0;
-    if (sk >= av || nin0 <= 0) return;
-    const int n = min(len, av - sk);                       // (a partial last block is filtered too; no call will consume it)
+    // first round trip: the block grid's header, the first block's phases (their addresses do not depend on the header), the taps, the phase-table entries
+    const float2 hdr = c[0];
+    float2 Pk = c[1 + k0];
+    const float2 Pp = c[k0 ? k0 : 1];
+    const int av = bpf_avail_of(a, b);
+    BpfTaps taps; bpf_load_taps(taps, tab16, lane);
+    const int i0 = 16 * (lane & 15) + 4 * (lane >> 4);    // this lane's four outputs inside a tile
+    float2 eb[BPF_NQ], eo[4];
+#pragma unroll
+    for (int q = 0; q < BPF_NQ; q++) eb[q] = ld2(tab->bpf_E, min(tid + 256 * q, RD_NEOO - 1));
+#pragma unroll
+    for (int r = 0; r < 4; r++) eo[r] = ld2(tab->bpf_E, 256 * wave + i0 + r);
+    const int nin0 = __float_as_int(hdr.x), ml0 = __float_as_int(hdr.y);
+    if (nin0 <= 0) return;
+    int sk = k0 ? nin0 + (k0 - 1) * RD_NMF : 0;
+    if (sk >= av) return;
     const float2 *x = rx + (size_t)b * rx_stride;
-    const float2 Pk = c[1 + k];
-    const float2 Pp = k ? c[k] : Pk;
-    const int sp = k > 1 ? sk - RD_NMF : 0;                // start of the block before this one
-    const rd_rx_stream *s = st + b;
-    for (int i = tid; i < RD_NTAP; i += BPF_NT) hs[i] = tab->bpf_h[i];
-    for (int i = tid; i < 102 + BPF_NT * BPF_NO + 104; i += BPF_NT) {
-        float2 v = make_float2(0.0f, 0.0f);
-        if (i >= 102) { if (i - 102 < n) v = cmul(x[sk + i - 102], cmul(Pk, ld2(tab->bpf_E, i - 102))); }
-        else if (k) { const int q = sk - 102 + i; v = cmul(x[q], cmul(Pp, ld2(tab->bpf_E, q - sp))); }
-        else { const int mi = ml0 - 102 + i; if (mi >= 0) v = make_float2(s->bpf.mem[mi][0], s->bpf.mem[mi][1]); }
-        xs[i] = v;
+    const rd_bpf_state *s = bpf_state_of(a, b);
+    // second round trip: the first block's samples in one batch (clamped addresses, values dropped afterwards: no branch around a load), and its filter memory
+    int n = min(k0 ? RD_NMF : nin0, av - sk);              // (a partial last block is filtered too; no call will consume it)
+    float2 xb[BPF_NQ], head = make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int q = 0; q < BPF_NQ; q++) xb[q] = x[sk + min(tid + 256 * q, n - 1)];
+    if (tid < 102) {
+        if (k0) { const int sp = k0 > 1 ? sk - RD_NMF : 0, q = sk - 102 + tid; head = cmul_nc(x[q], cmul_nc(Pp, ld2(tab->bpf_E, q - sp))); }
+        else { const int mi = ml0 - 102 + tid; if (mi >= 0) head = make_float2(s->mem[mi][0], s->mem[mi][1]); }
     }
-    __syncthreads();
-    const int i0 = BPF_NO * tid;
-    if (i0 >= n) return;
-    const int o = (k == 0 && ml0 == 100) ? 2 : 0;          // before the first call the memory is two samples shorter (dsp.py:55)
-    const f32x2 *xw = (const f32x2 *)xs + i0 + o;
-    f32x2 acc[BPF_NO];
+    for (int kk = 0; kk < BPF_BPW; kk++) {
+        const int k = k0 + kk;
+        const int o = (k == 0 && ml0 == 100) ? 2 : 0;      // before the first call the memory is two samples shorter (dsp.py:55)
+        float2 body[BPF_NQ];
 #pragma unroll
-    for (int j = 0; j < BPF_NO; j++) acc[j] = (f32x2){ 0.0f, 0.0f };
-#pragma unroll 2
-    for (int kb = 0; kb < 96; kb += 8) {
-        f32x2 xv[8 + BPF_NO - 1]; float h[8];
+        for (int q = 0; q < BPF_NQ; q++) { body[q] = cmul_nc(xb[q], cmul_nc(Pk, eb[q])); if (tid + 256 * q >= n) body[q] = make_float2(0.0f, 0.0f); }
+        // the next block's samples and phase: in flight from here on
+        const int sk2 = sk + (k ? RD_NMF : nin0);
+        const bool more = kk + 1 < BPF_BPW && sk2 < av;    // uniform
+        const int n2 = more ? min(RD_NMF, av - sk2) : 1;
+        const float2 Pn = c[1 + k + (more ? 1 : 0)];
+        if (more) {
 #pragma unroll
-        for (int u = 0; u < 8 + BPF_NO - 1; u++) xv[u] = xw[kb + u];
-#pragma unroll
-        for (int u = 0; u < 8; u++) h[u] = hs[kb + u];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-#pragma unroll
-            for (int j = 0; j < BPF_NO; j++) { acc[j][0] = fmaf(xv[u + j][0], h[u], acc[j][0]); acc[j][1] = fmaf(xv[u + j][1], h[u], acc[j][1]); }
+            for (int q = 0; q < BPF_NQ; q++) xb[q] = x[sk2 + min(tid + 256 * q, n2 - 1)];
         }
-    }
-    {
-        f32x2 xv[5 + BPF_NO - 1]; float h[5];
+        const float unsc = bpf_stage_planes(&pl, &maxw, tid, head, body, o);
+        // this block's last 102 baseband samples are the next block's filter memory
 #pragma unroll
-        for (int u = 0; u < 5 + BPF_NO - 1; u++) xv[u] = xw[96 + u];
+        for (int q = 0; q < BPF_NQ; q++) { const int ti = tid + 256 * q - (n - 102); if (ti >= 0 && ti < 102) tailbuf[ti] = body[q]; }
+        float2 *dst = rxf + (size_t)b * rxf_stride + sk;
+        for (int tile = wave; tile < BPF_TILES(n); tile += BPF_NT / 64) {
+            f32x4 re, im;
+            bpf_fir_tile(&pl, taps, tile, lane, re, im);
 #pragma unroll
-        for (int u = 0; u < 5; u++) h[u] = hs[96 + u];
-#pragma unroll
-        for (int u = 0; u < 5; u++) {
-#pragma unroll
-            for (int j = 0; j < BPF_NO; j++) { acc[j][0] = fmaf(xv[u + j][0], h[u], acc[j][0]); acc[j][1] = fmaf(xv[u + j][1], h[u], acc[j][1]); }
+            for (int r = 0; r < 4; r++) {
+                const int i = 256 * tile + i0 + r;
+                const float2 e = tile == wave ? eo[r] : ld2(tab->bpf_E, min(i, RD_NEOO - 1));     // (a fifth tile only exists for blocks longer than 1024 samples)
+                if (i < n) {
+                    float2 y = cmul_nc(make_float2(re[r] * unsc, im[r] * unsc), cconj(cmul_nc(Pk, e)));
+                    if (a.clip) {                           // np.clip(abs(tx), 0, 1) * exp(1j * angle(tx)) (radae_txe.py:132): the phase kept, the magnitude limited to 1
+                        const float m2 = y.x * y.x + y.y * y.y;
+                        if (m2 > 1.0f) { const float inv = 1.0f / sqrtf(m2); y.x *= inv; y.y *= inv; }
+                    }
+                    dst[i] = y;
+                }
+            }
         }
-    }
-    float2 *dst = rxf + (size_t)b * rxf_stride + sk;
-#pragma unroll
-    for (int j = 0; j < BPF_NO; j++) {
-        const int i = i0 + j;
-        if (i < n) dst[i] = cmul(make_float2(acc[j][0], acc[j][1]), cconj(cmul(Pk, ld2(tab->bpf_E, i))));
+        if (!more) break;
+        __syncthreads();
+        if (tid < 102) head = tailbuf[tid];
+        sk = sk2; n = n2; Pk = Pn;
     }
 }
-// the two launches of the pre-pass; n_blocks = blocks of the longest stream (the host knows every stream's avail)
-extern "C" int rd_launch_rx_bpf(rd_rx_stream *st, const rd_tables *tab, const void *rx, long rx_stride, const int *avail, void *chain, int chain_stride,
-                                void *rxf, long rxf_stride, int n_blocks, int B, rd_stream_t s)
+// the launches of a filtering pass: block phases, the FIR over every block, and (transmit side) the state the filter is left in
+extern "C" int rd_launch_bpf(const rd_bpf_args *a, rd_stream_t s)
 {
-    if (B <= 0 || n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(k_rx_bpf_chain, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)s, st, tab, avail, (float2 *)chain, chain_stride, B);
-    hipLaunchKernelGGL(k_rx_bpf, dim3(n_blocks, B), dim3(BPF_NT), 0, (hipStream_t)s, (const rd_rx_stream *)st, tab, (const float2 *)rx, rx_stride, avail,
-                       (const float2 *)chain, chain_stride, (float2 *)rxf, rxf_stride);
+    if (a->B <= 0 || a->n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(k_bpf_chain, dim3((a->B + 63) / 64), dim3(64), 0, (hipStream_t)s, *a);
+    hipLaunchKernelGGL(k_bpf_fir, dim3((a->n_blocks + BPF_BPW - 1) / BPF_BPW, a->B), dim3(BPF_NT), 0, (hipStream_t)s, *a);
+    if (a->advance) hipLaunchKernelGGL(k_bpf_advance, dim3(a->B), dim3(128), 0, (hipStream_t)s, *a);
     return (int)hipGetLastError();
 }
 

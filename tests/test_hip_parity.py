@@ -196,6 +196,32 @@ def test_bpf_prepass_golden(Engine, torch_dev, golden):
     eng.close()
 
 
+def test_tx_bpf_and_clip_golden(Engine, torch_dev, golden, oracle, oracle_model):
+    """RADE_BATCH_TX_BPF = radae_tx(..., txbpf_en=True) (radae_txe.py:74-83, :130-132, :141-143; ctest radae_tx_basic): every frame and the end-of-over frame
+    through the Tx band-pass filter and the magnitude clip.  Against the reference's own output (tests/golden/txbpf.npz) and the oracle; six frames in one call
+    == six calls of one frame, bit for bit (the filter state is carried); two streams with different inputs stay independent."""
+    import torch
+    g = golden("txbpf")
+    n_mf = 6
+    f2 = np.stack([g["features"], g["features"][::-1].copy()])        # stream 1: another utterance (the same frames in reverse order)
+    eng = Engine(2, max_tx_mf=n_mf, flags=0x400)                      # RADE_BATCH_TX_BPF
+    iq = eng.tx(torch.tensor(f2, device=torch_dev)).cpu().numpy()
+    eoo = eng.tx_eoo().cpu().numpy()
+    assert np.abs(iq[0] - g["tx"]).max() < 2e-5 and rms(iq[0], g["tx"]) < 5e-6
+    assert np.abs(eoo[0] - g["eoo"]).max() < 2e-5
+    assert np.abs(iq).max() <= 1.0 + 1e-6 and np.abs(eoo).max() <= 1.0 + 1e-6
+    tx = oracle.Tx(oracle_model); tx.set_txbpf(True)
+    o1 = np.concatenate([tx.frame(f2[1, 12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+    assert np.abs(iq[1] - o1).max() < 2e-5 and np.abs(eoo[1] - tx.eoo()).max() < 2e-5
+    eng.tx_reset()
+    parts = [eng.tx(torch.tensor(f2[:, 12 * k:12 * k + 12].copy(), device=torch_dev)).cpu().numpy() for k in range(n_mf)]
+    assert np.array_equal(np.concatenate(parts, axis=1), iq) and np.array_equal(eng.tx_eoo().cpu().numpy(), eoo)
+    eng.close()
+    plain = Engine(2, max_tx_mf=n_mf)
+    assert rms(plain.tx(torch.tensor(f2, device=torch_dev)).cpu().numpy()[0], g["tx"]) > 1e-2      # the option is off by default
+    plain.close()
+
+
 def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden, monkeypatch):
     """One do_radae_rx call per invocation (the rade_rx() usage) == the whole stream at once."""
     import torch

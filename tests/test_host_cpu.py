@@ -133,7 +133,7 @@ def test_no_cpu_fallback(lib):
 class Tables(C.Structure):
     _fields_ = [("Winv", C.c_float * (30 * 160 * 2)), ("Wfwd", C.c_float * (160 * 30 * 2)), ("P", C.c_float * 30), ("Pend", C.c_float * 30),
                 ("p", C.c_float * 320), ("pend", C.c_float * 320), ("eoo", C.c_float * 2304), ("Pmat", C.c_float * 360), ("eq_rot", C.c_float * 60),
-                ("bpf_h", C.c_float * 104), ("bpf_E", C.c_float * 2240), ("p_w", C.c_float * 12800), ("fcoarse", C.c_double * 40),
+                ("bpf_h", C.c_float * 104), ("bpf_E", C.c_float * 2304), ("p_w", C.c_float * 12800), ("fcoarse", C.c_double * 40),
                 ("pilot_gain", C.c_float), ("snr_c1", C.c_float), ("snr_c2", C.c_float), ("pad", C.c_float)]
 
 
@@ -182,6 +182,32 @@ def test_demodulator_dft_matrix_as_matrix_core_operands(lib, golden):
     v1 = np.empty(320); v1[0::2] = x.imag; v1[1::2] = -x.real
     ref = x @ c["Wfwd"].astype(np.complex128)                     # sym[c] = sum_n x[n] Wfwd[n][c] (dsp.py:501)
     assert np.abs(((R @ v0)[:30] + 1j * (R @ v1)[:30]) - ref).max() < 3e-6 * np.abs(ref).max()
+
+
+def test_bandpass_taps_as_matrix_core_operands(lib, golden):
+    """rd_bpf16_table_fill: complex_bpf's 101 taps as the Toeplitz A operand of the matrix-core FIR (k_rx_bpf), two binary16 planes in the lane order of
+    v_mfma_f32_16x16x32_f16.  Un-permuted and applied (CPU, float64) to the Hankel matrix of a random window it must reproduce the direct FIR sums of
+    the reference's taps to the planes' 22 bits."""
+    c = golden("consts")
+    T = Tables()
+    lib.rd_tables_fill.argtypes = [C.POINTER(Tables)]; lib.rd_tables_fill(C.byref(T))
+    out = np.zeros(4 * 2 * 64 * 8, np.uint16)
+    lib.rd_bpf16_table_fill.argtypes = [C.POINTER(Tables), C.c_void_p]; lib.rd_bpf16_table_fill.restype = None
+    lib.rd_bpf16_table_fill(C.byref(T), out.ctypes.data_as(C.c_void_p))
+    tab = out.view(np.float16).astype(np.float64).reshape(4, 2, 64, 8)
+    Tm = np.zeros((16, 128))
+    for ks in range(4):
+        for lane in range(64):
+            Tm[lane & 15, 32 * ks + 8 * (lane >> 4):32 * ks + 8 * (lane >> 4) + 8] = (tab[ks, 0, lane] + tab[ks, 1, lane]) / 1024.0
+    h = c["bpf_h"].real.astype(np.float64)
+    for r in range(16):
+        assert np.abs(Tm[r, r:r + 101] - h).max() < 2.0 ** -22 * np.abs(h).max() and not Tm[r, :r].any() and not Tm[r, r + 101:].any()
+    rng = np.random.default_rng(6)
+    w = rng.standard_normal(256 + 127)
+    U = np.stack([w[16 * q:16 * q + 128] for q in range(16)], axis=1)          # U[m][q] = w[16 q + m]
+    Y = Tm @ U                                                                  # Y[r][q] = y[16 q + r]
+    ref = np.array([np.dot(h, w[i:i + 101]) for i in range(256)])
+    assert np.abs(Y.T.ravel() - ref).max() < 1e-6 * np.abs(ref).max()
 
 
 class Lin(C.Structure):

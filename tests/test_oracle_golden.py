@@ -38,6 +38,20 @@ def test_bpf_golden(oracle, golden):
     assert np.abs(y - g["y"]).max() < 2e-6 * np.abs(g["y"]).max() and rms(y, g["y"]) < 3e-7 * np.abs(g["y"]).max()
 
 
+def test_txbpf_golden(oracle, oracle_model, golden):
+    """radae_tx(..., txbpf_en=True) (radae_txe.py:74-83, :130-132, :141-143; ctest radae_tx_basic): six frames and the end-of-over frame through the Tx
+    band-pass filter and the magnitude clip (oracle/gen_golden_r4.py)."""
+    g = golden("txbpf")
+    tx = oracle.Tx(oracle_model); tx.set_txbpf(True)
+    out = np.concatenate([tx.frame(g["features"][12 * k:12 * k + 12].ravel())[0] for k in range(6)])
+    assert np.abs(out - g["tx"]).max() < 2e-5 and rms(out, g["tx"]) < 5e-6
+    assert np.abs(tx.eoo() - g["eoo"]).max() < 2e-5
+    assert np.abs(g["tx"]).max() <= 1.0 + 1e-6 and np.abs(out).max() <= 1.0 + 1e-6          # the clip
+    plain = oracle.Tx(oracle_model)
+    ref = np.concatenate([plain.frame(g["features"][12 * k:12 * k + 12].ravel())[0] for k in range(6)])
+    assert rms(out, ref) > 1e-2                                                            # (the option really changes the signal: 50-sample group delay)
+
+
 def test_blob_reader_matches_python_reader(oracle_model, golden):
     w = golden("weights_check")
     for k in w.files:
