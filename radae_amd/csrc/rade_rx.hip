@@ -40,6 +40,7 @@ struct RxScalars {
     uint32_t lcg;
     unsigned rxmax_cur, rxmax_h0, rxmax_h1;   // float bits of max |re|,|im| of the filtered samples of this call / the two calls before (check_pilots operand scale)
     int consumed_inv, calls_inv, valid_inv, eoo_inv, n_calls, n_rows, uw_from_row, consumed_round, pending_valid, out_base;
+    int tab_ok;               // refine()'s per-frequency constants for the CURRENT fmax are in LDS (left by the previous synchronised call's idle wavefront)
     int bpf_grid, nin0;       // the stream's calls still follow the block grid of the invocation's band-pass pre-pass (k_rx_bpf); the grid's first block length
     int entry;                // this candidate call enters sync (decided by thread 0 before a barrier: see do_entry)
     int go, need_decode, batch_call0, state_before, nin_before, valid_output, endofover, uw_fail, candidate, dt_valid, dt_new, lds_sync;
@@ -474,7 +475,10 @@ __device__ void dq2_layers(DecShared2 *sh, const rd_decs_args &a, int b, const f
             dq2_gemm_tiles<1>(sh, gc, wave, Tb, rstmask);
             if (!last) dq2_gemm_tiles<3>(sh, gm, 3 * wave, Tb, rstmask);
         } else if (last) dq2_gemm_tiles<3>(sh, gm, 3 * (wave - 2), Tb, rstmask);
-        else dq2_gemm_tiles<6>(sh, gm, 6 + 6 * (wave - 2), Tb, rstmask);
+        else {          // six projection tiles as two calls of three: with six tiles' fragments (4 k-steps x 6 x 4 registers) in flight the K loop spilled -- 20 scratch instructions per k-step
+            dq2_gemm_tiles<3>(sh, gm, 6 + 6 * (wave - 2), Tb, rstmask);
+            dq2_gemm_tiles<3>(sh, gm, 9 + 6 * (wave - 2), Tb, rstmask);
+        }
         __syncthreads();
         PH2(23);
         // fix-up: the conv's 32 new columns (one k-step) added onto the staged sums
@@ -1258,7 +1262,7 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
         S->bpf_phase = make_float2(st->bpf.phase[0], st->bpf.phase[1]);      // only used off the grid (rx2_bpf_own)
         S->consumed_inv = a.acc[b * 4 + 0]; S->calls_inv = a.acc[b * 4 + 1]; S->valid_inv = a.acc[b * 4 + 2]; S->eoo_inv = a.acc[b * 4 + 3];
         S->n_calls = 0; S->n_rows = 0; S->uw_from_row = 0; S->consumed_round = 0; S->pending_valid = 0; S->out_base = S->valid_inv;
-        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0;
+        S->go = 0; S->dt_valid = st->dt_valid; S->dt_new = 0; S->lds_sync = 0; S->need_decode = 0; S->batch_call0 = 0; S->tab_ok = 0;
         S->bpf_grid = st->bpf.grid_off == 0; S->nin0 = __float_as_int(((const float *)a.bpf_chain)[(size_t)b * a.chain_stride * 2]);
     }
     const int avail = a.avail[b];
@@ -1288,6 +1292,7 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
         if (S->need_decode) { rx2_decode_pending(sh, a, b); PH2(2); }
         if (!S->go) break;
         const int nin = S->nin, state = S->state;
+        if (tid == 0 && state != ST_SYNC) S->tab_ok = 0;
         const int mf0 = S->mf, n_rows0 = S->n_rows;
         auto state_update = [&](int entry, int valid_out, int eoo) {
             int next_state = state;
@@ -1427,7 +1432,7 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
                         // refine()'s grid, check_pilots' 48 row draws, and the first touch of the NEXT call's filtered samples (HBM + address translation:
                         // 256 streams read 256 separate regions; one load per 128-byte line, values dropped)
                         const int l = tid - (NT2 - 64);
-                        refine2_tables_sync(sh, l, fm - 1.0, fm + 1.0, 0.1);
+                        if (!S->tab_ok) refine2_tables_sync(sh, l, fm - 1.0, fm + 1.0, 0.1);      // (first synchronised call after sync entry: nobody prepared them)
                         const int k = min(l, 47);
                         const uint32_t x = LCG_A[k] * S->lcg + LCG_C[k];
                         if (l < 48) sh->rows48[k] = (int)((x >> 8) % RD_NMF);
@@ -1604,6 +1609,13 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
 #pragma unroll
                         for (int rr = 0; rr < 4; rr++) { const int c = 16 * tile + 4 * g + rr; if (c < RD_NC) dst[2 * c] = r[rr]; }
                     }
+                } else if (wave == 2) {
+                    // the third wavefront has no part in this phase: it prepares the NEXT call's refine() constants (one double-precision sincos per lane: 4 k cycles
+                    // that every wavefront waited for at refine()'s first barrier when they were computed at the top of the call).  fmax is final for this call
+                    // (refine() is done, the state machine does not touch it); a call that is not synchronised, or a sync entry, clears the flag.
+                    const double fm = S->fmax;
+                    refine2_tables_sync(sh, lane, fm - 1.0, fm + 1.0, 0.1);
+                    if (lane == 0) S->tab_ok = 1;
                 }
             }
             PH2(25);
