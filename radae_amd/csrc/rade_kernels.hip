@@ -661,6 +661,8 @@ __global__ __launch_bounds__(192) void k_ofdm_mod_mp(const rd_tables *tab, const
     __syncthreads();
     const size_t base = (size_t)mf * RD_NMF;
     const f32x4 *Gb = (const f32x4 *)G + (size_t)b * n_mf * RD_NMF;      // (G1[i], G2[i]) as one 16-byte load per sample
+    // (requesting these before the IDFT instead -- 20 more registers live across it -- made the kernel 5 % slower: 187 -> 196 us; the IDFT and the
+    // limiter, not the round trip, are what a workgroup spends its time on)
     float2 *mpo = mp + (size_t)b * n_mf * RD_NMF + base;
     float2 *txo = tx ? tx + (size_t)b * tx_stride + base : nullptr;
     // second path: c2[i + 16] = tx[i] G2[i], written to LDS by the thread that holds G2[i]; the first 16 slots of the frame come from the
@@ -784,11 +786,12 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 __device__ __forceinline__ float2 gauss_pair(uint32_t u0, uint32_t u1)
-{   // Box-Muller, unit variance per component
+{   // Box-Muller, unit variance per component, on the hardware log2 / sqrt / sin / cos units (v_sin_f32 and v_cos_f32 take their argument in
+    // revolutions: exactly what the second uniform is): this generator only feeds the device-noise path (seed != 0: benchmark and
+    // statistics runs; parity tests pass an explicit noise tensor), where the libm versions were most of k_chan_apply's instructions
     const float a = ((float)u0 + 0.5f) * (1.0f / 4294967296.0f), bq = ((float)u1 + 0.5f) * (1.0f / 4294967296.0f);
-    const float rad = sqrtf(-2.0f * logf(a));
-    float sn, cs; sincosf(6.28318530718f * bq, &sn, &cs);
-    return make_float2(rad * cs, rad * sn);
+    const float rad = __builtin_amdgcn_sqrtf(-1.38629436112f * __builtin_amdgcn_logf(a));       // -2 ln a = -2 ln 2 log2 a
+    return make_float2(rad * __builtin_amdgcn_cosf(bq), rad * __builtin_amdgcn_sinf(bq));
 }
 
 __device__ __forceinline__ double chan_phase_acc(int i, float f0, float df_dt)
