@@ -34,6 +34,7 @@ struct rade {
      * [features H2D, encoder + modulator kernels, samples D2H] is captured once and replayed as a hipGraph */
     hipStream_t gs; hipGraphExec_t tx_graph; int tx_calls, tx_graph_off;
     float *h_feat; RADE_COMP *h_iq;          /* pinned staging buffers the graph copies from / to */
+    void *txc;                               /* rade_tx as ONE launch per frame (rade_core.c: rd_core_tx_*); NULL: the batched engine's launch sequence above */
 };
 
 void rade_initialize(void) { /* reference: Py_InitializeEx (rade_api.c:329-332); HIP initialises lazily */ }
@@ -76,6 +77,15 @@ struct rade *rade_open(char model_file[], int flags)
     r->eng = rade_batch_open(path, &cfg);
     if (!r->eng) { free(r); return NULL; }
     r->flags = flags; r->nin = RD_NMF; r->device = cfg.device;
+    if (!rd_batch_has_tx_bpf(r->eng)) {      /* (the Tx band-pass option filters between modulator and output: that path stays on the engine) */
+        FILE *f = fopen(path, "rb");
+        if (f) {
+            fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+            void *blob = n > 0 ? malloc((size_t)n) : NULL;
+            if (blob && fread(blob, 1, (size_t)n, f) == (size_t)n) r->txc = rd_core_tx_open(blob, (int)n, rd_batch_tables(r->eng));
+            free(blob); fclose(f);
+        }
+    }
     if (hipMalloc((void **)&r->d_feat_in, sizeof(float) * RD_FEAT_MF) || hipMalloc((void **)&r->d_feat_out, sizeof(float) * RD_FEAT_MF) ||
         hipMalloc((void **)&r->d_eoo, sizeof(float) * RD_NEOOBITS) || hipMalloc(&r->d_iq, sizeof(RADE_COMP) * RD_NEOO) ||
         hipMalloc(&r->d_rx, sizeof(RADE_COMP) * RD_NINMAX)) { rade_close(r); return NULL; }
@@ -90,6 +100,7 @@ struct rade *rade_open(char model_file[], int flags)
 void rade_close(struct rade *r)
 {
     if (!r) return;
+    if (r->txc) rd_core_tx_close(r->txc);
     if (r->tx_graph) hipGraphExecDestroy(r->tx_graph);
     if (r->h_feat) hipHostFree(r->h_feat);
     if (r->h_iq) hipHostFree(r->h_iq);
@@ -123,7 +134,8 @@ int rade_tx(struct rade *r, RADE_COMP tx_out[], float features_in[])
     int ret = 0;
     pthread_mutex_lock(&r->lock);
     (void)hipSetDevice(r->device);          /* any thread may call; the staging copies below must target the engine's device */
-    if (r->tx_calls > 0 && !r->tx_graph_off && r->gs && r->h_feat && r->h_iq) {
+    if (r->txc) { if (rd_core_tx_frame(r->txc, features_in, (float *)tx_out) == 0) ret = RD_NMF; }
+    else if (r->tx_calls > 0 && !r->tx_graph_off && r->gs && r->h_feat && r->h_iq) {
         if (!r->tx_graph) {                                   /* second call: record the sequence (nothing runs during capture) */
             hipGraph_t g = NULL;
             int ok = hipStreamBeginCapture(r->gs, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -144,7 +156,7 @@ int rade_tx(struct rade *r, RADE_COMP tx_out[], float features_in[])
             }
         }
     }
-    if (!ret && hipMemcpy(r->d_feat_in, features_in, sizeof(float) * RD_FEAT_MF, hipMemcpyHostToDevice) == hipSuccess &&
+    if (!ret && !r->txc && hipMemcpy(r->d_feat_in, features_in, sizeof(float) * RD_FEAT_MF, hipMemcpyHostToDevice) == hipSuccess &&
         rade_batch_tx(r->eng, r->d_feat_in, 1, r->d_iq, RD_NMF, NULL, NULL) == RD_NMF &&
         hipMemcpy(tx_out, r->d_iq, sizeof(RADE_COMP) * RD_NMF, hipMemcpyDeviceToHost) == hipSuccess) ret = RD_NMF;
     r->tx_calls++;

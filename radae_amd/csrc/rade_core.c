@@ -247,6 +247,72 @@ static core_dev *dev_open(const void *blob, int len, int dim, int enc)
     return d;
 }
 
+/* ---- internal (rade_api.c): rade_tx() on the single-stream kernels -- one launch per modem frame (k_tx_frame: three encoder steps + the OFDM
+ * modulator), features and samples in pinned host memory the kernel reads / writes directly, completion by a polled word ------------------------- */
+typedef struct { core_dev *d; float *h_in, *h_iq; unsigned *done; rd_core_args *a_dev; } tx_dev;
+void rd_core_tx_close(void *p)
+{
+    tx_dev *t = p;
+    if (!t) return;
+    if (t->h_in) hipHostFree(t->h_in);
+    if (t->h_iq) hipHostFree(t->h_iq);
+    if (t->a_dev) hipFree(t->a_dev);
+    if (t->d) dev_close(t->d);
+    free(t);
+}
+void *rd_core_tx_open(const void *blob, int len, const rd_tables *d_tab)
+{
+    if (getenv("RADE_CORE_LAYERWISE") || getenv("RADE_TX_LAYERWISE")) return NULL;
+    tx_dev *t = calloc(1, sizeof *t);
+    if (!t) return NULL;
+    t->d = dev_open(blob, len, 84, 1);
+    if (!t->d || hipHostMalloc((void **)&t->h_in, sizeof(float) * 3 * 84, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&t->h_iq, sizeof(float) * 2 * RD_NMF + 64, hipHostMallocMapped) != hipSuccess) { rd_core_tx_close(t); (void)hipGetLastError(); return NULL; }
+    rd_core_args *a = &t->d->a;
+    void *dp = NULL;
+    if (hipHostGetDevicePointer(&dp, t->h_in, 0) != hipSuccess) { rd_core_tx_close(t); return NULL; }
+    a->in = dp;
+    if (hipHostGetDevicePointer(&dp, t->h_iq, 0) != hipSuccess) { rd_core_tx_close(t); return NULL; }
+    a->iq_out = dp; a->tab = d_tab;
+    t->done = (unsigned *)(t->h_iq + 2 * RD_NMF); *t->done = 0;
+    a->done = (unsigned *)((float *)dp + 2 * RD_NMF);
+    /* the kernel reads the layer table through a pointer: the record goes to device memory once (every pointer in it is fixed from here on) */
+    if (hipMalloc((void **)&t->a_dev, sizeof *a) != hipSuccess || hipMemcpy(t->a_dev, a, sizeof *a, hipMemcpyHostToDevice) != hipSuccess) { rd_core_tx_close(t); return NULL; }
+    return t;
+}
+void rd_core_tx_reset(void *p)
+{
+    tx_dev *t = p; core_dev *d = t->d;
+    (void)hipSetDevice(d->device);
+    (void)hipMemsetAsync(d->a.hist, 0, sizeof(float) * 2 * d->a.W, d->gs);
+    (void)hipMemsetAsync(d->a.h, 0, sizeof(float) * 5 * d->a.H, d->gs);
+    (void)hipStreamSynchronize(d->gs);
+}
+/* features_in: 12 frames x 36 floats (rade_api.c:426-434 packs the first 20 of each + the aux symbol -1 into three rows of 4 x 21); tx_out: 960 complex samples */
+int rd_core_tx_frame(void *p, const float *features_in, float *tx_out)
+{
+    tx_dev *t = p; core_dev *d = t->d;
+    if (hipSetDevice(d->device) != hipSuccess) return -1;
+    for (int c = 0; c < 3; c++)
+        for (int i = 0; i < 4; i++) {
+            memcpy(t->h_in + c * 84 + i * 21, features_in + (c * 4 + i) * 36, sizeof(float) * 20);
+            t->h_in[c * 84 + i * 21 + 20] = -1.0f;
+        }
+    volatile unsigned *done = (volatile unsigned *)t->done;
+    d->a.seq++;
+    if (rd_launch_tx_frame(t->a_dev, d->a.seq, d->gs)) return -1;
+    struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; *done != d->a.seq; spins++) {
+        if ((spins & 1023u) == 1023u) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 20.0) { if (hipStreamSynchronize(d->gs) != hipSuccess || *done != d->a.seq) return -1; break; }
+        }
+    }
+    __sync_synchronize();
+    memcpy(tx_out, t->h_iq, sizeof(float) * 2 * RD_NMF);
+    return 0;
+}
+
 void rade_init_encoder(RADEEncState *s) { memset(s, 0, sizeof *s); }     /* rade_enc.c:39-43: the caller's memory may be uninitialised */
 void rade_init_decoder(RADEDecState *s) { memset(s, 0, sizeof *s); }
 void rade_free_encoder(RADEEncState *s) { if (s && s->initialized) dev_close(s->dev); if (s) memset(s, 0, sizeof *s); }

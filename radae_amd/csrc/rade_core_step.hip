@@ -17,10 +17,7 @@
 #include <stdint.h>
 #include <math.h>
 
-#include "rade_dev.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#include "rade_devutil.h"
 
 #define CS_THREADS 512
 #define CS_WAVES (CS_THREADS / 64)
@@ -147,6 +144,7 @@ __device__ __forceinline__ void cs_enc_layer(CsShared *sh, const rd_core_args &a
     if (tid < H) {
         const float hn = cs_gru_unit(a.gin[l], sh->pa, sh->gh, sh->h[l][tid], H, tid);
         a.h[l * H + tid] = hn;
+        sh->h[l][tid] = hn;                                          // (this layer's W_hh h was formed a stage ago: nobody reads the old value any more)
         sh->x[n + tid] = cs_clamp1(hn);
     }
     CS_SYNC();
@@ -159,16 +157,18 @@ __device__ __forceinline__ void cs_enc_layer(CsShared *sh, const rd_core_args &a
     CS_SYNC();
 }
 
-__global__ __launch_bounds__(CS_THREADS) void k_core_enc_step(rd_core_args a)
+// one encoder step; FIRST: conv history and GRU states come from HBM (else they are in LDS, left there by the step before); LASTSTEP: they go back.
+// in: the step's n_in inputs; zout: its 80 latents (any address space the workgroup can write)
+__device__ __forceinline__ void cs_enc_step(CsShared *sh, const rd_core_args &a, const float *in, float *zout, const bool FIRST, const bool LASTSTEP)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
-    CsShared *sh = (CsShared *)cs_raw;
     const int tid = threadIdx.x, W = 864, H = 64;
     WQ<3, 1> g0, h0;
     cs_issue<3, 1>(a.gin[0], g0); cs_issue<3, 1>(a.ghh[0], h0);
-    for (int i = tid; i < 2 * W; i += CS_THREADS) sh->hist[i / W][i % W] = a.hist[i];
-    if (tid < 96) sh->vin[tid] = tid < a.n_in ? a.in[tid] : 0.0f;
-    if (tid < 5 * H) sh->h[tid / H][tid % H] = a.h[tid];
+    if (FIRST) {
+        for (int i = tid; i < 2 * W; i += CS_THREADS) sh->hist[i / W][i % W] = a.hist[i];
+        if (tid < 5 * H) sh->h[tid / H][tid % H] = a.h[tid];
+    }
+    if (tid < 96) sh->vin[tid] = tid < a.n_in ? in[tid] : 0.0f;
     CS_SYNC();
     cs_f32_product<2>(a.dense1, 1, sh->vin, sh->pa);                // dense1 + tanh (radae_base.py:263)
     cs_consume<3, 1>(a.ghh[0], h0, sh->h[0], H, sh->h[0], sh->pb);
@@ -183,9 +183,28 @@ __global__ __launch_bounds__(CS_THREADS) void k_core_enc_step(rd_core_args a)
     cs_enc_layer<9, 19, 11, false>(sh, a, 3, 544, g3, g4);
     cs_enc_layer<11, 24, 11, true>(sh, a, 4, 704, g4, g4);
     cs_f32_product<14>(a.out, 2, sh->x, sh->pa);                    // z_dense, linear (bottleneck 3; the tanh of bottleneck 1 is the caller's)
-    for (int i = tid; i < W; i += CS_THREADS) { a.hist[W + i] = sh->hist[0][i]; a.hist[i] = sh->x[i]; }      // history of the next step
+    if (LASTSTEP) { for (int i = tid; i < W; i += CS_THREADS) { a.hist[W + i] = sh->hist[0][i]; a.hist[i] = sh->x[i]; } }      // history of the next step
     CS_SYNC();
-    if (tid < a.n_out) { a.out_vec[tid] = cs_row(a.out, sh->pa, tid); __threadfence_system(); }
+    if (tid < a.n_out) zout[tid] = cs_row(a.out, sh->pa, tid);
+    if (!LASTSTEP) { for (int i = tid; i < W; i += CS_THREADS) { const float v = sh->hist[0][i]; sh->hist[1][i] = v; sh->hist[0][i] = sh->x[i]; } }   // (each thread moves its own columns)
+    CS_SYNC();
+}
+
+// the same step as a REAL function for k_tx_frame's loop (one copy of the code with its own register allocation; inlined into the loop the
+// three steps' weight prefetches overlapped and 400 registers spilled).  The layer table is read through a pointer to device memory: a by-value
+// struct handed to a real function would live in scratch memory.
+__device__ __attribute__((noinline)) void cs_enc_step_fn(CsShared *sh, const rd_core_args *ap, int st, float *zs)
+{
+    cs_enc_step(sh, *ap, ap->in + st * ap->n_in, zs + st * RD_LATENT, st == 0, st == 2);
+}
+
+__global__ __launch_bounds__(CS_THREADS) void k_core_enc_step(rd_core_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
+    CsShared *sh = (CsShared *)cs_raw;
+    const int tid = threadIdx.x;
+    cs_enc_step(sh, a, a.in, a.out_vec, true, true);
+    if (tid < a.n_out) __threadfence_system();
     CS_SYNC();
     // completion word in the caller's (pinned host) memory: the host polls it instead of going through a stream synchronisation,
     // whose interrupt / wake-up path costs more than this whole kernel
@@ -252,6 +271,54 @@ __global__ __launch_bounds__(CS_THREADS) void k_core_dec_step(rd_core_args a)
     // completion word in the caller's (pinned host) memory: the host polls it instead of going through a stream synchronisation,
     // whose interrupt / wake-up path costs more than this whole kernel
     if (tid == 0 && a.done) { __threadfence_system(); *(volatile unsigned *)a.done = a.seq; }
+}
+
+// ---- rade_tx() as ONE launch: the three encoder steps of a modem frame (state in LDS between them) and the OFDM modulator (dsp.py:340-378:
+// pilot row + four data rows, 30 -> 160 IDFT, cyclic prefix, tanh limiter) in the same workgroup; a.in = 3 x 84 packed features, a.iq_out = 960
+// complex samples (both pinned host memory the kernel reads / writes directly), then the completion word.  (The reference's rade_tx runs the
+// same sequence through CPython: rade_api.c:403-445, radae_txe.py:108-135.)
+__global__ __launch_bounds__(CS_THREADS) void k_tx_frame(const rd_core_args *ap, unsigned seq)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs_raw[];
+    CsShared *sh = (CsShared *)cs_raw;
+    __shared__ float zs[RD_ZMF];
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int st = 0; st < 3; st++) cs_enc_step_fn(sh, ap, st, zs);
+    const rd_tables *tab = ap->tab;
+    float2 *out = (float2 *)ap->iq_out;
+    if (tid < RD_M) {
+        float2 acc[RD_NS + 1];
+#pragma unroll
+        for (int s = 0; s <= RD_NS; s++) acc[s] = make_float2(0.0f, 0.0f);
+#pragma unroll 6
+        for (int c = 0; c < RD_NC; c++) {
+            const float2 w = ld2(tab->Winv[c], tid);
+            acc[0] = cadd(acc[0], cmul(make_float2(tab->P[c] * tab->pilot_gain, 0.0f * tab->pilot_gain), w));
+#pragma unroll
+            for (int s = 1; s <= RD_NS; s++) { const int k = (s - 1) * RD_NC + c; acc[s] = cadd(acc[s], cmul(make_float2(zs[2 * k], zs[2 * k + 1]), w)); }
+        }
+#pragma unroll
+        for (int s = 0; s <= RD_NS; s++) {
+            const float mag = hypotf(acc[s].x, acc[s].y);
+            float2 v = make_float2(0.0f, 0.0f);
+            if (mag != 0.0f) { const float g = tanhf(mag) / mag; v = make_float2(acc[s].x * g, acc[s].y * g); }      // tanh(|x|) e^{j angle(x)} (radae.py:218, dsp.py:377)
+            out[s * RD_SYM + RD_NCP + tid] = v;
+            if (tid >= RD_M - RD_NCP) out[s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
+        }
+        __threadfence_system();
+    }
+    CS_SYNC();
+    if (tid == 0 && ap->done) { __threadfence_system(); *(volatile unsigned *)ap->done = seq; }
+}
+/* a_dev: the rd_core_args record in DEVICE memory (written once by the caller: every pointer in it is fixed for the life of the state) */
+extern "C" int rd_launch_tx_frame(const rd_core_args *a_dev, unsigned seq, rd_stream_t s)
+{
+    static int attr_dev[64];
+    int dev_ = 0; (void)hipGetDevice(&dev_);
+    if (!attr_dev[dev_ & 63]) { (void)hipFuncSetAttribute((const void *)k_tx_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsShared)); attr_dev[dev_ & 63] = 1; }
+    hipLaunchKernelGGL(k_tx_frame, dim3(1), dim3(CS_THREADS), sizeof(CsShared), (hipStream_t)s, a_dev, seq);
+    return (int)hipGetLastError();
 }
 
 extern "C" int rd_launch_core_step(const rd_core_args *a, rd_stream_t s)

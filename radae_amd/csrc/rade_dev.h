@@ -242,8 +242,11 @@ typedef struct {
     float *h;                          /* [5][H] GRU states */
     const float *in; float *out_vec;   /* device-visible buffers (pinned host memory in rade_core.c) */
     unsigned *done; unsigned seq;      /* optional completion word (device-visible host memory): set to seq after out_vec is written */
+    const rd_tables *tab; float *iq_out;   /* rd_launch_tx_frame only: the constant tables and the 960 complex output samples (device-visible) */
 } rd_core_args;
 int rd_launch_core_step(const rd_core_args *a, rd_stream_t s);
+/* a whole modem frame of the transmitter in one launch: in = 3 x n_in packed feature rows -> three encoder steps -> OFDM modulator -> iq_out[960] */
+int rd_launch_tx_frame(const rd_core_args *a_dev /* the record in DEVICE memory */, unsigned seq, rd_stream_t s);
 
 
 #ifdef __cplusplus

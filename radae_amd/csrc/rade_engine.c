@@ -404,6 +404,8 @@ void rade_batch_close(rade_batch *h)
 }
 
 int rade_batch_n_streams(const rade_batch *h) { return h->B; }
+const rd_tables *rd_batch_tables(const rade_batch *h) { return h->d_tab; }
+int rd_batch_has_tx_bpf(const rade_batch *h) { return h->tx_bpf != NULL; }
 
 /* ---- per-kernel-class timing (HIP events on the launch stream) -------------------------------- */
 /* Events are only recorded while the work is queued and read back afterwards (prof_drain): a profiled step runs back to

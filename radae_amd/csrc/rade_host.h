@@ -45,4 +45,14 @@ long rd_pack_weights_f16x2_a16(const float *W, int N, int K, unsigned short *out
 #ifdef __cplusplus
 }
 #endif
+/* rade_core.c, for rade_api.c: rade_tx() as one launch per modem frame (NULL from open: fall back to the batched engine) */
+void *rd_core_tx_open(const void *blob, int len, const rd_tables *d_tab);
+void rd_core_tx_close(void *t);
+void rd_core_tx_reset(void *t);
+int rd_core_tx_frame(void *t, const float *features_in, float *tx_out);
+/* rade_engine.c: the engine's constant tables on its device */
+struct rade_batch;
+const rd_tables *rd_batch_tables(const struct rade_batch *h);
+int rd_batch_has_tx_bpf(const struct rade_batch *h);
+
 #endif
