@@ -1,14 +1,9 @@
 #!/bin/bash
-# developer aid (gpurun): A/B of two builds of the library on the per-stream cycle counts of the receiver launch (mean over streams is
-# free of the tail noise a kernel duration carries).  ab/base.so = the build to compare against (tools/ab_build_base.sh <rev>).
-cd ${GRAFT_REPO_ROOT:-/root/repo}
-summ() { python -c "
+# developer aid, runs on the GPU box: mean per-stream cycles of the receiver launch (tools/stream_cycles.py) for each library in turn, N rounds
+N=$1; shift; R=${GRAFT_REPO_ROOT:-/root/repo}
+for r in $(seq 1 $N); do for L in "$@"; do
+  RADE_LIBRADEHIP=$R/$L python $R/tools/stream_cycles.py 2>/dev/null | python -c "
 import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])['seeds']
-print('$1', ' '.join(f\"seed{k}: mean {v['cycles_mean']/1e6:.3f}M max {v['cycles_max']/1e6:.3f}M ms {v['kernel_ms']:.3f} search {v['cycles_per_search_call_fit']/1e3:.1f}k sync {v['cycles_per_sync_call_fit']/1e3:.1f}k |\" for k,v in d.items()))"; }
-python tools/stream_cycles.py 2>/dev/null | summ new
-if [ -f ab/base.so ]; then
-  cp radae_amd/libradehip.so /tmp/new.so; cp ab/base.so radae_amd/libradehip.so
-  python tools/stream_cycles.py 2>/dev/null | summ base
-  cp /tmp/new.so radae_amd/libradehip.so
-fi
+c=json.load(sys.stdin); v=c['seeds']['1']
+print('$L', 'round $r', 'mean cycles', round(v['cycles_mean']), 'search call', round(v['cycles_per_search_call_fit']), 'sync call', round(v['cycles_per_sync_call_fit']), 'ms', round(v['kernel_ms'],3))"
+done; done

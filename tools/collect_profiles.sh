@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats of the bench command + separate PMC passes (never combined with
 # trace domains other than --kernel-trace).  Outputs land in gpurun_out/prof_$TAG/ and are summarised into profiles/ by
 # tools/make_profile_summary.py (run it afterwards in the repo).  Usage: bash tools/collect_profiles.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
@@ -24,24 +24,22 @@ pass write WRITE_SIZE
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 pass sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA
 pass l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-# 3b. the other configurations and variants (plain lines, no profiler): configs[1] alone, the two-streams-per-CU receiver at 2 and 3 batches in flight,
-#     configs 1 and 5 rates, rocprofv3 stats of the single-stream step kernels
+# 3b. the other configurations and variants (plain lines, no profiler): configs[1] alone, other pipeline depths, the two-call channel, configs 1 and 5 rates,
+#     the C host, the single-stream ABI, rocprofv3 stats of the single-stream step kernels
 python $R/bench.py --config 2 > $O/bench_config2.json 2> $O/bench_config2.err
-for p in 2 3; do python $R/bench.py --steps 60 --rx-kernel 1 --pipeline $p --no-cpu-baseline > $O/bench_rx1_p$p.json 2> /dev/null; done      # the one-stream-per-CU receiver (round 2's configuration at p = 2)
-python $R/bench.py --steps 60 --pipeline 2 --no-cpu-baseline > $O/bench_rx2_p2.json 2> /dev/null
-python $R/bench.py --steps 60 --two-pass-channel --no-cpu-baseline > $O/bench_two_pass_channel.json 2> /dev/null
-python $R/tools/rx2_stress.py > $O/rx2_stress.json 2> /dev/null
+for p in 1 2 4; do python $R/bench.py --steps 60 --pipeline $p --no-cpu-baseline --no-parity --no-roofline > $O/bench_p$p.json 2> /dev/null; done
+python $R/bench.py --steps 60 --two-pass-channel --no-cpu-baseline --no-parity --no-roofline > $O/bench_two_pass_channel.json 2> /dev/null
 python $R/tools/config_rates.py > $O/config_rates.txt 2>&1; cp $R/gpurun_out/config_rates.json $O/ 2>/dev/null
+(cd $R && ./hosts/rade_multi_bench --gpus 1 --steps 30 > $O/c_host_pipeline3.json 2> /dev/null)
+python $R/tools/single_stream_latency.py > $O/single_stream_latency.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python $R/bench.py --config 2 > /dev/null 2> $O/stats_c2.err
-RADE_RX_VARIANT=2 python $R/tools/stream_cycles.py > $O/stream_cycles_rx2.json 2> /dev/null
-RADE_RX_VARIANT=1 python $R/tools/stream_cycles.py > $O/stream_cycles_rx1.json 2> /dev/null
-# 4. per-stream duration of the receiver launch (tail analysis) and the receiver's traffic by source
-RADE_RX_VARIANT=2 python $R/tools/stream_cycles.py > $O/stream_cycles.json 2> $O/stream_cycles.err
+# 4. per-stream duration of the receiver launch (tail analysis)
+python $R/tools/stream_cycles.py > $O/stream_cycles.json 2> $O/stream_cycles.err
 # 5. developer-build runs (built here beforehand: tools/ab_build.sh census -DRX2_CENSUS ; tools/ab_build.sh timing -DRD_PHASE_TIMING): the per-phase
 #    instruction census of k_rx_sync2, its stall / LDS / instruction-cache counters at one and two workgroups per CU, and the per-phase cycle table
-if [ -f $R/gpu_ab/census.so ]; then bash $R/tools/rx2_census.sh > $O/rx2_census.txt 2>&1; cp $R/gpurun_out/census/census.json $O/rx2_census.json 2>/dev/null; fi
+if [ -f $R/abso/census.so ]; then bash $R/tools/rx2_census.sh > $O/rx2_census.txt 2>&1; cp $R/gpurun_out/census/census.json $O/rx2_census.json 2>/dev/null; fi
 bash $R/tools/rx2_counters.sh 2 > $O/rx2_counters.txt 2>&1; cp $R/gpurun_out/rxcnt/counters.json $O/rx2_counters.json 2>/dev/null
 cd /tmp
-if [ -f $R/gpu_ab/timing.so ]; then RADE_RX_VARIANT=2 RADE_LIBRADEHIP=$R/gpu_ab/timing.so python $R/tools/phase_timing2.py > $O/phase_timing_rx2.txt 2>/dev/null; fi
+if [ -f $R/abso/timing.so ]; then RADE_LIBRADEHIP=$R/abso/timing.so python $R/tools/phase_timing2.py > $O/phase_timing_rx2.txt 2>/dev/null; fi
 find $O -name "*.csv" | head -30
 tail -c 400 $O/bench_line.json

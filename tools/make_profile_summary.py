@@ -3,7 +3,7 @@
 <tag>_bench_kernel_stats.csv, <tag>_bench_line.json, <tag>_bench_under_rocprof.json, <tag>_pmc_per_kernel.txt, <tag>_pmc_summary.json,
 <tag>_stream_cycles.json.  Usage: python tools/make_profile_summary.py [tag]"""
 import csv, glob, json, os, shutil, subprocess, sys, collections
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(R, "gpurun_out", "prof_" + tag); dst = os.path.join(R, "profiles")
 shutil.copy(glob.glob(os.path.join(src, "stats", "**", "bench_kernel_stats.csv"), recursive=True)[0], os.path.join(dst, tag + "_bench_kernel_stats.csv"))
@@ -12,7 +12,7 @@ if pp: shutil.copy(pp[0], os.path.join(dst, tag + "_bench_pipelined_kernel_stats
 pc = glob.glob(os.path.join(src, "stats_c2", "**", "c2_kernel_stats.csv"), recursive=True)
 if pc: shutil.copy(pc[0], os.path.join(dst, tag + "_config2_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "config_rates.json")): shutil.copy(os.path.join(src, "config_rates.json"), os.path.join(dst, tag + "_config_rates.json"))
-for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles", "bench_config2", "bench_rx2_p2", "bench_rx1_p2", "bench_rx1_p3", "bench_two_pass_channel", "stream_cycles_rx2", "stream_cycles_rx1", "rx2_stress"):
+for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles", "bench_config2", "bench_p1", "bench_p2", "bench_p4", "bench_two_pass_channel", "c_host_pipeline3", "single_stream_latency"):
     if not os.path.exists(os.path.join(src, name + ".json")): continue
     line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
@@ -62,25 +62,34 @@ for k in mf:
         sh = {kk: (round(v, 4) if v is not None else None) for kk, v in sh.items()}
         sh["bound"] = ("latency (s_waitcnt/s_barrier)" if sh["parked_s_waitcnt_s_barrier"] > 0.4 else "issue") + (" + valu-issue" if sh["issuing_valu"] > 0.15 else "")
         out["sq_breakdown"][k] = sh
-# where k_rx_sync's counter bytes go (per launch): what can be computed from the call counts of the un-profiled bench line, the rest by difference
+# where the receiver kernel's bytes go (per launch).  Two different things side by side, NOT subtracted from one another any more (round 3 did, and got a
+# negative "remainder"): the bytes the kernel REQUESTS by source, from the call counts of the un-profiled bench line (a model), and the bytes that
+# reached HBM (FETCH_SIZE / WRITE_SIZE).  counter / model < 1 on the fetch side = the rest was served by L2 / the infinity cache (a search call's
+# |Dt| surface was written ~100 k cycles earlier by the same workgroup); on the write side everything listed does go out, so counter - model = spills.
 try:
     bl = json.load(open(os.path.join(dst, tag + "_bench_line.json")))
-    rxk = "k_rx_sync2" if "k_rx_sync2" in out["kernels"] else "k_rx_sync"
+    rxk = "k_rx_sync2"
     c = bl["roofline"]["per_launch_counts"]; k = out["kernels"][rxk]; B = bl["config"]["streams_per_gpu"]
     surf = 960 * 40 * 4
-    rd = {"rx samples in (algorithmic)": 640.0 * c["offered_frames"], "|Dt| surface of the previous search call (dtcache)": c["search_calls"] * surf,
-          "per-stream state at launch start": B * 33e3, "decoder latents / history (zrows, hist)": c["decoded_modem_frames"] * 960 + c["decoded_modem_frames"] / 8 * 2944 * 1.0}
+    state = 25.6e3            # sizeof(rd_rx_stream): scalars, filter state, rx_buf (2112 c64), two row-sum vectors
+    rd = {"filtered samples in (k_bpf_fir's output; 8 B per sample consumed)": 640.0 * c["offered_frames"],
+          "|Dt| surface of the previous search call (dtcache; every search call but a stream's first after (re)entering the search state)": c["search_calls"] * surf,
+          "per-stream state at launch start": B * state, "decoder latents / history (zrows, hist)": c["decoded_modem_frames"] * 960 + c["decoded_modem_frames"] / 8 * 2944 * 1.0,
+          "rx_buf / row sums back from HBM after each decoder stage": c["decoded_modem_frames"] / 8 * 24576}
     wr = {"features out (algorithmic)": 144.0 * 12 * c["decoded_modem_frames"], "|Dt| surface written by every search call (dtcache)": c["search_calls"] * surf,
-          "per-stream state at launch end": B * 33e3, "decoder latents, 84-float rows, history": c["decoded_modem_frames"] * (960 + 1008) + c["decoded_modem_frames"] / 8 * 2944}
-    if rxk == "k_rx_sync2":          # rx_buf + row sums parked in HBM while the decoder stage runs (every 8 frames): 24.6 KB out and back
-        rd["rx_buf / row sums back from HBM after each decoder stage"] = c["decoded_modem_frames"] / 8 * 24576
-        wr["rx_buf / row sums parked in HBM during each decoder stage"] = c["decoded_modem_frames"] / 8 * 24576
-    rd["remainder: L2 misses on weights / FFT tables / pilot planes + scratch reloads"] = k["fetch_bytes_per_dispatch"] - sum(rd.values())
-    wr["remainder: scratch spills (about 2.5 M wave-stores of 256 B)"] = k["write_bytes_per_dispatch"] - sum(wr.values())
-    out["rx_sync_traffic_breakdown_bytes_per_launch"] = {"kernel": rxk, "fetch_raw": k["fetch_bytes_per_dispatch"], "write_raw": k["write_bytes_per_dispatch"], "fetch": rd, "write": wr,
+          "per-stream state at launch end": B * state, "decoder latents, 84-float rows, history": c["decoded_modem_frames"] * (960 + 1008) + c["decoded_modem_frames"] / 8 * 2944,
+          "rx_buf / row sums parked in HBM during each decoder stage": c["decoded_modem_frames"] / 8 * 24576}
+    fm, wm = sum(rd.values()), sum(wr.values())
+    out["rx_sync_traffic_breakdown_bytes_per_launch"] = {"kernel": rxk, "fetch_counter": k["fetch_bytes_per_dispatch"], "write_counter": k["write_bytes_per_dispatch"],
+        "fetch_requested_model": rd, "fetch_requested_model_total": fm, "fetch_counter_over_model": k["fetch_bytes_per_dispatch"] / fm,
+        "write_model": wr, "write_model_total": wm, "write_counter_minus_model_is_scratch_spills": k["write_bytes_per_dispatch"] - wm,
         "algorithmic_io_bytes": 784.0 * c["offered_frames"], "ratio_raw_over_io": (k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]) / (784.0 * c["offered_frames"]),
         "ratio_raw_over_io_plus_search_state": (k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]) / (784.0 * c["offered_frames"] + 2 * c["search_calls"] * surf),
-        "note": "the |Dt| surface (960 x 40 float32 = 153.6 KB) a search call leaves for the next one is state the reference's algorithm defines (dsp.py keeps Dt1/Dt2 between calls); it does not fit beside the FFT work area in LDS and must stay float32 for the arg-max to stay bit-exact"}
+        "note": "the |Dt| surface (960 x 40 float32 = 153.6 KB) a search call leaves for the next one is state the reference's algorithm defines (dsp.py keeps Dt1/Dt2 between calls); it does not fit in LDS beside the pilot search's operands and must stay float32 for the arg-max to stay bit-exact"}
+    if "k_bpf_fir" in out["kernels"]:
+        kb = out["kernels"]["k_bpf_fir"]; n_rx = 8000 + (bl["config"]["frames_per_stream"] // 12) * 960 + 1152 + 1152
+        out["bpf_fir_traffic_bytes_per_launch"] = {"fetch_counter": kb["fetch_bytes_per_dispatch"], "write_counter": kb["write_bytes_per_dispatch"],
+            "algorithmic": {"raw samples in": 8.0 * B * n_rx, "filtered samples out": 8.0 * B * n_rx}, "ratio_counter_over_algorithmic": (kb["fetch_bytes_per_dispatch"] + kb["write_bytes_per_dispatch"]) / (16.0 * B * n_rx)}
 except Exception as e:
     print("traffic breakdown skipped:", e)
 json.dump(out, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)

@@ -4,7 +4,7 @@
 # second workgroup; d2 / d1 = 1 means the phase's time is fully hidden behind / beside the neighbour's work, 2 means the two workgroups serialise on it.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/pair; rm -rf $O; mkdir -p $O
-export RADE_LIBRADEHIP=$R/gpu_ab/census.so
+export RADE_LIBRADEHIP=$R/abso/census.so
 for B in 256 512; do for m in 0 1 2 4 16 32 128 256 512; do
   RADE_RX2_CENSUS=$m python $R/tools/rx_only.py 6 2 $B 2>/dev/null | tail -1 > $O/b${B}_m$m.txt
 done; done

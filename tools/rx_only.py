@@ -17,7 +17,7 @@ feats = torch.tensor(base[np.arange(B) % 16], device=dev)
 G = torch.empty((B, n_mf * 960, 2), dtype=torch.complex64, device=dev)
 for b in range(16):
     G[b::16] = torch.from_numpy(multipath_g("mpp", 8000, n_mf * 960, 7000 + b)).to(dev)
-e = BatchEngine(B, max_tx_mf=n_mf, flags=0x200 if variant == 2 else 0)
+e = BatchEngine(B, max_tx_mf=n_mf)
 rx = e.tx_channel(feats, sigma_from_EbNodB(3.0), -11.0, n_pre=8000, n_post=1152, with_eoo=True, G=G, seed=1)
 e.rx(rx); torch.cuda.synchronize()
 t0 = time.perf_counter()
