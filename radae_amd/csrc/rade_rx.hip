@@ -329,46 +329,42 @@ __device__ __forceinline__ void dq2_scan_mfma_body(DecShared2 *sh, const unsigne
 {
     constexpr int H = 96;
     const int tid = rx_tid(), lane = tid & 63, c = lane & 15, g = lane >> 4, cs = c & 3, par = c & 1;
+    // every column of a tile's C holds the same sums once neighbouring lanes are added (the planes sit in even / odd columns), so in a two-block wavefront the lanes of
+    // columns 8..15 take block 1 and those of columns 0..7 block 0: ONE pass over the gates (two sigmoids and a tanh: six transcendental instructions and their
+    // latencies, the longest dependent chain of the step) serves both blocks instead of one pass per block
+    const int blk = NB == 2 ? (c >> 3) & 1 : 0;
     typedef const __attribute__((address_space(1))) f16x8 glb_f16x8_t;
     f16x8 A[NB][3][3];
-    float sc[NB][3], bb[NB][3], hj[NB];
-    const bool finl = c < 4;
-    int ju[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-        ju[k] = 16 * (ub0 + k) + 4 * g + cs;
-#pragma unroll
-        for (int gate = 0; gate < 3; gate++) {
-#pragma unroll
-            for (int ks = 0; ks < 3; ks++) A[k][gate][ks] = *(glb_f16x8_t *)(whq + (((size_t)ks * 18 + gate * 6 + ub0 + k) * 64 + lane) * 8);
-            sc[k][gate] = whs[gate * H + ju[k]] * 0x1p-8f; bb[k][gate] = bhh[gate * H + ju[k]];
-        }
-        hj[k] = hstate[ju[k]];
-    }
-    _Float16 (*hp)[2][H] = (_Float16 (*)[2][H])&sh->hs[0][0];           // [buffer][plane][k]: 2^8 h_{t-1} = hi + lo
-#pragma unroll
-    for (int k = 0; k < NB; k++) if (finl) { _Float16 a, b; dq_split(hj[k], a, b); hp[0][0][ju[k]] = a; hp[0][1][ju[k]] = b; }
-    const float *gi = &sh->gi[0][0];
-    float g0[NB][3];
+    float sc[3], bb[3];
+    const bool finl = (c & 4) == 0 && (NB == 2 || c < 4);      // the lanes that publish: columns 0..3 (block 0) and, with two blocks, 8..11 (block 1)
+    const int ju = 16 * (ub0 + blk) + 4 * g + cs;
 #pragma unroll
     for (int k = 0; k < NB; k++)
 #pragma unroll
-        for (int gate = 0; gate < 3; gate++) g0[k][gate] = gi[gate * H + ju[k]];
+        for (int gate = 0; gate < 3; gate++)
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) A[k][gate][ks] = *(glb_f16x8_t *)(whq + (((size_t)ks * 18 + gate * 6 + ub0 + k) * 64 + lane) * 8);
+#pragma unroll
+    for (int gate = 0; gate < 3; gate++) { sc[gate] = whs[gate * H + ju] * 0x1p-8f; bb[gate] = bhh[gate * H + ju]; }
+    float hj = hstate[ju];
+    _Float16 (*hp)[2][H] = (_Float16 (*)[2][H])&sh->hs[0][0];           // [buffer][plane][k]: 2^8 h_{t-1} = hi + lo
+    if (finl) { _Float16 a, b; dq_split(hj, a, b); hp[0][0][ju] = a; hp[0][1][ju] = b; }
+    const float *gi = &sh->gi[0][0];
+    float g0[3];
+#pragma unroll
+    for (int gate = 0; gate < 3; gate++) g0[gate] = gi[gate * H + ju];
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < Tb; t++) {
         if ((rstmask >> t) & 1u) {                     // uniform over the workgroup
             __syncthreads();
-#pragma unroll
-            for (int k = 0; k < NB; k++) { hj[k] = 0.0f; if (finl) { hp[cur][0][ju[k]] = (_Float16)0.0f; hp[cur][1][ju[k]] = (_Float16)0.0f; } }
+            hj = 0.0f; if (finl) { hp[cur][0][ju] = (_Float16)0.0f; hp[cur][1][ju] = (_Float16)0.0f; }
             __syncthreads();
         }
         const float *gn_ = gi + (size_t)min(t + 1, Tb - 1) * 288;
-        float g1[NB][3];
+        float g1[3];
 #pragma unroll
-        for (int k = 0; k < NB; k++)
-#pragma unroll
-            for (int gate = 0; gate < 3; gate++) g1[k][gate] = gn_[gate * H + ju[k]];
+        for (int gate = 0; gate < 3; gate++) g1[gate] = gn_[gate * H + ju];
         f16x8 bq[3];
 #pragma unroll
         for (int ks = 0; ks < 3; ks++) bq[ks] = *(const f16x8 *)&hp[cur][par][32 * ks + 8 * g];
@@ -385,42 +381,36 @@ __device__ __forceinline__ void dq2_scan_mfma_body(DecShared2 *sh, const unsigne
 #pragma unroll
                 for (int gate = 0; gate < 3; gate++) acc[k][gate] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[k][gate][ks], bq[ks], acc[k][gate], 0, 0, 0);
         // C layout: this lane holds rows 4 g + 0..3 of each tile for column c: high-plane product in even columns, low-plane product in odd ones
-        float s3[NB][3];
+        float s3[3];
 #pragma unroll
-        for (int k = 0; k < NB; k++)
+        for (int gate = 0; gate < 3; gate++) {
+            float sr[4];
 #pragma unroll
-            for (int gate = 0; gate < 3; gate++) {
-                float sr[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { sr[r] = acc[k][gate][r] + quad_dpp<QUAD_XOR1>(acc[k][gate][r]); asm volatile("" : "+v"(sr[r])); }   // (computed before the select: no branches)
-                const float s01 = (cs & 1) ? sr[1] : sr[0], s23 = (cs & 1) ? sr[3] : sr[2];
-                s3[k][gate] = (cs & 2) ? s23 : s01;
+            for (int r = 0; r < 4; r++) {
+                const float v = NB == 2 ? (blk ? acc[NB - 1][gate][r] : acc[0][gate][r]) : acc[0][gate][r];      // this lane's block
+                sr[r] = v + quad_dpp<QUAD_XOR1>(v); asm volatile("" : "+v"(sr[r]));                               // (computed before the select: no branches)
             }
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const float r = gate_sigmoid((s3[k][0] * sc[k][0] + bb[k][0]) + g0[k][0]);
-            const float z = gate_sigmoid((s3[k][1] * sc[k][1] + bb[k][1]) + g0[k][1]);
-            const float n = gate_tanh(g0[k][2] + (s3[k][2] * sc[k][2] + bb[k][2]) * r);
-            hj[k] = (hj[k] - n) * z + n;
+            const float s01 = (cs & 1) ? sr[1] : sr[0], s23 = (cs & 1) ? sr[3] : sr[2];
+            s3[gate] = (cs & 2) ? s23 : s01;
+        }
+        {
+            const float r = gate_sigmoid((s3[0] * sc[0] + bb[0]) + g0[0]);
+            const float z = gate_sigmoid((s3[1] * sc[1] + bb[1]) + g0[1]);
+            const float n = gate_tanh(g0[2] + (s3[2] * sc[2] + bb[2]) * r);
+            hj = (hj - n) * z + n;
         }
         if (finl) {
-#pragma unroll
-            for (int k = 0; k < NB; k++) {
-                _Float16 a, b; dq_split(hj[k], a, b);
-                hp[cur ^ 1][0][ju[k]] = a; hp[cur ^ 1][1][ju[k]] = b;
-                dq_split(clamp1(hj[k]), a, b);
-                sh->hbh[0][dq_hoff(t, ju[k])] = a; sh->hbl[0][dq_hoff(t, ju[k])] = b;
-            }
+            _Float16 a, b; dq_split(hj, a, b);
+            hp[cur ^ 1][0][ju] = a; hp[cur ^ 1][1][ju] = b;
+            dq_split(clamp1(hj), a, b);
+            sh->hbh[0][dq_hoff(t, ju)] = a; sh->hbl[0][dq_hoff(t, ju)] = b;
         }
 #pragma unroll
-        for (int k = 0; k < NB; k++)
-#pragma unroll
-            for (int gate = 0; gate < 3; gate++) g0[k][gate] = g1[k][gate];
+        for (int gate = 0; gate < 3; gate++) g0[gate] = g1[gate];
         cur ^= 1;
         __syncthreads();
     }
-#pragma unroll
-    for (int k = 0; k < NB; k++) if (finl) hstate[ju[k]] = hj[k];
+    if (finl) hstate[ju] = hj;
 }
 __device__ void dq2_scan_mfma(DecShared2 *sh, const unsigned short *whq, const float *whs, const float *bhh, float *hstate, int Tb, unsigned rstmask)
 {
