@@ -455,14 +455,23 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
     float hj = a.h[(size_t)b * H + j];
     if (p == 0) hs[0][j] = hj;
     const float *gi = a.gi + (size_t)b * a.gi_sb + (p < 3 ? p * H + j : j);   // lane part p < 3 fetches gate p of unit j
-    // gi is fetched four steps at a time, one block ahead: a load issued inside the step that consumes an older one makes
-    // the compiler wait for all of them (vmcnt(0)), i.e. one L2 round trip per step on the serial chain
-    float gcur[4], gnxt[4];
+    // gi is fetched four steps at a time into TWO register sets that take turns: a set is refilled right after its block of steps and consumed a whole
+    // block later, so the loads land in the registers they are used from.  (Rounds 1-3 had one set and a copy "next -> current" at the end of a block: the
+    // compiler put the fresh loads and `s_waitcnt vmcnt(0)` in front of that copy -- a memory round trip exposed every four steps, a quarter of the step.)
+    // Rows beyond Tb re-read the last row (never used): no branch around a load.
+    float gA[4], gB[4];
+    auto fetch = [&](float (&dst)[4], int t0) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) { gcur[u] = u < Tb ? gi[(size_t)u * a.gi_st] : 0.0f; gnxt[u] = 4 + u < Tb ? gi[(size_t)(4 + u) * a.gi_st] : 0.0f; }
+        for (int u = 0; u < 4; u++) dst[u] = gi[(size_t)min(t0 + u, max(Tb - 1, 0)) * a.gi_st];
+    };
+    // every load issued so far (W_hh rows, biases, state) completes here: left pending into the loop, the wait-count bookkeeping (one state per loop header,
+    // merged over entry and back edge) makes the first step of every block wait for ALL outstanding loads
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(gA, 0); fetch(gB, 4);
     __syncthreads();
     int cur = 0;
-    for (int t0 = 0; t0 < Tb; t0 += 4) {
+    auto block = [&](const float (&gq)[4], int t0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int t = t0 + u;
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
             }
             sr += quad_dpp<QUAD_XOR1>(sr); sz += quad_dpp<QUAD_XOR1>(sz); sn += quad_dpp<QUAD_XOR1>(sn);
             sr += quad_dpp<QUAD_XOR2>(sr); sz += quad_dpp<QUAD_XOR2>(sz); sn += quad_dpp<QUAD_XOR2>(sn);
-            const float g0 = gcur[u];
+            const float g0 = gq[u];
             const float gr = quad_dpp<QUAD_BC0>(g0), gz = quad_dpp<QUAD_BC1>(g0), gn = quad_dpp<QUAD_BC2>(g0);
             const float r = gate_sigmoid((sr + br) + gr);
             const float z = gate_sigmoid((sz + bz) + gz);
@@ -496,10 +505,12 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
             cur ^= 1;
             __syncthreads();
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) gcur[u] = gnxt[u];         // loaded a whole block ago: no stall
-#pragma unroll
-        for (int u = 0; u < 4; u++) gnxt[u] = t0 + 8 + u < Tb ? gi[(size_t)(t0 + 8 + u) * a.gi_st] : 0.0f;
+    };
+    for (int t0 = 0; t0 < Tb; t0 += 8) {
+        block(gA, t0);
+        fetch(gA, t0 + 8);
+        block(gB, t0 + 4);
+        fetch(gB, t0 + 12);
     }
     if (p == 0) a.h[(size_t)b * H + j] = hj;
 }
