@@ -426,9 +426,14 @@ __device__ void dq2_layers(DecShared2 *sh, const rd_decs_args &a, int b, const f
     PH2_T0();
     {
         const unsigned *hist = (const unsigned *)(a.x + (size_t)b * a.x_sb - RD_DEC_W);
-        for (int c = tid; c < RD_DEC_W; c += NT2) {
-            const unsigned u = hist[c];
-            sh->xh[0][dq_xoff(-1, c)] = __builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); sh->xl[0][dq_xoff(-1, c)] = __builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+        constexpr int NH_ = (RD_DEC_W + NT2 - 1) / NT2;
+        unsigned hu[NH_];                                       // (all requested before the first LDS store: see rx2_load_rxbuf)
+#pragma unroll
+        for (int q = 0; q < NH_; q++) hu[q] = hist[min(tid + q * NT2, RD_DEC_W - 1)];
+#pragma unroll
+        for (int q = 0; q < NH_; q++) {
+            const int c = tid + q * NT2; const unsigned u = hu[q];
+            if (c < RD_DEC_W) { sh->xh[0][dq_xoff(-1, c)] = __builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); sh->xl[0][dq_xoff(-1, c)] = __builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
         }
         for (int c = tid; c < DQ_XB * 8; c += NT2) { sh->xh[DQ2_ROWS + 1][c] = (_Float16)0.0f; sh->xl[DQ2_ROWS + 1][c] = (_Float16)0.0f; }
     }
@@ -953,6 +958,22 @@ __device__ void rx2_refine(RxShared2 *sh, const double *vmg, int *tmax, double *
     if (best > 0.0f) { *tmax = t0 + bt; *fmax = fstart + bf * delta; }
 }
 
+// rx_buf and the |Dt| row sums from the stream's HBM record into LDS: every load of a thread requested before the first store (as a plain loop
+// the compiler cannot tell that the LDS stores do not alias the record and waits for each load before the next: 13 round trips in a row)
+__device__ __forceinline__ void rx2_load_rxbuf(RxShared2 *sh, const rd_rx_stream *st, int tid)
+{
+    constexpr int NB_ = (RD_RXBUF + NT2 - 1) / NT2, NR_ = (RD_NMF + NT2 - 1) / NT2;
+    float2 v[NB_]; float r1[NR_], r2[NR_];
+#pragma unroll
+    for (int q = 0; q < NB_; q++) { const int i = min(tid + q * NT2, RD_RXBUF - 1); v[q] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]); }
+#pragma unroll
+    for (int q = 0; q < NR_; q++) { const int i = min(tid + q * NT2, RD_NMF - 1); r1[q] = st->rowsum1[i]; r2[q] = st->rowsum2[i]; }
+#pragma unroll
+    for (int q = 0; q < NB_; q++) { const int i = tid + q * NT2; if (i < RD_RXBUF) sh->rxb[i] = v[q]; }
+#pragma unroll
+    for (int q = 0; q < NR_; q++) { const int i = tid + q * NT2; if (i < RD_NMF) { sh->rowsum1[i] = r1[q]; sh->rowsum2[i] = r2[q]; } }
+}
+
 // ---- decoder + output stage for the rows a stream has pending (rx_decode_pending on four wavefronts, chunks of 12 rows) -----------
 // rx_buf and the row sums leave LDS for the duration (the stage's 64 KB overlay them): out to the stream's HBM record, back afterwards
 __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_args &a, int b)
@@ -978,10 +999,17 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
     const float *f84 = a.dec.out + (size_t)b * a.dec.out_sb;
     for (int r = tid; r < Tb; r += NT2) ds->err[r] = f84[r * 84 + 20] > 0.0f ? 1 : 0;
     float *out = a.features_out + (size_t)b * a.feat_stride + (size_t)S->out_base * RD_FEAT_MF;
-    for (int i = tid; i < (Tb / 3) * RD_FEAT_MF; i += NT2) {
-        const int fr = i / 36, j = i - fr * 36;
-        const int row = fr >> 2, sub = fr & 3;
-        out[i] = j < 20 ? f84[row * 84 + sub * 21 + j] : 0.0f;
+    for (int i0 = tid; i0 < (Tb / 3) * RD_FEAT_MF; i0 += 4 * NT2) {      // four loads in flight per thread (a plain loop waits for each load before its store: the stores may alias)
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int i = min(i0 + q * NT2, (Tb / 3) * RD_FEAT_MF - 1), fr = i / 36, j = i - fr * 36;
+            const int row = fr >> 2, sub = fr & 3;
+            v[q] = f84[row * 84 + sub * 21 + min(j, 19)];
+            if (j >= 20) v[q] = 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int i = i0 + q * NT2; if (i < (Tb / 3) * RD_FEAT_MF) out[i] = v[q]; }
     }
     __syncthreads();
     if (a.trace) {
@@ -1000,13 +1028,7 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
         S->out_base += Tb / 3; S->n_rows = 0; S->uw_from_row = 0; S->pending_valid = 0; S->batch_call0 = S->n_calls; S->need_decode = 0;
     }
     __syncthreads();
-#ifdef RX2_RELOAD_AGENT
-    for (int i = tid; i < RD_RXBUF; i += NT2) sh->rxb[i] = make_float2(__hip_atomic_load(&st->rx_buf[i][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(&st->rx_buf[i][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    for (int i = tid; i < RD_NMF; i += NT2) { sh->rowsum1[i] = __hip_atomic_load(&st->rowsum1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sh->rowsum2[i] = __hip_atomic_load(&st->rowsum2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#else
-    for (int i = tid; i < RD_RXBUF; i += NT2) sh->rxb[i] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]);
-    for (int i = tid; i < RD_NMF; i += NT2) { sh->rowsum1[i] = st->rowsum1[i]; sh->rowsum2[i] = st->rowsum2[i]; }
-#endif
+    rx2_load_rxbuf(sh, st, tid);
     __syncthreads();
 }
 
@@ -1240,8 +1262,7 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
     const float2 *rxin = (const float2 *)a.rx + (size_t)b * a.rx_stride;
 
     // ---- load the stream's working set into LDS
-    for (int i = tid; i < RD_RXBUF; i += NT2) sh->rxb[i] = make_float2(st->rx_buf[i][0], st->rx_buf[i][1]);
-    for (int i = tid; i < RD_NMF; i += NT2) { sh->rowsum1[i] = st->rowsum1[i]; sh->rowsum2[i] = st->rowsum2[i]; }
+    rx2_load_rxbuf(sh, st, tid);
     if (tid == 0) {
         S->state = st->state; S->nin = st->nin; S->tmax = st->tmax; S->tmax_candidate = st->tmax_candidate; S->valid_count = st->valid_count;
         S->uw_errors = st->uw_errors; S->synced_count = st->synced_count; S->mf = st->mf; S->f_ind_max = st->f_ind_max;
