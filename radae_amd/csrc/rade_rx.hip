@@ -171,9 +171,10 @@ __device__ __forceinline__ void dq2_gemm_tiles_(DecShared2 *sh_, const DqGemm g_
 #pragma unroll
     for (int i = 0; i < NT; i++) {
         bias[i] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; scl[i] = (f32x4){ 0x1p-18f, 0x1p-18f, 0x1p-18f, 0x1p-18f };
-        if (biasp && !init_gi) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) bias[i][r] = n0 + 16 * i + r < N ? biasp[n0 + 16 * i + r] : 0.0f;
+        if (biasp && !init_gi) {        // (N is a multiple of 4 in every layer: one 16-byte load from a clamped address instead of four guarded dwords)
+            const int nn = n0 + 16 * i;
+            bias[i] = *(const __attribute__((address_space(1))) f32x4 *)(biasp + min(nn, N - 4));
+            if (nn >= N) bias[i] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
         }
         if (single) scl[i] = *(const __attribute__((address_space(1))) f32x4 *)(wscale + n0 + 16 * i) * 0x1p-8f;
     }
@@ -1349,10 +1350,16 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
 #pragma unroll
         for (int q = 0; q < NNEW; q++) { const int i = tid + q * NT2; nv[q] = i < nin ? (on_grid ? rxf[cons0 + i] : sh->xm[i]) : make_float2(0.0f, 0.0f); }
         if (state == ST_SYNC && !S->lds_sync) {      // pilot replicas and equaliser constants share LDS with the pilot search and the decoder stage
-            for (int i = tid; i < RD_M; i += NT2) { sh->pd[i] = make_double2(tab->p[i][0], tab->p[i][1]); sh->pendd[i] = make_double2(tab->pend[i][0], tab->pend[i][1]); }
-            if (tid < RD_NC) { sh->eqP[tid] = tab->P[tid]; sh->eqrot[tid] = make_float2(tab->eq_rot[tid][0], tab->eq_rot[tid][1]); }
-            if (tid < RD_NC * 6) { const int c = tid / 6, r = tid - 6 * c; sh->eqPmat[c][r / 3][r % 3] = make_float2(tab->Pmat[c][r / 3][r % 3][0], tab->Pmat[c][r / 3][r % 3][1]); }
-            if (tid == 0) { sh->eq_pg = tab->pilot_gain; sh->eq_snrc1 = tab->snr_c1; sh->eq_snrc2 = tab->snr_c2; }
+            // (after every decoder stage: all of a thread's table loads requested before its first LDS store -- as one statement after the other each load was waited for)
+            const int i0 = min(tid, RD_M - 1), cc = min(tid, RD_NC - 1), c6 = min(tid, RD_NC * 6 - 1) / 6, r6 = min(tid, RD_NC * 6 - 1) - 6 * c6;
+            const float2 vp = ld2(tab->p, i0), ve = ld2(tab->pend, i0);
+            const float vP = tab->P[cc]; const float2 vr = ld2(tab->eq_rot, cc);
+            const float2 vm_ = make_float2(tab->Pmat[c6][r6 / 3][r6 % 3][0], tab->Pmat[c6][r6 / 3][r6 % 3][1]);
+            const float g0_ = tab->pilot_gain, g1_ = tab->snr_c1, g2_ = tab->snr_c2;
+            if (tid < RD_M) { sh->pd[tid] = make_double2(vp.x, vp.y); sh->pendd[tid] = make_double2(ve.x, ve.y); }
+            if (tid < RD_NC) { sh->eqP[tid] = vP; sh->eqrot[tid] = vr; }
+            if (tid < RD_NC * 6) sh->eqPmat[c6][r6 / 3][r6 % 3] = vm_;
+            if (tid == 0) { sh->eq_pg = g0_; sh->eq_snrc1 = g1_; sh->eq_snrc2 = g2_; }
         }
         PH2(3);
         // rx_buf shift and append (radae_rxe.py:196-197); the largest component of the new samples sets the operand scale of the binary16 planes
