@@ -270,6 +270,8 @@ def main():
         out["roofline"]["rx_kernel"] = "k_rx_sync2 (256 threads / at most 80 KB of LDS per stream: two streams per CU)"
         if depth > 1 and out["roofline"].get("kernel") == "rx_sync":
             pipelined_roofline(out["roofline"], engs, run_steps, min(args.steps, 24), dev)
+        if out["roofline"].get("kernel") == "rx_sync":
+            two_per_cu_leg(out["roofline"], B, T, n_mf, local, blob, feats, G, sigma, n_pre, n_post)
     if rank == 0 and not args.no_parity:
         out["parity_sample"] = parity_leg(feats_np, fo, st, rx_last, blob, local, B)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -407,6 +409,39 @@ def pipelined_roofline(r, engs, run_steps, n, dev):
     r["achieved"], r["frac"] = ach, ach / F32_PEAK_TFLOPS
     r["avg_launch_ms"] = union / max(len(iv), 1)
     r["avg_launch_ms_note"] = "busy time of the receiver kernel per launch in the timed (pipelined) configuration; alone.avg_launch_ms = one launch by itself; pipelined.avg_launch_ms_overlapped = event duration of a launch sharing the chip"
+
+
+def two_per_cu_leg(r, B, T, n_mf, local, blob, feats, G, sigma, n_pre, n_post, steps=6):
+    """The receiver kernel at the occupancy it is built for, in ONE launch: k_rx_sync2 is sized for two workgroups (streams) per CU, and a
+    launch of B = 256 streams alone puts one on each of the 256 CUs (`alone`).  Here one engine carries 2 B streams (the same utterances
+    twice; the channel's noise is keyed by stream index, so the two copies differ), so a single launch fills both slots of every CU with no other
+    kernel on the chip: executed FLOP of that launch / its HIP-event duration."""
+    from radae_amd.engine import BatchEngine
+    e2 = BatchEngine(2 * B, max_tx_mf=n_mf, device=local, blob_bytes=blob)
+    f2 = torch.cat([feats, feats]); G2 = torch.cat([G, G])
+
+    def step2(seed):
+        e2.reset()
+        return e2.rx(e2.tx_channel(f2, sigma, -11.0, n_pre=n_pre, n_post=n_post, with_eoo=True, G=G2, seed=seed))
+    step2(1); step2(2)
+    torch.cuda.synchronize()
+    e2.profile(True)
+    search = sync = dec_mf = 0
+    for k in range(steps):
+        _, st, _ = step2(1 + k)
+        s_sync = sum(s.n_valid + s.has_eoo for s in st)
+        sync += s_sync; search += sum(s.n_calls for s in st) - s_sync; dec_mf += sum(s.n_valid for s in st)
+    torch.cuda.synchronize()
+    e2.profile(False)
+    p = e2.profile_get()["rx_sync"]
+    e2.close()
+    ms = p["ms"] / max(p["launches"], 1)
+    fl = executed_flop(search / steps, sync / steps, dec_mf / steps)
+    ach = fl / (ms * 1e-3) / 1e12
+    r["two_per_cu"] = {"streams_per_launch": 2 * B, "avg_launch_ms": ms, "executed_flop_per_launch": fl, "achieved": ach, "frac": ach / F32_PEAK_TFLOPS,
+                       "ms_per_256_streams": ms / 2,
+                       "note": "one launch of 2 x 256 streams alone on the chip: both stream slots of every CU filled by a single launch (the kernel's design occupancy), "
+                               "same flop model; `alone` is the same kernel with one slot of every CU empty"}
 
 
 def parity_leg(feats_np, fo, st, rx, blob, local, B):
