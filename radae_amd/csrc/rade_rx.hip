@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(128) void k_bpf_advance(rd_bpf_args a)
 // filter memory: nothing is read twice), and the phase-table entries a thread needs are the same for every block (loaded once).
 #define BPF_NT 256
 #define BPF_BPW 8
-__global__ __launch_bounds__(BPF_NT) void k_bpf_fir(rd_bpf_args a)
+__global__ __launch_bounds__(BPF_NT, 4) void k_bpf_fir(rd_bpf_args a)      // (at most 128 registers: two of its wavefronts fit on a SIMD beside a receiver wavefront)
 {
     const rd_tables *tab = a.tab; const unsigned short *tab16 = a.bpf16;
     const float2 *rx = (const float2 *)a.x; const long rx_stride = a.x_stride; float2 *rxf = (float2 *)a.y; const long rxf_stride = a.y_stride;
