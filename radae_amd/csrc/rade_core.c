@@ -237,14 +237,37 @@ static core_dev *dev_open(const void *blob, int len, int dim, int enc)
     a->hist = core_upload(d, NULL, sizeof(float) * 2 * a->W);          /* zero state = rade_init_encoder / rade_init_decoder */
     a->h = core_upload(d, NULL, sizeof(float) * 5 * a->H);
     if (e || !a->hist || !a->h || hipStreamCreate(&d->gs) != hipSuccess ||
-        hipHostMalloc((void **)&d->h_in, sizeof(float) * 96, hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc((void **)&d->h_out, sizeof(float) * 128, hipHostMallocMapped) != hipSuccess ||
+        hipHostMalloc((void **)&d->h_in, sizeof(float) * 96, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostMalloc((void **)&d->h_out, sizeof(float) * 128, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer((void **)&a->in, d->h_in, 0) != hipSuccess || hipHostGetDevicePointer((void **)&a->out_vec, d->h_out, 0) != hipSuccess) {
         fprintf(stderr, "rade_core: device set-up failed\n"); dev_close(d); return NULL;
     }
     memset(d->h_out, 0, sizeof(float) * 128);
     a->done = (unsigned *)(a->out_vec + 96);
     return d;
+}
+
+/* Completion of a single-stream launch: the kernel writes `seq` into a word of pinned, host-coherent memory after its outputs.  Polling that word returns
+ * as soon as the result is there (a stream synchronisation goes through the runtime's interrupt path: ~100 us of wake-up for a 40 us kernel), but a polling
+ * thread owns a core: so the spin is bounded by RD_POLL_US (a few kernel durations) and then the stream is waited for the ordinary way, which yields the
+ * core and surfaces device errors.  $RADE_CORE_NO_POLL=1: never spin (hosts with fewer cores than single-stream states). */
+#define RD_POLL_US 1000.0
+static int wait_done(volatile unsigned *done, unsigned seq, hipStream_t st)
+{
+    static int no_poll = -1;
+    if (no_poll < 0) no_poll = getenv("RADE_CORE_NO_POLL") ? 1 : 0;
+    if (!no_poll) {
+        struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0; *done != seq; spins++) {
+            if ((spins & 255u) == 255u) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3 > RD_POLL_US) break;
+            }
+        }
+    }
+    if (*done != seq && (hipStreamSynchronize(st) != hipSuccess || *done != seq)) return -1;
+    __sync_synchronize();
+    return 0;
 }
 
 /* ---- internal (rade_api.c): rade_tx() on the single-stream kernels -- one launch per modem frame (k_tx_frame: three encoder steps + the OFDM
@@ -266,8 +289,8 @@ void *rd_core_tx_open(const void *blob, int len, const rd_tables *d_tab)
     tx_dev *t = calloc(1, sizeof *t);
     if (!t) return NULL;
     t->d = dev_open(blob, len, 84, 1);
-    if (!t->d || hipHostMalloc((void **)&t->h_in, sizeof(float) * 3 * 84, hipHostMallocMapped) != hipSuccess ||
-        hipHostMalloc((void **)&t->h_iq, sizeof(float) * 2 * RD_NMF + 64, hipHostMallocMapped) != hipSuccess) { rd_core_tx_close(t); (void)hipGetLastError(); return NULL; }
+    if (!t->d || hipHostMalloc((void **)&t->h_in, sizeof(float) * 3 * 84, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostMalloc((void **)&t->h_iq, sizeof(float) * 2 * RD_NMF + 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { rd_core_tx_close(t); (void)hipGetLastError(); return NULL; }
     rd_core_args *a = &t->d->a;
     void *dp = NULL;
     if (hipHostGetDevicePointer(&dp, t->h_in, 0) != hipSuccess) { rd_core_tx_close(t); return NULL; }
@@ -301,14 +324,7 @@ int rd_core_tx_frame(void *p, const float *features_in, float *tx_out)
     volatile unsigned *done = (volatile unsigned *)t->done;
     d->a.seq++;
     if (rd_launch_tx_frame(t->a_dev, d->a.seq, d->gs)) return -1;
-    struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (unsigned spins = 0; *done != d->a.seq; spins++) {
-        if ((spins & 1023u) == 1023u) {
-            clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 20.0) { if (hipStreamSynchronize(d->gs) != hipSuccess || *done != d->a.seq) return -1; break; }
-        }
-    }
-    __sync_synchronize();
+    if (wait_done(done, d->a.seq, d->gs)) return -1;
     memcpy(tx_out, t->h_iq, sizeof(float) * 2 * RD_NMF);
     return 0;
 }
@@ -343,15 +359,8 @@ static int core_step(core_dev *d, int enc, const float *in, int n_in, float *out
         if (rd_launch_core_step(&d->a, d->gs)) return -1;
         /* the kernel writes its completion word into pinned host memory after the output: polling it returns as soon as the result is
          * there (a stream synchronisation goes through the runtime's interrupt path: ~100 us of wake-up for a 40 us kernel); a kernel
-         * that has not signalled after 20 ms is waited for the ordinary way, which also surfaces device errors */
-        struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
-        for (unsigned spins = 0; *done != d->a.seq; spins++) {
-            if ((spins & 1023u) == 1023u) {
-                clock_gettime(CLOCK_MONOTONIC, &t1);
-                if ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6 > 20.0) { if (hipStreamSynchronize(d->gs) != hipSuccess || *done != d->a.seq) return -1; break; }
-            }
-        }
-        __sync_synchronize();
+         * that has not signalled after RD_POLL_US is waited for the ordinary way, which also surfaces device errors (wait_done) */
+        if (wait_done(done, d->a.seq, d->gs)) return -1;
         memcpy(out, d->h_out, sizeof(float) * n_out);
         return 0;
     }

@@ -152,7 +152,7 @@ int rd_launch_copy_eoo(const float *eoo, void *out, long stride, int B, rd_strea
 
 typedef struct {
     const rd_tables *tab; const void *tx; long tx_stride; void *rx; long rx_stride;
-    const void *G; const void *noise; const float *eoo; void *scratch; /* >= B * max(64, n_sig / 960) * 2 doubles */
+    const void *G; const void *noise; const float *eoo; void *scratch; /* >= B * (1 + max(64, n_sig / 960)) * 2 doubles: [B][4] floats (gain, final phase), then the partial power sums */
     const void *mp;                    /* optional [B][n_sig] c64: the multipath output k_ofdm_mod_mp left (scratch then holds its n_sig / 960 per-frame power sums per stream) */
     int B, n_sig, n_pre, n_post, with_eoo; float sigma, freq_offset, df_dt; unsigned long long seed;
     float sine_amp, sine_freq, rx_gain;

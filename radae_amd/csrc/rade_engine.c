@@ -308,7 +308,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         h->tx_chain = dev_zeros(sizeof(float) * 2 * B * (cfg->max_tx_mf + 8));
         if (!h->tx_bpf_init || !h->tx_bpf || !h->tx_raw || !h->tx_chain) goto fail;
     }
-    h->chan_scratch = dev_zeros(sizeof(double) * B * (cfg->max_tx_mf > 64 ? cfg->max_tx_mf : 64) * 2);
+    h->chan_scratch = dev_zeros(sizeof(double) * B * (1 + (cfg->max_tx_mf > 64 ? cfg->max_tx_mf : 64)) * 2);   /* rd_chan_args.scratch */
     h->enc_h[0] = dev_zeros(sizeof(float) * 5 * B * 64); h->dec_h[0] = dev_zeros(sizeof(float) * 5 * B * 96);
     if (!h->enc_h[0] || !h->dec_h[0]) goto fail;
     for (int l = 1; l < 5; l++) { h->enc_h[l] = h->enc_h[0] + (size_t)l * B * 64; h->dec_h[l] = h->dec_h[0] + (size_t)l * B * 96; }
@@ -613,7 +613,7 @@ int rade_batch_tx_channel(rade_batch *h, const float *features_dev, int n_mf, vo
     int e = rd_launch_enc_pack(features_dev, h->enc_xin, B, T, stream);
     e |= encode_core(h, T, h->enc_z, stream);
     PROF_BEGIN(h, stream);
-    e |= rd_launch_ofdm_mod_mp(h->d_tab, h->enc_z, iq_out_dev, iq_stride, B, n_mf, p->G_dev, h->chan_mp, (double *)h->chan_scratch, stream);
+    e |= rd_launch_ofdm_mod_mp(h->d_tab, h->enc_z, iq_out_dev, iq_stride, B, n_mf, p->G_dev, h->chan_mp, (double *)h->chan_scratch + 2 * (size_t)B, stream);
     PROF_END(h, stream, RADE_PROF_MOD, 8.0 * B * n_mf * 5 * 30 * 160);
     if (e) return -1;
     rd_chan_args a;

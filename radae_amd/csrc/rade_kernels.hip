@@ -812,23 +812,27 @@ __device__ __forceinline__ double chan_phase_acc(int i, float f0, float df_dt)
     return (2.0 * PI_D / 8000.0) * (n * (double)f0 + ((double)df_dt / 8000.0) * 0.5 * (double)i * n);
 }
 
-__global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const double *part, int n_part)
+// per stream, ahead of k_chan_apply: the power-normalising gain and the phase the frequency offset has reached at the end of the signal, from the
+// stream's partial power sums (added in their fixed order).  As a prologue of every k_chan_apply workgroup -- one thread, a hundred dependent
+// additions, powf and a double-precision sincos while 255 threads wait -- this was a third of that kernel's time.
+__global__ __launch_bounds__(64) void k_chan_gain(rd_chan_args a, const double *part, int n_part, float *gf)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    double p0 = 0.0, p1 = 0.0;
+    for (int c = 0; c < n_part; c++) { p0 += part[((size_t)b * n_part + c) * 2]; p1 += part[((size_t)b * n_part + c) * 2 + 1]; }
+    const float tx_power = (float)(p0 / a.n_sig), mp_power = (float)(p1 / a.n_sig);
+    float2 fin = make_float2(1.0f, 0.0f);
+    if (a.freq_offset != 0.0f && a.n_sig > 0) { float sn, cs; sincosf((float)chan_phase_acc(a.n_sig - 1, a.freq_offset, a.df_dt), &sn, &cs); fin = make_float2(cs, sn); }
+    gf[4 * b] = a.G ? powf(tx_power / mp_power, 0.5f) : 1.0f; gf[4 * b + 1] = fin.x; gf[4 * b + 2] = fin.y;
+}
+
+__global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const float *gf)
 {
     const int b = blockIdx.y;
     const int n_eoo = a.with_eoo ? RD_NEOO : 0;
     const int n_total = a.n_pre + a.n_sig + n_eoo + a.n_post;
-    __shared__ float s_gain; __shared__ float2 s_fin;
-    if (threadIdx.x == 0) {
-        double p0 = 0.0, p1 = 0.0;
-        for (int c = 0; c < n_part; c++) { p0 += part[((size_t)b * n_part + c) * 2]; p1 += part[((size_t)b * n_part + c) * 2 + 1]; }
-        const float tx_power = (float)(p0 / a.n_sig), mp_power = (float)(p1 / a.n_sig);
-        s_gain = a.G ? powf(tx_power / mp_power, 0.5f) : 1.0f;
-        float2 fin = make_float2(1.0f, 0.0f);
-        if (a.freq_offset != 0.0f && a.n_sig > 0) { float sn, cs; sincosf((float)chan_phase_acc(a.n_sig - 1, a.freq_offset, a.df_dt), &sn, &cs); fin = make_float2(cs, sn); }
-        s_fin = fin;
-    }
-    __syncthreads();
-    const float gain = s_gain; const float2 fin = s_fin;
+    const float gain = gf[4 * b]; const float2 fin = make_float2(gf[4 * b + 1], gf[4 * b + 2]);
     const float2 *tx = (const float2 *)a.tx + (size_t)b * a.tx_stride;
     const float2 *G = a.G ? (const float2 *)a.G + (size_t)b * a.n_sig * 2 : nullptr;
     const float2 *noise = a.noise ? (const float2 *)a.noise + (size_t)b * n_total : nullptr;
@@ -968,11 +972,14 @@ extern "C" int rd_launch_channel(const rd_chan_args *a, rd_stream_t s)
 {
     if (a->B <= 0) return 0;
     hipStream_t st = (hipStream_t)s;
-    double *part = (double *)a->scratch;
+    float *gf = (float *)a->scratch;                        // scratch: [B][4] floats (gain, final phase), then the partial power sums
+    double *part = (double *)a->scratch + 2 * (size_t)a->B;
+    const int n_part = a->mp ? a->n_sig / RD_NMF : CH_NCH;
     if (!a->mp) hipLaunchKernelGGL(k_chan_power, dim3(CH_NCH, a->B), dim3(256), 0, st, *a, part);      // a->mp: the modulator left mp and its per-frame power sums (k_ofdm_mod_mp)
+    hipLaunchKernelGGL(k_chan_gain, dim3((a->B + 63) / 64), dim3(64), 0, st, *a, (const double *)part, n_part, gf);
     const int n_total = a->n_pre + a->n_sig + (a->with_eoo ? RD_NEOO : 0) + a->n_post;
-    int gx = (n_total + 255) / 256; if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k_chan_apply, dim3(gx, a->B), dim3(256), 0, st, *a, (const double *)part, a->mp ? a->n_sig / RD_NMF : CH_NCH);
+    int gx = (n_total + 255) / 256; if (gx > 32) gx = 32;          // (16..32 workgroups per stream measure the same; 64: +4 %, 8: +13 %)
+    hipLaunchKernelGGL(k_chan_apply, dim3(gx, a->B), dim3(256), 0, st, *a, (const float *)gf);
     return (int)hipGetLastError();
 }
 
