@@ -288,21 +288,21 @@ __global__ __launch_bounds__(CS_THREADS) void k_tx_frame(const rd_core_args *ap,
     const rd_tables *tab = ap->tab;
     float2 *out = (float2 *)ap->iq_out;
     if (tid < RD_M) {
-        float2 acc[RD_NS + 1];
+        f32x2 acc[RD_NS + 1];
 #pragma unroll
-        for (int s = 0; s <= RD_NS; s++) acc[s] = make_float2(0.0f, 0.0f);
+        for (int s = 0; s <= RD_NS; s++) acc[s] = (f32x2){ 0.0f, 0.0f };
 #pragma unroll 6
         for (int c = 0; c < RD_NC; c++) {
             const float2 w = ld2(tab->Winv[c], tid);
-            acc[0] = cadd(acc[0], cmul(make_float2(tab->P[c] * tab->pilot_gain, 0.0f * tab->pilot_gain), w));
+            acc[0] = idft_term(acc[0], make_float2(tab->P[c] * tab->pilot_gain, 0.0f * tab->pilot_gain), w);
 #pragma unroll
-            for (int s = 1; s <= RD_NS; s++) { const int k = (s - 1) * RD_NC + c; acc[s] = cadd(acc[s], cmul(make_float2(zs[2 * k], zs[2 * k + 1]), w)); }
+            for (int s = 1; s <= RD_NS; s++) { const int k = (s - 1) * RD_NC + c; acc[s] = idft_term(acc[s], make_float2(zs[2 * k], zs[2 * k + 1]), w); }
         }
 #pragma unroll
         for (int s = 0; s <= RD_NS; s++) {
-            const float mag = hypotf(acc[s].x, acc[s].y);
+            const float mag = hypotf(acc[s][0], acc[s][1]);
             float2 v = make_float2(0.0f, 0.0f);
-            if (mag != 0.0f) { const float g = tanhf(mag) / mag; v = make_float2(acc[s].x * g, acc[s].y * g); }      // tanh(|x|) e^{j angle(x)} (radae.py:218, dsp.py:377)
+            if (mag != 0.0f) { const float g = tanhf(mag) / mag; v = make_float2(acc[s][0] * g, acc[s][1] * g); }      // tanh(|x|) e^{j angle(x)} (radae.py:218, dsp.py:377)
             out[s * RD_SYM + RD_NCP + tid] = v;
             if (tid >= RD_M - RD_NCP) out[s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
         }

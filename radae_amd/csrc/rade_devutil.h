@@ -29,6 +29,16 @@ __device__ __forceinline__ float2 cmul_nc(float2 a, float2 b)
     const float rr = a.x * b.x, ii = a.y * b.y, ri = a.x * b.y, ir = a.y * b.x;
     return make_float2(rr - ii, ri + ir);
 }
+
+// one term of the modulator's 30-term IDFT as two packed FMAs (v_pk_fma_f32: both components of a sample in one instruction; the scalar form,
+// 720 FMAs per thread, was half of k_ofdm_mod_mp's time): acc += s.re (w.re, w.im); acc += s.im (-w.im, w.re).  Every place that synthesises a
+// transmit sample uses this one form, so the same sample comes out the same bits wherever it is computed.
+__device__ __forceinline__ f32x2 idft_term(f32x2 acc, float2 sy, float2 w)
+{
+    acc = __builtin_elementwise_fma((f32x2){ sy.x, sy.x }, (f32x2){ w.x, w.y }, acc);
+    return __builtin_elementwise_fma((f32x2){ sy.y, sy.y }, (f32x2){ -w.y, w.x }, acc);
+}
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // e^{-j angle(c)} = conj(c)/|c| (np.exp(-1j*np.angle(c)) without atan2 / sincos); angle(0) = 0

@@ -482,14 +482,18 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
                 if (p == 0) hs[cur][j] = 0.0f;
                 __syncthreads();
             }
-            float sr = 0.0f, sz = 0.0f, sn = 0.0f;
+            // this lane's quarter of the three dot products as packed FMAs (even / odd k in the two halves of an accumulator pair): 3 KP / 2 instructions
+            // instead of 3 KP on the step's serial path
+            f32x2 ar = { 0.0f, 0.0f }, az = ar, an = ar;
             const float *hp = hs[cur] + p * KP;
 #pragma unroll
             for (int k = 0; k < KP; k += 4) {
                 const f32x4 hv = *(const f32x4 *)(hp + k);
-#pragma unroll
-                for (int q = 0; q < 4; q++) { sr += wr[k + q] * hv[q]; sz += wz[k + q] * hv[q]; sn += wn[k + q] * hv[q]; }
+                const f32x2 h0 = { hv[0], hv[1] }, h1 = { hv[2], hv[3] };
+                ar = __builtin_elementwise_fma((f32x2){ wr[k], wr[k + 1] }, h0, ar); az = __builtin_elementwise_fma((f32x2){ wz[k], wz[k + 1] }, h0, az); an = __builtin_elementwise_fma((f32x2){ wn[k], wn[k + 1] }, h0, an);
+                ar = __builtin_elementwise_fma((f32x2){ wr[k + 2], wr[k + 3] }, h1, ar); az = __builtin_elementwise_fma((f32x2){ wz[k + 2], wz[k + 3] }, h1, az); an = __builtin_elementwise_fma((f32x2){ wn[k + 2], wn[k + 3] }, h1, an);
             }
+            float sr = ar[0] + ar[1], sz = az[0] + az[1], sn = an[0] + an[1];
             sr += quad_dpp<QUAD_XOR1>(sr); sz += quad_dpp<QUAD_XOR1>(sz); sn += quad_dpp<QUAD_XOR1>(sn);
             sr += quad_dpp<QUAD_XOR2>(sr); sz += quad_dpp<QUAD_XOR2>(sz); sn += quad_dpp<QUAD_XOR2>(sn);
             const float g0 = gq[u];
@@ -606,18 +610,18 @@ __global__ __launch_bounds__(192) void k_ofdm_mod(const rd_tables *tab, const fl
     __syncthreads();
     float2 *out = tx + (size_t)b * tx_stride + (size_t)mf * RD_NMF;
     if (tid < RD_M) {
-        float2 acc[RD_NS + 1];
+        f32x2 acc[RD_NS + 1];
 #pragma unroll
-        for (int s = 0; s <= RD_NS; s++) acc[s] = make_float2(0.0f, 0.0f);
+        for (int s = 0; s <= RD_NS; s++) acc[s] = (f32x2){ 0.0f, 0.0f };
 #pragma unroll 6
         for (int c = 0; c < RD_NC; c++) {                 // one Winv load feeds the five symbols of the frame
             const float2 w = ld2(tab->Winv[c], tid);
 #pragma unroll
-            for (int s = 0; s <= RD_NS; s++) acc[s] = cadd(acc[s], cmul(sym[s][c], w));
+            for (int s = 0; s <= RD_NS; s++) acc[s] = idft_term(acc[s], sym[s][c], w);
         }
 #pragma unroll
         for (int s = 0; s <= RD_NS; s++) {
-            const float2 v = pa_limit(acc[s]);
+            const float2 v = pa_limit(make_float2(acc[s][0], acc[s][1]));
             out[s * RD_SYM + RD_NCP + tid] = v;
             if (tid >= RD_M - RD_NCP) out[s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
         }
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(192) void k_ofdm_mod_mp(const rd_tables *tab, const
     __shared__ float2 sym[RD_NS + 1][RD_NC];
     __shared__ float2 prevsym[RD_NC];
     __shared__ float2 fr[16 + RD_NMF];                    // [0, 16): tail of the previous frame, then this frame
-    __shared__ double red[2][192];
+    __shared__ double red[2][4];
     const int mf = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const float *zf = z + ((size_t)b * n_mf + mf) * RD_ZMF;
     if (tid < RD_NC) sym[0][tid] = make_float2(tab->P[tid] * tab->pilot_gain, 0.0f * tab->pilot_gain);
@@ -648,25 +652,25 @@ __global__ __launch_bounds__(192) void k_ofdm_mod_mp(const rd_tables *tab, const
     if (tid >= 128 && tid < 128 + RD_NC && mf > 0) { const int c = tid - 128; prevsym[c] = make_float2(zf[-RD_ZMF + 2 * (90 + c)], zf[-RD_ZMF + 2 * (90 + c) + 1]); }   // last data symbol of frame mf - 1
     __syncthreads();
     if (tid < RD_M) {
-        float2 acc[RD_NS + 1];
+        f32x2 acc[RD_NS + 1];
 #pragma unroll
-        for (int s = 0; s <= RD_NS; s++) acc[s] = make_float2(0.0f, 0.0f);
+        for (int s = 0; s <= RD_NS; s++) acc[s] = (f32x2){ 0.0f, 0.0f };
 #pragma unroll 6
         for (int c = 0; c < RD_NC; c++) {
             const float2 w = ld2(tab->Winv[c], tid);
 #pragma unroll
-            for (int s = 0; s <= RD_NS; s++) acc[s] = cadd(acc[s], cmul(sym[s][c], w));
+            for (int s = 0; s <= RD_NS; s++) acc[s] = idft_term(acc[s], sym[s][c], w);
         }
 #pragma unroll
         for (int s = 0; s <= RD_NS; s++) {
-            const float2 v = pa_limit(acc[s]);
+            const float2 v = pa_limit(make_float2(acc[s][0], acc[s][1]));
             fr[16 + s * RD_SYM + RD_NCP + tid] = v;
             if (tid >= RD_M - RD_NCP) fr[16 + s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
         }
     } else if (tid < RD_M + 16) {                          // samples 944..959 of the previous frame = the last 16 of its last symbol
         const int n = RD_M - 16 + (tid - RD_M);
         float2 a = make_float2(0.0f, 0.0f);
-        if (mf > 0) { for (int c = 0; c < RD_NC; c++) a = cadd(a, cmul(prevsym[c], ld2(tab->Winv[c], n))); a = pa_limit(a); }
+        if (mf > 0) { f32x2 ac = { 0.0f, 0.0f }; for (int c = 0; c < RD_NC; c++) ac = idft_term(ac, prevsym[c], ld2(tab->Winv[c], n)); a = pa_limit(make_float2(ac[0], ac[1])); }
         fr[tid - RD_M] = a;                                // frame 0: the signal starts here, nothing before it (chan_mp: i >= 16)
     }
     __syncthreads();
@@ -701,12 +705,11 @@ __global__ __launch_bounds__(192) void k_ofdm_mod_mp(const rd_tables *tab, const
         const float ax = hypotf(x.x, x.y), am = hypotf(m.x, m.y);
         s0 += (double)(ax * ax); s1 += (double)(am * am);
     }
-    red[0][tid] = s0; red[1][tid] = s1;
+    // frame sums: inside a wavefront by DPP, the three wavefronts' results through LDS (one barrier; the LDS tree this replaces had eight)
+    s0 = wave_sum_f64(s0); s1 = wave_sum_f64(s1);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = s1; }
     __syncthreads();
-    if (tid < 64) { red[0][tid] += red[0][tid + 64] + red[0][tid + 128]; red[1][tid] += red[1][tid + 64] + red[1][tid + 128]; }
-    __syncthreads();
-    for (int w = 32; w > 0; w >>= 1) { if (tid < w) { red[0][tid] += red[0][tid + w]; red[1][tid] += red[1][tid + w]; } __syncthreads(); }
-    if (tid == 0) { part[((size_t)b * n_mf + mf) * 2] = red[0][0]; part[((size_t)b * n_mf + mf) * 2 + 1] = red[1][0]; }
+    if (tid == 0) { part[((size_t)b * n_mf + mf) * 2] = (red[0][0] + red[0][1]) + red[0][2]; part[((size_t)b * n_mf + mf) * 2 + 1] = (red[1][0] + red[1][1]) + red[1][2]; }
 }
 extern "C" int rd_launch_ofdm_mod_mp(const rd_tables *tab, const float *z, void *tx, long tx_stride, int B, int n_mf, const void *G, void *mp, double *part, rd_stream_t s)
 {
