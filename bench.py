@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     args = ap.parse_args()
+    if args.pipeline > 3:                # HIP multiplexes a process's streams onto 4 hardware queues per device by default; streams that share one serialise
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     mode, child = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0, sys.argv[1:])
     if mode == "spawn":                  # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run; rank 0 of the child prints the line
