@@ -198,6 +198,7 @@ int main(int argc, char **argv)
     j.low_ratio = 800; doppler_taps(1.0, 10.0, j.taps);         /* MPP: 1 Hz Doppler spread, lowFs = 10 Hz (multipath_samples.m:13) */
     if (j.pipeline < 1) j.pipeline = 1;
     if (j.pipeline > 16) j.pipeline = 16;
+    if (j.pipeline > 3) setenv("GPU_MAX_HW_QUEUES", "8", 0);     /* HIP's default of 4 hardware queues per device makes more streams than that share a queue and serialise */
     j.flags = 0; j.blob = blob;
     rade_multi *m = rade_multi_open(blob, B * n_dev, j.n_mf, mask, j.flags);
     if (!m) return 1;
