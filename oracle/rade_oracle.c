@@ -673,9 +673,15 @@ static int arange_d(double start, double stop, double step, double *v, int maxn)
     return len;
 }
 
+/* diagnostic (tools/parity_sweep.py): how far the runner-up cell of the most recent refine() arg-max was below the winner, relative to the winner, and where it
+ * was -- the reference takes the FIRST maximum of float32 magnitudes of complex128 sums, so two cells within float32 rounding of each other are a tie that a
+ * different (equally valid) summation order resolves the other way */
+double orc_debug_refine_margin = 1.0; int orc_debug_refine_second_t = 0; double orc_debug_refine_second_f = 0.0;
+
 static void refine(const orc_c32 *rx, int *tmax, double *fmax, int t0, int t1, const double *fr, int nf)
 {   /* dsp.py:233-270; complex128 dot products rounded to complex64, |Dt1+Dt2| in float32 */
     float Dtmax = 0.0f; int tbest = *tmax; double fbest = *fmax;
+    float second = 0.0f; int tsec = *tmax; double fsec = *fmax;
     for (int fi = 0; fi < nf; fi++) {
         double w = 2.0 * PI_D * fr[fi] / 8000.0;
         c64d wp1[ORC_M], wp2[ORC_M];
@@ -693,9 +699,11 @@ static void refine(const orc_c32 *rx, int *tmax, double *fmax, int t0, int t1, c
             }
             orc_c32 s = caddf(c32((float)a.re, (float)a.im), c32((float)b.re, (float)b.im));
             float v = cabsf_(s);
-            if (v > Dtmax) { Dtmax = v; tbest = t; fbest = fr[fi]; }
+            if (v > Dtmax) { second = Dtmax; tsec = tbest; fsec = fbest; Dtmax = v; tbest = t; fbest = fr[fi]; }
+            else if (v > second) { second = v; tsec = t; fsec = fr[fi]; }
         }
     }
+    orc_debug_refine_margin = Dtmax > 0.0f ? ((double)Dtmax - (double)second) / (double)Dtmax : 1.0; orc_debug_refine_second_t = tsec; orc_debug_refine_second_f = fsec;
     *tmax = tbest; *fmax = fbest;
 }
 

@@ -30,6 +30,24 @@ __device__ __forceinline__ float2 cmul_nc(float2 a, float2 b)
     return make_float2(rr - ii, ri + ir);
 }
 
+// Double-precision expressions whose LAST BIT reaches a decision: the receiver's frequency estimate fmax = 0.9 fmax + 0.1 fhat and the grid value
+// fhat = start + i delta are doubles in the reference (radae_rxe.py:202-206), and the next call's grid np.arange(fmax - 1, fmax + 1, 0.1) has 20 or 21
+// points depending on whether (fmax + 1) - (fmax - 1) rounds to 2 or to 2 + 4e-16.  Contracted into an FMA (one rounding instead of two) fmax differs
+// from the reference's in the last bit now and then, the device searched 20 frequencies where the reference searches 21, and when the 21st won the two
+// parted for good (two of 1248 random utterances, tools/parity_sweep.py seeds 99 / 12345).  These forms round like numpy and the C oracle.
+__device__ __forceinline__ double dlin2_nc(double a, double x, double b, double y)
+{
+#pragma clang fp contract(off)
+    const double p = a * x, q = b * y;
+    return p + q;
+}
+__device__ __forceinline__ double dgrid_nc(double start, int i, double delta)
+{
+#pragma clang fp contract(off)
+    const double p = (double)i * delta;
+    return start + p;
+}
+
 // one term of the modulator's 30-term IDFT as two packed FMAs (v_pk_fma_f32: both components of a sample in one instruction; the scalar form,
 // 720 FMAs per thread, was half of k_ofdm_mod_mp's time): acc += s.re (w.re, w.im); acc += s.im (-w.im, w.re).  Every place that synthesises a
 // transmit sample uses this one form, so the same sample comes out the same bits wherever it is computed.

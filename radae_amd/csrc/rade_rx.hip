@@ -801,7 +801,7 @@ __device__ __forceinline__ void refine2_tables(RxShared2 *sh, int k, double fsta
     const double delta = (fstart + fstep) - fstart;
     if (k < 0 || k >= 3 * nf) return;
     const int which = k / nf, fi = k - which * nf;
-    const double w = 2.0 * PI_D * (fstart + fi * delta) / 8000.0;
+    const double w = 2.0 * PI_D * dgrid_nc(fstart, fi, delta) / 8000.0;
     const double arg = which == 0 ? -w : (which == 1 ? -w * RD_NMF : -w * 80.0);
     double sn, cs; sincos(arg, &sn, &cs);
     double2 *dstp = which == 0 ? sh->rtw : (which == 1 ? sh->rrot80 : sh->rt80);
@@ -811,11 +811,11 @@ __device__ __forceinline__ void refine2_tables_sync(RxShared2 *sh, int k, double
 {
     const int nf = (int)ceil((fstop - fstart) / fstep);
     const double delta = (fstart + fstep) - fstart;
-    const double wc = 0.5 * (2.0 * PI_D * fstart / 8000.0 + 2.0 * PI_D * (fstart + (nf - 1) * delta) / 8000.0);
+    const double wc = 0.5 * (2.0 * PI_D * fstart / 8000.0 + 2.0 * PI_D * dgrid_nc(fstart, nf - 1, delta) / 8000.0);
     if (k < 0 || k > 52) return;
     const int kf = k < 24 ? k : k - 24;
     if (k < 48 && kf >= nf) return;
-    const double w = 2.0 * PI_D * (fstart + kf * delta) / 8000.0, dw = w - wc;
+    const double w = 2.0 * PI_D * dgrid_nc(fstart, kf, delta) / 8000.0, dw = w - wc;
     const double arg = k < 24 ? -w * RD_NMF : (k < 48 ? -dw * 79.5 : (k < 52 ? -wc * 40.0 * (k - 48) : -wc));
     double sn, cs; sincos(arg, &sn, &cs);
     const double2 v = make_double2(cs, sn);
@@ -956,7 +956,7 @@ __device__ void rx2_refine(RxShared2 *sh, const double *vmg, int *tmax, double *
     PH2(30);
     block_argmax2(sh, best, bf, bt);
     PH2(31);
-    if (best > 0.0f) { *tmax = t0 + bt; *fmax = fstart + bf * delta; }
+    if (best > 0.0f) { *tmax = t0 + bt; *fmax = dgrid_nc(fstart, bf, delta); }      // (two roundings, like np.arange's elements: rade_devutil.h)
 }
 
 // rx_buf and the |Dt| row sums from the stream's HBM record into LDS: every load of a thread requested before the first store (as a plain loop
@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
                 }
                 if (CENSUS(16)) { int t_ = tm; double f_ = fm; rx2_refine(sh, a.vm, &t_, &f_, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true); __syncthreads(); }
                 rx2_refine(sh, a.vm, &tnew, &fhat, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true);
-                tm_ref = tnew; fm_ref = 0.9 * fm + 0.1 * fhat;
+                tm_ref = tnew; fm_ref = dlin2_nc(0.9, fm, 0.1, fhat);                  // radae_rxe.py:206, rounded like the reference's doubles (rade_devutil.h)
                 if (tid == 0) { S->tmax = tm_ref; S->fmax = fm_ref; S->lcg = (uint32_t)sh->redi[15]; }
             }
             PH2(9);

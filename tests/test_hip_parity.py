@@ -429,46 +429,62 @@ def test_rx_output_capacity_is_respected(Engine, torch_dev, golden, monkeypatch)
     eng.close()
 
 
-def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_model, monkeypatch):
-    """tools/parity_sweep.py as a test: random channel (AWGN / MPP / MPD / MPG), Eb/No -1..12 dB, offset +-40 Hz, noise prefix; the oracle makes
-    the received samples, both receivers consume exactly those.  Every per-call discrete output must be equal and the features within 1e-4 RMS --
-    except for the documented refine() near-tie: all discrete outputs equal, fmax apart by less than 0.05 Hz because two 0.1 Hz bins
-    had complex64 magnitudes equal to within the rounding of the complex128 sums; at most a few such cases are tolerated, no other mismatch."""
-    import torch
+def _random_utterance(oracle, oracle_model, seed, chan, eb, fo, n_mf=24):
+    """one utterance of tools/parity_sweep.py: the oracle's transmitter and channel make the received samples"""
     from radae_amd.channel_tools import multipath_g, synth_features
     from radae_amd.engine import sigma_from_EbNodB
+    r2 = np.random.default_rng(seed)
+    feats = synth_features(seed, n_mf * 12); n_sig = n_mf * 960
+    G = multipath_g(chan, 8000, n_sig, seed + 1) if chan != "awgn" else None
+    n_pre = int(r2.integers(1000, 9000)); n_tot = n_pre + n_sig + 2304
+    noise = ((r2.standard_normal(n_tot) + 1j * r2.standard_normal(n_tot)) / np.sqrt(2)).astype(np.complex64)
+    sigma = sigma_from_EbNodB(eb)
+    tx = oracle.Tx(oracle_model)
+    sig = np.concatenate([tx.frame(feats[12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
+    r, fin = oracle.channel(sig, G, noise[n_pre:n_pre + n_sig], sigma, fo)
+    e = oracle.channel_eoo(tx.eoo(), noise[n_pre + n_sig:n_pre + n_sig + 1152], sigma, fo, 0.0, fin)
+    return np.concatenate([sigma * noise[:n_pre], r, e, sigma * noise[-1152:]]).astype(np.complex64)
+
+
+def _receiver_vs_oracle(Engine, torch_dev, oracle, oracle_model, full):
+    """both receivers on the same samples -> (discrete outputs equal, fmax of every call the same double, features within 1e-4 RMS)"""
+    import torch
+    d = oracle.run_rx_stream(oracle_model, full)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
+    fo_dev, st, _ = eng.rx(torch.tensor(full[None], device=torch_dev))
+    t = eng.rx_trace(0); nv = st[0].n_valid
+    eng.close()
+    disc = all(np.array_equal(t[k], d[k]) for k in INT_KEYS) and nv == len(d["features_out"])
+    fmax_eq = disc and np.array_equal(t["fmax"], d["fmax"])
+    feat_ok = disc and (nv == 0 or rms(fo_dev.cpu().numpy()[0, :nv], d["features_out"]) < 1e-4)
+    return disc, fmax_eq, feat_ok
+
+
+def test_randomised_receiver_sweep_vs_oracle(Engine, torch_dev, oracle, oracle_model, monkeypatch):
+    """tools/parity_sweep.py as a test: random channel (AWGN / MPP / MPD / MPG), Eb/No -1..12 dB, offset +-40 Hz, noise prefix; the oracle makes
+    the received samples, both receivers consume exactly those.  Every per-call discrete output must be equal, the frequency estimate of every call
+    the SAME DOUBLE, and the features within 1e-4 RMS.  (Rounds 2-3 tolerated "refine() near-ties" here, three per cent of random utterances whose fmax
+    moved by a grid step: they were the device's FMA-contracted fmax update, see test_refine_grid_length_follows_the_reference_doubles.)"""
     rng = np.random.default_rng(2027)
-    n_mf, bad, ties, N = 24, [], 0, 32
+    bad, N = [], 32
     for case in range(N):
         seed = int(rng.integers(1, 1 << 30)); eb = float(rng.uniform(-1.0, 12.0)); fo = float(rng.uniform(-40.0, 40.0))
         chan = ["awgn", "mpp", "mpd", "mpg"][int(rng.integers(0, 4))]
-        r2 = np.random.default_rng(seed)
-        feats = synth_features(seed, n_mf * 12); n_sig = n_mf * 960
-        G = multipath_g(chan, 8000, n_sig, seed + 1) if chan != "awgn" else None
-        n_pre = int(r2.integers(1000, 9000)); n_tot = n_pre + n_sig + 2304
-        noise = ((r2.standard_normal(n_tot) + 1j * r2.standard_normal(n_tot)) / np.sqrt(2)).astype(np.complex64)
-        sigma = sigma_from_EbNodB(eb)
-        tx = oracle.Tx(oracle_model)
-        sig = np.concatenate([tx.frame(feats[12 * k:12 * k + 12].ravel())[0] for k in range(n_mf)])
-        r, fin = oracle.channel(sig, G, noise[n_pre:n_pre + n_sig], sigma, fo)
-        e = oracle.channel_eoo(tx.eoo(), noise[n_pre + n_sig:n_pre + n_sig + 1152], sigma, fo, 0.0, fin)
-        full = np.concatenate([sigma * noise[:n_pre], r, e, sigma * noise[-1152:]]).astype(np.complex64)
-        d = oracle.run_rx_stream(oracle_model, full)
-        eng = Engine(1, max_tx_mf=1, rx_trace_calls=64)
-        fo_dev, st, _ = eng.rx(torch.tensor(full[None], device=torch_dev))
-        t = eng.rx_trace(0); nv = st[0].n_valid
-        eng.close()
-        disc = all(np.array_equal(t[k], d[k]) for k in INT_KEYS) and nv == len(d["features_out"])
-        feat_ok = disc and (nv == 0 or rms(fo_dev.cpu().numpy()[0, :nv], d["features_out"]) < 1e-4)
-        if feat_ok:
-            continue
-        dfm = float(np.abs(t["fmax"] - d["fmax"]).max()) if disc else -1.0
-        if disc and 0.0 < dfm < 0.0501:
-            ties += 1
-        else:
-            bad.append((case, seed, chan, eb, fo))
+        disc, fmax_eq, feat_ok = _receiver_vs_oracle(Engine, torch_dev, oracle, oracle_model, _random_utterance(oracle, oracle_model, seed, chan, eb, fo))
+        if not (disc and fmax_eq and feat_ok):
+            bad.append((case, seed, chan, eb, fo, disc, fmax_eq, feat_ok))
     assert not bad, bad
-    assert ties <= 3, ties
+
+
+@pytest.mark.parametrize("seed,chan,eb,fo", [(927382851, "awgn", 1.8613418150778065, 7.307787791453919), (319558060, "mpp", 0.5046517495824037, 7.847441899881964)])
+def test_refine_grid_length_follows_the_reference_doubles(Engine, torch_dev, oracle, oracle_model, seed, chan, eb, fo):
+    """Two utterances of tools/parity_sweep.py (sweep seeds 99 / 12345) on which the receivers parted in round 4: in the synchronised state the reference
+    searches np.arange(fmax - 1, fmax + 1, 0.1), which has 20 or 21 points depending on the LAST BIT of the double fmax = 0.9 fmax + 0.1 fhat
+    (radae_rxe.py:202-206).  The device evaluated that update (and fhat = start + i delta) as FMAs -- one rounding instead of two --, now and then had a
+    20-point grid where the reference had 21, and on these two utterances the 21st point won (timing estimate off by 1 resp. 6 samples from that call on,
+    loss of sync later).  The same contraction was behind every "refine() near-tie" of rounds 2-3.  Now: every discrete output and every fmax bit-equal."""
+    disc, fmax_eq, feat_ok = _receiver_vs_oracle(Engine, torch_dev, oracle, oracle_model, _random_utterance(oracle, oracle_model, seed, chan, eb, fo))
+    assert disc and fmax_eq and feat_ok, (disc, fmax_eq, feat_ok)
 
 
 def test_streams_are_independent_and_ragged(Engine, torch_dev, golden, monkeypatch):
