@@ -462,7 +462,7 @@ def parity_leg(feats_np, fo, st, rx, blob, local, B):
     torch.cuda.synchronize()
     keys = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
     res = {"streams": idx, "discrete_equal": True, "timed_equals_replay_bitwise": True, "feat_rms_max": 0.0, "loss_gpu": [], "loss_oracle": [], "loss_delta_max": 0.0,
-           "refine_near_ties": 0, "calls_compared": 0, "decoded_modem_frames": []}
+           "refine_near_ties": 0, "fmax_bit_equal": True, "calls_compared": 0, "decoded_modem_frames": []}
     for j, b in enumerate(idx):
         d = O.run_rx_stream(m, rx_host[j])
         t = e2.rx_trace(j)
@@ -476,9 +476,9 @@ def parity_leg(feats_np, fo, st, rx, blob, local, B):
         if not ok:
             res["discrete_equal"] = False
             continue
-        dfm = float(np.abs(t["fmax"] - d["fmax"]).max()) if len(d["fmax"]) else 0.0
-        if 1e-9 < dfm < 0.0501:
-            res["refine_near_ties"] += 1          # a 0.1 Hz refine() bin pair equal to within rounding, resolved the other way
+        if not np.array_equal(t["fmax"], d["fmax"]):
+            res["fmax_bit_equal"] = False          # the frequency estimate of every call is the same double on both sides since round 4
+            res["refine_near_ties"] += 1           # (rounds 2-3 counted fmax moved by a grid step here and tolerated it: it was a device bug)
         if nvb:
             res["feat_rms_max"] = max(res["feat_rms_max"], float(np.sqrt(np.mean((f_timed - d["features_out"]) ** 2))))
             lg, _ = find_loss(feats_np[b], f_timed.reshape(-1, 36)); lo, _ = find_loss(feats_np[b], d["features_out"].reshape(-1, 36))
