@@ -225,9 +225,18 @@ typedef struct {
     int B;
     int clip;                                    /* 1: magnitude limited to 1 after the filter (radae_txe.py:132) */
     int advance;                                 /* 1: every sample is consumed -- leave the state complex_bpf would hold (the receiver kernel does that itself, by what it consumed) */
+    int *zero_acc, *zero_progress;               /* optional: [B][4] / [4] ints that k_bpf_chain clears on its way (the receiver's per-invocation counters: two memsets less in the stream) */
 } rd_bpf_args;
 int rd_launch_bpf(const rd_bpf_args *a, rd_stream_t s);
-int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds_dev, double foff_err, int B, rd_stream_t s);
+/* start-of-utterance state of every stream in ONE launch (one workgroup per stream): the receiver record (radae_rxe.py:128-142) when st != NULL, and any of
+ * the GRU states [5][B][H] / conv history rows that are given (NULL = leave alone) */
+typedef struct {
+    rd_rx_stream *st; const unsigned *seeds; double foff_err;
+    float *dec_h; float *dec_x; long dec_x_sb;      /* [5][B][96]; history row of stream b at dec_x + b * dec_x_sb, RD_DEC_W floats */
+    float *enc_h; float *enc_x; long enc_x_sb;      /* [5][B][64]; the two history rows of stream b at enc_x + b * enc_x_sb, 2 * RD_ENC_W floats */
+    int B;
+} rd_reset_args;
+int rd_launch_reset(const rd_reset_args *a, rd_stream_t s);
 
 /* ---- one core encoder / decoder step of ONE stream as one launch (rade_core_step.hip; include/rade_core.h) ----
  * A layer = row-major W[N][K] (K a multiple of 8, zero padded): wq != NULL: ONE binary16 plane of the integers q of an int8 layer

@@ -173,28 +173,33 @@ static int upload_lin(dev_lin *d, const float *w, const float *b, const float *r
     return (d->wp && (!b || d->bias)) ? 0 : -1;
 }
 
-static void rx_reset_on(rade_batch *h, void *stream)
+/* start-of-utterance state, ONE launch (k_batch_reset) for the directions asked for; the trace buffers and the Tx filter state only where they exist */
+static void reset_on(rade_batch *h, int tx, int rx, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    rd_launch_rx_reset(h->rx_st, h->d_lcg_seeds, (h->flags & RADE_FOFF_TEST) ? 10.0 : 0.0 /* rade_api.c:263-264 */, h->B, st);
-    hipMemsetAsync(h->dec_h[0], 0, sizeof(float) * 5 * h->B * 96, st);                         /* the five layers' states are one allocation */
-    /* only a stream's history row has to start from zero: every other row of dec_x is written before it is read */
-    hipMemset2DAsync(h->dec_x, sizeof(float) * (size_t)(1 + h->dec_rows) * RD_DEC_W, 0, sizeof(float) * RD_DEC_W, h->B, st);
-    if (h->trace) { hipMemsetAsync(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap, st); hipMemsetAsync(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF, st); }
-}
-static void tx_reset_on(rade_batch *h, void *stream)
-{
-    hipStream_t st = (hipStream_t)stream;
-    if (h->tx_bpf) hipMemcpyAsync(h->tx_bpf, h->tx_bpf_init, sizeof(rd_bpf_state) * h->B, hipMemcpyDeviceToDevice, st);
-    hipMemsetAsync(h->enc_h[0], 0, sizeof(float) * 5 * h->B * 64, st);
-    /* the two history rows of each stream (conv taps before the first frame); rows 2.. are written layer by layer before they are read */
-    hipMemset2DAsync(h->enc_x, sizeof(float) * (size_t)(2 + h->Tcap) * RD_ENC_W, 0, sizeof(float) * 2 * RD_ENC_W, h->B, st);
+    rd_reset_args r;
+    memset(&r, 0, sizeof r);
+    r.B = h->B;
+    if (rx) {
+        r.st = h->rx_st; r.seeds = h->d_lcg_seeds; r.foff_err = (h->flags & RADE_FOFF_TEST) ? 10.0 : 0.0;   /* rade_api.c:263-264 */
+        r.dec_h = h->dec_h[0];                             /* the five layers' states are one allocation */
+        /* only a stream's history row has to start from zero: every other row of dec_x is written before it is read */
+        r.dec_x = h->dec_x; r.dec_x_sb = (long)(1 + h->dec_rows) * RD_DEC_W;
+        if (h->trace) { hipMemsetAsync(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap, st); hipMemsetAsync(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF, st); }
+    }
+    if (tx) {
+        if (h->tx_bpf) hipMemcpyAsync(h->tx_bpf, h->tx_bpf_init, sizeof(rd_bpf_state) * h->B, hipMemcpyDeviceToDevice, st);
+        r.enc_h = h->enc_h[0];
+        /* the two history rows of each stream (conv taps before the first frame); rows 2.. are written layer by layer before they are read */
+        r.enc_x = h->enc_x; r.enc_x_sb = (long)(2 + h->Tcap) * RD_ENC_W;
+    }
+    rd_launch_reset(&r, st);
 }
 
-void rade_batch_rx_reset(rade_batch *h) { ON_DEV(h); rx_reset_on(h, NULL); hipDeviceSynchronize(); }
+void rade_batch_rx_reset(rade_batch *h) { ON_DEV(h); reset_on(h, 0, 1, NULL); hipDeviceSynchronize(); }
 
 /* stream-ordered reset of both directions (start of a new batch of utterances) */
-void rade_batch_reset(rade_batch *h, void *stream) { ON_DEV(h); tx_reset_on(h, stream); rx_reset_on(h, stream); }
+void rade_batch_reset(rade_batch *h, void *stream) { ON_DEV(h); reset_on(h, 1, 1, stream); }
 
 void rade_batch_rx_set_lcg(rade_batch *h, const unsigned *seeds_host)
 {
@@ -204,7 +209,7 @@ void rade_batch_rx_set_lcg(rade_batch *h, const unsigned *seeds_host)
     rade_batch_rx_reset(h);
 }
 
-void rade_batch_tx_reset(rade_batch *h) { ON_DEV(h); tx_reset_on(h, NULL); hipDeviceSynchronize(); }
+void rade_batch_tx_reset(rade_batch *h) { ON_DEV(h); reset_on(h, 1, 0, NULL); hipDeviceSynchronize(); }
 
 rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_batch_config *cfg)
 {
@@ -314,8 +319,9 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     for (int l = 1; l < 5; l++) { h->enc_h[l] = h->enc_h[0] + (size_t)l * B * 64; h->dec_h[l] = h->dec_h[0] + (size_t)l * B * 96; }
     h->rx_st = dev_zeros(sizeof(rd_rx_stream) * B);
     h->rx_round = dev_zeros(sizeof(rd_rx_round) * B);
-    h->rx_avail = dev_zeros(sizeof(int) * B); h->rx_acc = dev_zeros(sizeof(int) * B * 4); h->rx_progress = dev_zeros(sizeof(int) * 4);
-    h->rx_status = dev_zeros(sizeof(int) * B * 4);
+    h->rx_avail = dev_zeros(sizeof(int) * B); /* progress word, per-stream counters and status in ONE block, in the order of the host copy (rade_batch_rx: one transfer back per invocation) */
+    h->rx_progress = dev_zeros(sizeof(int) * (8 + B * 8));
+    if (h->rx_progress) { h->rx_acc = h->rx_progress + 8; h->rx_status = h->rx_progress + 8 + 4 * B; }
     h->wg_cycles = dev_zeros(sizeof(long long) * B);
     h->zrows = dev_zeros(sizeof(float) * B * DR * RD_LATENT);
     h->dec_x = dev_zeros(sizeof(float) * B * (1 + DR) * RD_DEC_W);
@@ -382,8 +388,8 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     ON_DEV(h);
-    void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail, h->rx_acc,
-                     h->rx_progress, h->rx_status, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
+    void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail,
+                     h->rx_progress /* + rx_acc, rx_status */, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -738,10 +744,12 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
         ba.state = &h->rx_st->bpf; ba.state_stride = sizeof(rd_rx_stream); ba.len0 = &h->rx_st->nin; ba.len0_stride = sizeof(rd_rx_stream); ba.avail = h->rx_avail;
         ba.tab = h->d_tab; ba.bpf16 = h->bpf16; ba.x = rx_dev; ba.x_stride = rx_stride; ba.y = h->rx_filt; ba.y_stride = h->filt_cap;
         ba.chain = h->bpf_chain; ba.chain_stride = h->chain_stride; ba.n_blocks = n_blocks; ba.B = B;
+        ba.zero_acc = h->rx_acc; ba.zero_progress = h->rx_progress;        /* the invocation's counters are cleared by the pre-pass's first kernel */
         if (rd_launch_bpf(&ba, st)) goto fail;
     }
     PROF_END(h, st, RADE_PROF_BPF, 8.0 * 101.0 * (double)B * max_avail);
-    CHK(hipMemsetAsync(h->rx_acc, 0, sizeof(int) * B * 4, st));
+    int counters_clear = n_blocks > 0;
+    if (!counters_clear) CHK(hipMemsetAsync(h->rx_acc, 0, sizeof(int) * B * 4, st));
     rd_sync_args sa;
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.rxf = h->rx_filt; sa.rxf_stride = h->filt_cap; sa.bpf16 = h->bpf16; sa.bpf_chain = h->bpf_chain; sa.chain_stride = h->chain_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
@@ -753,16 +761,13 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only
      * continues when a stream ran into the per-launch call limit */
     for (;;) {
-        CHK(hipMemsetAsync(h->rx_progress, 0, sizeof(int) * 4, st));
+        if (!counters_clear) CHK(hipMemsetAsync(h->rx_progress, 0, sizeof(int) * 4, st));
+        counters_clear = 0;
         PROF_BEGIN(h, st);
         if (rd_launch_rx_sync(&sa, st)) goto fail;
         PROF_END(h, st, RADE_PROF_SYNC, 0.0);
-        /* progress word and (normally final) per-stream results come back in one round trip */
-        CHK(hipMemcpyAsync(hs, h->rx_progress, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-        if (status_host) {
-            CHK(hipMemcpyAsync(hs + 8, h->rx_acc, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
-            CHK(hipMemcpyAsync(hs + 8 + 4 * B, h->rx_status, sizeof(int) * B * 4, hipMemcpyDeviceToHost, st));
-        }
+        /* progress word and (normally final) per-stream results come back in one transfer (one device block in the host copy's order) */
+        CHK(hipMemcpyAsync(hs, h->rx_progress, sizeof(int) * (status_host ? 8 + 8 * (size_t)B : 4), hipMemcpyDeviceToHost, st));
         if (sync_blocking_now()) { CHK(hipEventRecord(h->ev_block, st)); CHK(hipEventSynchronize(h->ev_block)); h->n_sync_block++; }
         else { CHK(hipStreamSynchronize(st)); h->n_sync_spin++; }
         if (hs[0] == 0 || hs[1] == 0) break;    /* nothing done, or no stream stopped at the per-launch limit */

@@ -435,6 +435,11 @@ extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
 template <int H>
 __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
 {
+    // a latency chain (one barrier per step, a handful of instructions between two of them) that shares its SIMDs with receiver wavefronts of other batches:
+    // at the default priority every one of its instructions queues behind theirs (72 us per launch alone, 200 us in the pipelined bench); raised, the
+    // recurrence runs close to its own latency and takes few issue slots from anybody (same-box A/B: +1.6 .. +3.3 % frames/s; the GEMM / modulator / channel
+    // kernels, which are throughput-bound, gained nothing from the same treatment)
+    __builtin_amdgcn_s_setprio(3);
     constexpr int KP = H / 4;                       // k range per lane
     __shared__ __attribute__((aligned(16))) float hs[2][H];   // double-buffered so one barrier per step suffices
     __shared__ int rst[RD_DEC_ROWS_MAX];            // reset flags are only used by the decoder rounds (T <= 384)
@@ -534,6 +539,7 @@ extern "C" int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s)
 // =====================================================================================================
 __global__ void k_enc_pack(const float *features, float *xin, int B, int T)
 {   // model19 only: 4 x (20 features + aux symbol -1) padded 84 -> 88
+    __builtin_amdgcn_s_setprio(3);
     const long n = (long)B * T * RD_ENC_IN;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % RD_ENC_IN); const long bt = i / RD_ENC_IN;
@@ -571,6 +577,7 @@ extern "C" int rd_launch_pad_rows(const float *src, float *dst, long R, int K, i
 // destination overlap when Tb < nhist, so every thread reads all its elements before any write.
 __global__ __launch_bounds__(256) void k_carry_rows(float *x, int Tcap, int W, int nhist, int T, const int *n_rows)
 {
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x;
     const int Tb = n_rows ? n_rows[b] : T;
     if (Tb <= 0) return;
@@ -820,6 +827,7 @@ __device__ __forceinline__ double chan_phase_acc(int i, float f0, float df_dt)
 // additions, powf and a double-precision sincos while 255 threads wait -- this was a third of that kernel's time.
 __global__ __launch_bounds__(64) void k_chan_gain(rd_chan_args a, const double *part, int n_part, float *gf)
 {
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
     double p0 = 0.0, p1 = 0.0;

@@ -5,7 +5,7 @@
 //   k_rx_sync2    acquisition (detect_pilots / refine / check_pilots, dsp.py:178-320), sync state machine, frequency correction, OFDM demod +
 //                 3-pilot LS EQ (dsp.py:418-526), the CoreDecoder stage (radae_base.py:358-430) and UW accounting (rade_api.c:480-513): 256 threads
 //                 and at most 80 KB of LDS per stream, so that two streams share a CU
-//   k_rx_reset    radae_rxe.py:128-142
+//   k_batch_reset radae_rxe.py:128-142 (and the encoder / decoder start-of-utterance state, one launch)
 //
 // Rounds 2-3 carried a second receiver kernel (k_rx_sync: 512 threads, one stream per CU) that this one was forked from; it is gone: one
 // receiver, every fix lands once.
@@ -1782,22 +1782,35 @@ __global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
 }
 
 
-// (re)initialise every stream's receiver state on the device (radae_rxe.py:128-142)
-__global__ __launch_bounds__(256) void k_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err)
+// start-of-utterance state of stream blockIdx.x in one launch: the receiver record (radae_rxe.py:128-142), the decoder's / encoder's GRU states and conv
+// history rows -- whichever are given.  (Rounds 1-4 issued a kernel + two memsets + two 2-D memsets per reset: five launches of a batch's stream, each of which
+// waits for a free slot beside the other batches' receiver workgroups.)
+__global__ __launch_bounds__(256) void k_batch_reset(rd_reset_args a)
 {
-    rd_rx_stream *s = st + blockIdx.x;
-    float *raw = (float *)s;
-    for (int i = threadIdx.x; i < (int)(sizeof(rd_rx_stream) / 4); i += blockDim.x) raw[i] = 0.0f;
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.st) {
+        rd_rx_stream *s = a.st + b;
+        float2 *raw = (float2 *)s;
+        static_assert(sizeof(rd_rx_stream) % 8 == 0, "rd_rx_stream is cleared in 8-byte pieces");
+        for (int i = tid; i < (int)(sizeof(rd_rx_stream) / 8); i += 256) raw[i] = make_float2(0.0f, 0.0f);
+    }
+    if (a.dec_h) for (int i = tid; i < 5 * 96; i += 256) a.dec_h[((size_t)(i / 96) * a.B + b) * 96 + i % 96] = 0.0f;
+    if (a.dec_x) for (int i = tid; i < RD_DEC_W; i += 256) a.dec_x[(size_t)b * a.dec_x_sb + i] = 0.0f;
+    if (a.enc_h) for (int i = tid; i < 5 * 64; i += 256) a.enc_h[((size_t)(i / 64) * a.B + b) * 64 + i % 64] = 0.0f;
+    if (a.enc_x) for (int i = tid; i < 2 * RD_ENC_W; i += 256) a.enc_x[(size_t)b * a.enc_x_sb + i] = 0.0f;
+    if (!a.st) return;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        s->state = ST_SEARCH; s->nin = RD_NMF; s->mf = 1; s->bpf.mem_len = 100; s->lcg = seeds ? seeds[blockIdx.x] : 1u;
-        s->rx_phase[0] = 1.0; s->rx_theta = 0.0; s->bpf.phase[0] = 1.0f; s->foff_err = foff_err;
+    if (tid == 0) {
+        rd_rx_stream *s = a.st + b;
+        s->state = ST_SEARCH; s->nin = RD_NMF; s->mf = 1; s->bpf.mem_len = 100; s->lcg = a.seeds ? a.seeds[b] : 1u;
+        s->rx_phase[0] = 1.0; s->rx_theta = 0.0; s->bpf.phase[0] = 1.0f; s->foff_err = a.foff_err;
     }
 }
-extern "C" int rd_launch_rx_reset(rd_rx_stream *st, const unsigned *seeds, double foff_err, int B, rd_stream_t s)
+extern "C" int rd_launch_reset(const rd_reset_args *a, rd_stream_t s)
 {
-    if (B <= 0) return 0;
-    hipLaunchKernelGGL(k_rx_reset, dim3(B), dim3(256), 0, (hipStream_t)s, st, seeds, foff_err);
+    if (a->B <= 0) return 0;
+    hipLaunchKernelGGL(k_batch_reset, dim3(a->B), dim3(256), 0, (hipStream_t)s, *a);
     return (int)hipGetLastError();
 }
 
@@ -1809,8 +1822,13 @@ __device__ __forceinline__ int bpf_avail_of(const rd_bpf_args &a, int b) { retur
 // as complex_bpf does from call to call; also resets the stream's off-grid flag (a new invocation starts on the grid)
 __global__ __launch_bounds__(64) void k_bpf_chain(rd_bpf_args a)
 {
+    __builtin_amdgcn_s_setprio(3);                         // a serial chain of ~100 steps on one thread per stream: latency, not throughput
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= a.B) return;
+    if (a.zero_acc) {                                      // the receiver's per-invocation counters (rade_batch_rx)
+        ((int4 *)a.zero_acc)[b] = make_int4(0, 0, 0, 0);
+        if (b == 0) *(int4 *)a.zero_progress = make_int4(0, 0, 0, 0);
+    }
     rd_bpf_state *s = bpf_state_of(a, b);
     float2 *c = (float2 *)a.chain + (size_t)b * a.chain_stride;
     const int nin0 = bpf_len0_of(a, b), av = bpf_avail_of(a, b);

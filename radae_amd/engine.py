@@ -319,9 +319,11 @@ class BatchEngine:
             arr = (C.c_uint * self.B)(*[int(s) for s in lcg_seeds])
             self.lib.rade_batch_rx_set_lcg(self.h, arr)
 
-    def rx(self, rx, n_avail=None, max_calls: int = 1 << 20, features_out=None):
+    def rx(self, rx, n_avail=None, max_calls: int = 1 << 20, features_out=None, eoo_out=None):
         """rx complex64 [B, N] holding each stream's not-yet-consumed samples.  Returns
-        (features [B, cap, 432], status list[RxStatus], eoo [B, 180])."""
+        (features [B, cap, 432], status list[RxStatus], eoo [B, 180]).  features_out / eoo_out: caller-owned device buffers (as a C host passes
+        them: rows beyond status.n_valid, and the EOO bits of a stream without status.has_eoo, keep whatever they held); without them fresh zeroed
+        ones are allocated per call."""
         import torch
         assert rx.is_cuda and rx.dtype == torch.complex64 and rx.is_contiguous() and rx.shape[0] == self.B
         N = rx.shape[1]
@@ -333,7 +335,8 @@ class BatchEngine:
         # once it has filled its rows, so a short buffer never makes the kernel write into the next stream's region
         assert features_out.is_cuda and features_out.dtype == torch.float32 and features_out.is_contiguous() and features_out.dim() == 3 \
             and features_out.shape[0] == self.B and features_out.shape[1] >= 1 and features_out.shape[2] == FEAT_MF
-        eoo = torch.zeros((self.B, NEOO_BITS), dtype=torch.float32, device=rx.device)
+        eoo = eoo_out if eoo_out is not None else torch.zeros((self.B, NEOO_BITS), dtype=torch.float32, device=rx.device)
+        assert eoo.is_cuda and eoo.dtype == torch.float32 and eoo.is_contiguous() and tuple(eoo.shape) == (self.B, NEOO_BITS)
         status = (RxStatus * self.B)()
         r = self.lib.rade_batch_rx(self.h, rx.data_ptr(), N, avail.ctypes.data_as(C.POINTER(C.c_int)), max_calls, features_out.data_ptr(),
                                    features_out.shape[1] * FEAT_MF, eoo.data_ptr(), status, _stream_ptr())
