@@ -279,24 +279,35 @@ __global__ __launch_bounds__(64) void k_gemm16p(rd_gemm_args a)
     fetch(0, 0); fetch(1, 1);
 #pragma unroll 1
     for (int kb = 0; kb < nkb; kb += 2) { block(0, kb + 2); block(1, kb + 3); }
+    // epilogue: a lane's rows once per row tile (tile row -> (stream, step) by ONE division per wavefront and carries, the row's output pointer), then the
+    // column tiles.  (Rounds 1-4 divided by T for every one of the 48 elements of a lane: a third of a short layer's instructions.)
+    const int cl0 = nt0 * 32 + (lane & 31);
+    float bias[NT], scl[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int col = min(cl0 + 32 * i, a.N - 1);
+        bias[i] = a.bias ? a.bias[col] : 0.0f;
+        scl[i] = SINGLE ? a.Wscale[col] * 0x1p-8f : 0x1p-18f;
+    }
+    const int b0 = r0 / a.T, t0 = r0 - b0 * a.T;
 #pragma unroll
     for (int q = 0; q < RT; q++)
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            const int col = (nt0 + i) * 32 + (lane & 31);
-            if (col >= a.N) continue;
-            const float bias = a.bias ? a.bias[col] : 0.0f;
-            const float scl = SINGLE ? a.Wscale[col] * 0x1p-8f : 0x1p-18f;
+        for (int j = 0; j < 16; j++) {
+            const int off = 32 * q + (j & 3) + 8 * (j >> 2) + 4 * half;
+            int bb = b0, tt = t0 + off;
+            while (tt >= a.T) { tt -= a.T; bb++; }               // (a tile spans more than two streams only when T < 32 RT)
+            if (r0 + off >= rows || (a.n_rows && tt >= a.n_rows[bb])) continue;
+            float *yr = a.y + bb * a.y_sb + tt * a.y_st;
+            const float *gr = a.a1 + bb * a.a1_sb + tt * a.a1_st;
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int rr = r0 + 32 * q + (j & 3) + 8 * (j >> 2) + 4 * half;
-                if (rr >= rows) continue;
-                const int bb = rr / a.T, tt = rr - bb * a.T;
-                if (a.n_rows && tt >= a.n_rows[bb]) continue;
-                float v = acc[q][i][j] * scl + bias;
+            for (int i = 0; i < NT; i++) {
+                const int col = cl0 + 32 * i;
+                if (col >= a.N) continue;
+                float v = acc[q][i][j] * scl[i] + bias[i];
                 if (a.act == 1) v = clamp1(gate_tanh(v));
-                else if (a.act == 2) v = clamp1(a.a1[bb * a.a1_sb + tt * a.a1_st + col] * gate_sigmoid(v));
-                a.y[bb * a.y_sb + tt * a.y_st + col] = v;
+                else if (a.act == 2) v = clamp1(gr[col] * gate_sigmoid(v));
+                yr[col] = v;
             }
         }
 }
