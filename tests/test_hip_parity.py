@@ -2,6 +2,7 @@
 against (1) golden vectors captured from the imported reference and (2) the CPU oracle on fresh inputs.
 
 Bars (BASELINE.json north_star): discrete sync outputs bit-exact; float32 features within 1e-4 RMS."""
+import os
 import numpy as np
 import pytest
 
@@ -557,6 +558,29 @@ def test_replicas_agree_over_many_fresh_launches(Engine, torch_dev):
         assert nv.min() == nv.max() == 81, (rep, nv.min(), nv.max())
         assert torch.equal(fo.view(32, 8, -1)[1:], fo.view(32, 8, -1)[:1].expand(31, -1, -1)), rep
         eng.close()
+
+
+def test_tx_frame_three_rows_equals_step_kernel(tmp_path):
+    """rade_tx as one launch that takes the frame's three encoder steps through each layer together (k_tx_frame3) against the form that runs the step
+    three times (k_tx_frame, $RADE_TX_FRAME_BY_STEP=1): same chunk -> wavefront assignment, same order of partial sums per row -- the transmit
+    samples of 20 consecutive frames (state carried from frame to frame) are equal bit for bit.  Two processes: the switch is read once per process."""
+    import subprocess, sys
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from radae_amd import api\n"
+        "from radae_amd.channel_tools import synth_features\n"
+        "f = synth_features(4242, 240); tx = api.radae_tx(); out = np.zeros((20, 960), np.complex64)\n"
+        "for k in range(20): tx.do_radae_tx(f[12 * k:12 * k + 12].ravel(), out[k])\n"
+        "np.save(sys.argv[1], out)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for name, extra in (("three", {}), ("step", {"RADE_TX_FRAME_BY_STEP": "1"})):
+        f = str(tmp_path / (name + ".npy"))
+        env = dict(os.environ); env.pop("RADE_TX_FRAME_BY_STEP", None); env.update(extra)
+        subprocess.run([sys.executable, "-c", script, f], check=True, env=env, timeout=300)
+        outs.append(np.load(f))
+    assert np.abs(outs[0]).max() > 0.1
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
 
 
 def test_single_stream_c_abi(golden):
