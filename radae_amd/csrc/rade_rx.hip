@@ -838,7 +838,9 @@ __device__ __forceinline__ void refine2_moments(const RxShared2 *sh, const doubl
     const double k2 = 2.0 * c2r;
     const double *xw = (const double *)&sh->xm[0] + 4 * (frame * 176 + (i < nt ? i : 0) + 2 * s0 + n0) + 2 * c;
     const double2 *pp = &sh->pd[2 * s0 + n0];
-    const double *vp = vmg + m * RD_M + 2 * s0 + n0;
+    // (an explicit global pointer: rx2_refine is a real function, its `vmg` a generic pointer, and the 20 loads below were flat loads, which count on the
+    // LDS wait counter too; as global loads they do not -- measured: no change in the cycles per call, the batch is issued far enough ahead either way)
+    const __attribute__((address_space(1))) double *vp = (const __attribute__((address_space(1))) double *)vmg + m * RD_M + 2 * s0 + n0;
     double vall[20];                                            // this lane's 20 powers of the quarter: one batch of loads ahead of the loop
 #pragma unroll
     for (int u = 0; u < 20; u++) vall[u] = vp[2 * u];
