@@ -591,11 +591,16 @@ def config2(T):
     enc.reset(); dec.reset()
     # encoder and decoder alternate as in a live link (tx and rx side of a radio run concurrently), every call timed on its own
     te = np.zeros(n_steps); td = np.zeros(n_steps)
+    # the interpreter's cyclic garbage collector is off inside the timed loop, as timeit does it: with torch imported a generation-2 collection is a
+    # 35-40 ms pause of the MEASURING script (seen once per 252 steps in two profile runs: encoder_call_max / decoder_call_max), a third of the loop's time
+    import gc
+    gc_was = gc.isenabled(); gc.disable()
     t0 = time.perf_counter()
     for i in range(n_steps):
         a = time.perf_counter(); z[i] = enc.step(rows[i]); b = time.perf_counter(); fh[i] = dec.step(z[i]); c = time.perf_counter()
         te[i] = b - a; td[i] = c - b
     t2 = time.perf_counter()
+    if gc_was: gc.enable()
     t1 = t0 + te.sum()
     from oracle import oracle_py as O
     O.build()
