@@ -211,13 +211,18 @@ def main():
     # the timed region: EXACTLY K steps between barrier + synchronize on both sides, max over ranks; run `--repeats` times (same seeds, so
     # the same work) and the median repeat is the one reported -- every repeat is in the line (value_repeats)
     reps = []
+    import gc
     for _ in range(max(1, args.repeats)):
+        # (the interpreter's cyclic garbage collector is collected before and off inside the timed region, as timeit does it: a generation-2 pause with
+        # torch imported is 35-40 ms of the MEASURING script holding the GIL -- no lane thread launches anything meanwhile; bench.py --config 2 met one per run)
+        gc.collect(); gc_was = gc.isenabled(); gc.disable()
         barrier()
         ru0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         fo, st, _, rx_last = run_steps(args.steps, 1)
         barrier()
         dt_local = time.perf_counter() - t0
+        if gc_was: gc.enable()
         ru1 = resource.getrusage(resource.RUSAGE_SELF)
         cpu_s = (ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)
         fo = fo.clone()                  # (outside the clock) the engine's own output buffer is reused by the measurement legs below; the parity sample wants the timed step's
