@@ -89,7 +89,11 @@ typedef struct {
     float freq_offset;    /* Hz */
     float df_dt;          /* Hz/s */
     const void *G_dev;    /* [B][n_sig][2] complex64 Doppler samples (G1,G2) or NULL = (1,0) */
-    const void *noise_dev;/* [B][n_total] complex64, unit variance, or NULL: generate (Philox) from seed; seed 0 = no noise */
+    const void *noise_dev;/* [B][n_total] complex64, unit variance, or NULL: generate (Philox) from seed; seed 0 = no noise.
+                           * The generated sequence is a property of the BUILD, not of the seed alone: Philox4x32-10 keyed by (seed, stream) with one counter per
+                           * PAIR of samples (words 0-1 -> sample 2p, 2-3 -> sample 2p + 1; round 3: one counter per sample), Box-Muller on the hardware
+                           * log2 / sqrt / sin / cos units (round 4).  Seeded statistics are reproducible within a build; anything that must be comparable
+                           * across builds (parity tests) passes noise_dev. */
     unsigned long long seed;
     float sine_amp, sine_freq;   /* complex tone added over the whole output, inference.py:285-288 (--sine_amp/--sine_freq); 0 = none */
     float rx_gain;               /* final scale, inference.py:289 (--rx_gain); 0 is taken as 1 */

@@ -30,7 +30,7 @@ python $R/bench.py --config 2 > $O/bench_config2.json 2> $O/bench_config2.err
 for p in 1 2 4; do python $R/bench.py --steps 60 --pipeline $p --no-cpu-baseline --no-parity --no-roofline > $O/bench_p$p.json 2> /dev/null; done
 python $R/bench.py --steps 60 --two-pass-channel --no-cpu-baseline --no-parity --no-roofline > $O/bench_two_pass_channel.json 2> /dev/null
 python $R/tools/config_rates.py > $O/config_rates.txt 2>&1; cp $R/gpurun_out/config_rates.json $O/ 2>/dev/null
-(cd $R && ./hosts/rade_multi_bench --gpus 1 --steps 30 > $O/c_host_pipeline3.json 2> /dev/null)
+(cd $R && ./hosts/rade_multi_bench --gpus 1 --steps 100 --warmup 420 > $O/c_host_pipeline3.json 2> /dev/null)    # (the warm-up is the 1.5 s of pre-warm bench.py does)
 python $R/tools/single_stream_latency.py > $O/single_stream_latency.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python $R/bench.py --config 2 > /dev/null 2> $O/stats_c2.err
 # 4. per-stream duration of the receiver launch (tail analysis)
