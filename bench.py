@@ -101,6 +101,14 @@ def cpu_quota():
         return ncpu, None
 
 
+def sync_peers(world, env):
+    """$RADE_SYNC_PEERS for a rank of a `world`-rank job (None: leave the environment alone): the ranks of a node share its CPUs, so the library's
+    wait policy must count every rank's engines -- the caller's value wins, else torchrun's LOCAL_WORLD_SIZE, else the world size (one node)."""
+    if world <= 1:
+        return None
+    return env.get("RADE_SYNC_PEERS") or env.get("LOCAL_WORLD_SIZE") or str(world)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +159,12 @@ def main():
     # encoder / channel kernels (and the head of its receiver launch) fill the CUs that the slowest streams of the previous batch's receiver
     # launch leave idle (a receiver launch lasts as long as its slowest stream; rade_batch_rx synchronises its stream, hence one thread each)
     depth = max(1, min(args.pipeline, args.steps))
+    # one process per GPU: the ranks of a node share the container's CPUs, and the library's wait policy (spin while engines <= CPUs, else sleep on a
+    # blocking event) only sees this process's engines -- tell it how many such processes there are (8 ranks x 3 engines spinning under a 16-core
+    # quota would throttle each other)
+    peers = sync_peers(world, os.environ)
+    if peers is not None:
+        os.environ["RADE_SYNC_PEERS"] = peers
     engs = [BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob) for _ in range(depth)]
     eng = engs[0]
     lanes = [torch.cuda.Stream(device=dev) for _ in range(depth)]
@@ -274,7 +288,7 @@ def main():
         sc = [e.sync_counts() for e in engs]
         out["host"] = {"cpu_s_per_step": cpu_s / args.steps, "cpu_cores_busy": cpu_s / dt, "logical_cpus": ncpu, "cgroup_cpu_quota": quota,
                        "engines_in_process": depth, "rx_waits_blocking": sum(a for a, _ in sc), "rx_waits_spinning": sum(b for _, b in sc),
-                       "RADE_SYNC": os.environ.get("RADE_SYNC", "auto")}
+                       "RADE_SYNC": os.environ.get("RADE_SYNC", "auto"), "RADE_SYNC_PEERS": int(os.environ.get("RADE_SYNC_PEERS", "1"))}
         out["decoded_modem_frames_per_stream"] = {"min": int(nv.min()), "mean": float(nv.mean()), "max": int(nv.max())}
 
     if rank == 0 and not args.no_roofline:

@@ -45,11 +45,17 @@ double rade_host_cpu_quota(void)
 }
 /* 1 = wait on a blocking event, 0 = spin: a pure function of the two counts (tests/test_host_cpu.py) */
 int rade_sync_policy(int engines_open, double cpu_quota) { return (double)engines_open > cpu_quota; }
+/* $RADE_SYNC_PEERS = processes that share this process's CPUs and hold as many engines each (one process per GPU under torchrun: the quota is the
+ * container's, the engine count this process's -- bench.py sets it to LOCAL_WORLD_SIZE): the policy then compares engines x peers with the quota */
 static int sync_blocking_now(void)
 {
-    static int mode = -1; static double quota;
-    if (mode < 0) { const char *e = getenv("RADE_SYNC"); quota = rade_host_cpu_quota(); mode = e && !strcmp(e, "block") ? 1 : (e && !strcmp(e, "spin") ? 0 : 2); }
-    return mode == 2 ? rade_sync_policy(__atomic_load_n(&g_engines_open, __ATOMIC_RELAXED), quota) : mode;
+    static int mode = -1, peers = 1; static double quota;
+    if (mode < 0) {
+        const char *e = getenv("RADE_SYNC"), *p = getenv("RADE_SYNC_PEERS");
+        quota = rade_host_cpu_quota(); peers = p && atoi(p) > 1 ? atoi(p) : 1;
+        __atomic_store_n(&mode, e && !strcmp(e, "block") ? 1 : (e && !strcmp(e, "spin") ? 0 : 2), __ATOMIC_RELEASE);
+    }
+    return mode == 2 ? rade_sync_policy(__atomic_load_n(&g_engines_open, __ATOMIC_RELAXED) * peers, quota) : mode;
 }
 
 typedef struct { float *wp, *bias; unsigned short *wp16, *wa16; float *wscale, *wscale16; int N, K; } dev_lin;   /* wscale16: column scales when wp16 is one plane of integers */

@@ -60,3 +60,19 @@ def test_command_line_exits_nonzero_without_enough_gpus():
     assert r.returncode != 0
     assert "HIP device" in (r.stderr + r.stdout)
     assert "\"metric\"" not in r.stdout
+
+
+def test_ranks_of_a_node_tell_the_wait_policy_about_each_other():
+    """One process per GPU: rade_batch_rx's wait policy (spin while engines <= CPUs) only sees its own process's engines; bench.py hands it the number
+    of ranks that share the node's CPUs ($RADE_SYNC_PEERS), and the library multiplies (rade_engine.c: sync_blocking_now): 8 ranks x 3 engines under a
+    16-core quota sleep on a blocking event, a single rank spins."""
+    import bench
+    assert bench.sync_peers(1, {}) is None
+    assert bench.sync_peers(8, {}) == "8"
+    assert bench.sync_peers(8, {"LOCAL_WORLD_SIZE": "4"}) == "4"
+    assert bench.sync_peers(8, {"LOCAL_WORLD_SIZE": "4", "RADE_SYNC_PEERS": "2"}) == "2"
+    import ctypes as C
+    from radae_amd import engine
+    lib = engine.load_library()
+    lib.rade_sync_policy.argtypes = [C.c_int, C.c_double]
+    assert lib.rade_sync_policy(3 * 8, 16.0) == 1 and lib.rade_sync_policy(3 * 1, 16.0) == 0
