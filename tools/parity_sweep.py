@@ -12,7 +12,7 @@ INT_KEYS = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tm
 N = int(os.environ.get("SWEEP_N", "48")); n_mf = 24
 O.build(); m = O.Model()
 rng = np.random.default_rng(int(os.environ.get("SWEEP_SEED", "2026")))
-bad = 0; ties = 0; dties = 0; tot_calls = 0; tot_valid = 0
+bad = 0; ties = 0; dties = 0; tties = 0; tot_calls = 0; tot_valid = 0
 for case in range(N):
     seed = int(rng.integers(1, 1 << 30)); eb = float(rng.uniform(-1.0, 12.0)); fo = float(rng.uniform(-40.0, 40.0))
     chan = ["awgn", "mpp", "mpd", "mpg"][int(rng.integers(0, 4))]
@@ -60,13 +60,27 @@ for case in range(N):
         if first and set(first) <= {"tmax", "f_ind_max"} and len(t["Dtmax12"]) == len(d["Dtmax12"]):
             calls = [i for i in range(len(t["tmax"])) if t["tmax"][i] != d["tmax"][i] or t["f_ind_max"][i] != d["f_ind_max"][i]]
             dtie = all(abs(float(t["Dtmax12"][i]) - float(d["Dtmax12"][i])) <= 1e-6 * abs(float(d["Dtmax12"][i])) and int(d["state_before"][i]) != 2 for i in calls)
-        dties += dtie; ties += tie; bad += not (tie or dtie)
-        print(f"{'refine near-tie' if tie else ('detect near-tie' if dtie else 'MISMATCH')} case {case}: seed {seed} {chan} Eb/No {eb!r} dB fo {fo!r} Hz valid {nv}/{len(d['features_out'])} max |fmax diff| {dfm:.4f} first differing call per key {first}")
+        # a refine() tie can also be between two cells of DIFFERENT timing (then tmax, and with it a few later outputs, differ until the estimates meet again):
+        # accepted under the same rule -- the oracle's own arg-max margin at the first differing call is within float32 rounding -- if, in addition, both
+        # receivers decode the same number of frames and their traces are equal again from some later call on to the end
+        ttie = False
+        if first and not dtie and len(t["tmax"]) == len(d["tmax"]) and nv == len(d["features_out"]):
+            import ctypes as C
+            mg = C.c_double.in_dll(O.lib(), "orc_debug_refine_margin")
+            i_first = min(first.values()); rxo = O.Rx(m); pos = 0; margin = 1.0
+            for i in range(i_first + 1):
+                nin = rxo.nin(); mg.value = 1.0; rxo.frame(full[pos:pos + nin]); pos += nin; margin = mg.value
+            differ = [i for i in range(len(t["tmax"])) if any(t[k][i] != d[k][i] for k in INT_KEYS)]
+            ttie = margin < 3e-7 and int(d["state_before"][i_first]) == 2 and max(differ) < len(t["tmax"]) - 1 and max(differ) - i_first <= 8
+            print(f"  (oracle arg-max margin at call {i_first}: {margin:.3e}; calls that differ: {differ})")
+        tties += ttie
+        dties += dtie; ties += tie; bad += not (tie or dtie or ttie)
+        print(f"{'refine near-tie' if tie else ('detect near-tie' if dtie else ('refine tie between timings' if ttie else 'MISMATCH'))} case {case}: seed {seed} {chan} Eb/No {eb!r} dB fo {fo!r} Hz valid {nv}/{len(d['features_out'])} max |fmax diff| {dfm:.4f} first differing call per key {first}")
     eng.close()
-print(f"{N} cases, {tot_calls} receiver calls, {tot_valid} decoded frames: {bad} mismatching case(s), {ties} with a refine() near-tie resolved the other way, {dties} with a detect_pilots arg-max tie (1 ulp) on an unsynchronised call")
+print(f"{N} cases, {tot_calls} receiver calls, {tot_valid} decoded frames: {bad} mismatching case(s), {ties} with a refine() near-tie resolved the other way, {dties} with a detect_pilots arg-max tie (1 ulp) on an unsynchronised call, {tties} with a refine() tie between two timings (oracle margin < 3e-7, traces equal again within 8 calls)")
 if os.environ.get("SWEEP_JSON"):
     import json
     json.dump({"tool": "tools/parity_sweep.py", "seed": int(os.environ.get("SWEEP_SEED", "2026")), "cases": N, "receiver_calls": int(tot_calls), "decoded_modem_frames": int(tot_valid),
-               "mismatching_cases": int(bad), "refine_near_tie_cases": int(ties), "detect_argmax_tie_cases": int(dties),
-               "rule": "per-call discrete outputs equal and features within 1e-4 RMS; a case whose discrete outputs are all equal but whose fmax differs by < 0.05 Hz is a refine() tie if, in addition, the oracle's own arg-max margin (runner-up cell relative to the winner) at the first differing call is below 3e-7 (two 0.1 Hz bins whose float32 magnitudes are within an ulp: summation order decides); a case whose only differing outputs are (tmax, f_ind_max) of unsynchronised calls whose maxima agree to 1e-6 is a detect_pilots arg-max tie (two of the 38,400 float32 cells within one ulp; FFT convolution and direct sums round differently), every later output being equal again"},
+               "mismatching_cases": int(bad), "refine_near_tie_cases": int(ties), "detect_argmax_tie_cases": int(dties), "refine_tie_between_timings_cases": int(tties),
+               "rule": "per-call discrete outputs equal and features within 1e-4 RMS; a case whose discrete outputs are all equal but whose fmax differs by < 0.05 Hz is a refine() tie if, in addition, the oracle's own arg-max margin (runner-up cell relative to the winner) at the first differing call is below 3e-7 (two 0.1 Hz bins whose float32 magnitudes are within an ulp: summation order decides); a case whose only differing outputs are (tmax, f_ind_max) of unsynchronised calls whose maxima agree to 1e-6 is a detect_pilots arg-max tie (two of the 38,400 float32 cells within one ulp; FFT convolution and direct sums round differently), every later output being equal again; a case whose first differing call is a synchronised one at which the oracle's own refine() arg-max margin is below 3e-7 (two cells of different timing with equal float32 magnitudes), with the same number of decoded frames and traces that are equal again within 8 calls and to the end, is a refine() tie between timings"},
               open(os.environ["SWEEP_JSON"], "w"), indent=1)
