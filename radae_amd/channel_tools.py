@@ -37,6 +37,22 @@ def _fir_from_gaussian_psd(spread_hz: float, low_fs: float, ntaps: int = 100) ->
     return h * np.hamming(ntaps)
 
 
+def fir2_from_gaussian_psd(spread_hz: float, low_fs: float, ntaps: int = 100) -> np.ndarray:
+    """The taps by `fir2`'s own recipe as `doppler_spread.m:27-29` calls it: the Gaussian sampled at the 51 points 0 : lowFs/100 : lowFs/2, LINEARLY interpolated
+    onto a 513-point grid, half-sample linear phase (an even number of taps: type II), inverse FFT, Hamming window.  Equal to scipy.signal.firwin2(100, f, m,
+    nfreqs=513) to rounding (tests/test_host_cpu.py) -- an independent implementation of the same algorithm; Octave itself cannot be run here.  The generator
+    above samples the Gaussian on the fine grid directly instead: its taps differ from these by 0.24 % of the largest tap (same test), which is what the
+    "statistics, not samples" contract of this module amounts to.  Kept as it is because the golden receiver traces were made with it."""
+    sigma = spread_hz / 2.0
+    npt = 512
+    x = np.arange(51) * low_fs / 100.0
+    y = (1.0 / (sigma * math.sqrt(2 * math.pi))) * np.exp(-(x ** 2) / (2 * sigma * sigma))
+    mag = np.interp(np.linspace(0.0, 1.0, npt + 1), x / (low_fs / 2.0), y)
+    k = np.arange(npt + 1)
+    spec = mag * np.exp(-1j * math.pi * k * (ntaps - 1) / (2.0 * npt))
+    return np.fft.irfft(spec, 2 * npt)[:ntaps] * np.hamming(ntaps)
+
+
 def doppler_plan(spread_hz: float, fs: int, nsam: int):
     """(FIR taps, Fs/lowFs ratio, low-rate sample count) doppler_spread() uses: the inputs of the device generator."""
     low_fs = math.ceil(10 * spread_hz)

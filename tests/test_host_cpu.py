@@ -458,3 +458,28 @@ def test_refine_moment_expansion_is_complex128_accurate():
         differing += int(np.sum(out.astype(np.complex64) != direct.astype(np.complex64)))
     assert worst_t < 1e-15 and worst_t < 20 * worst_d, (worst_t, worst_d)
     assert differing == 0
+
+
+def test_doppler_filter_design_against_scipy_firwin2():
+    """the reference designs its Doppler-spread filter with Octave's fir2 (doppler_spread.m:27-29), which cannot be run here.  scipy's
+    firwin2 is an independent implementation of the same frequency-sampling algorithm: the module's restatement of fir2's recipe equals it to rounding,
+    and the taps the generator actually uses (Gaussian sampled on the fine grid instead of interpolated from 51 points) are within 0.3 % of the largest tap
+    of it, for the three channel presets' spreads."""
+    import math
+    import scipy.signal as ss
+    from radae_amd.channel_tools import PRESETS, _fir_from_gaussian_psd, fir2_from_gaussian_psd, doppler_plan
+    for name, (spread, _) in PRESETS.items():
+        low_fs = math.ceil(10 * spread); m = 8000 / low_fs
+        if m != math.floor(m):
+            low_fs = 8000 / math.floor(m)
+        sigma = spread / 2.0
+        x = np.arange(51) * low_fs / 100.0
+        y = (1.0 / (sigma * math.sqrt(2 * math.pi))) * np.exp(-(x ** 2) / (2 * sigma * sigma))
+        assert y[-1] < 1e-20                      # (firwin2 insists on exactly zero gain at Nyquist for an even number of taps)
+        y[-1] = 0.0
+        ref = ss.firwin2(100, x / (low_fs / 2.0), y, nfreqs=513, window="hamming")
+        ours = fir2_from_gaussian_psd(spread, low_fs, 100)
+        used = _fir_from_gaussian_psd(spread, low_fs, 100)
+        assert np.abs(ours - ref).max() < 1e-12 * np.abs(ref).max(), name
+        assert np.abs(used - ref).max() < 3e-3 * np.abs(ref).max(), name
+        assert np.array_equal(doppler_plan(spread, 8000, 16000)[0], used)
