@@ -304,9 +304,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_tx_frame(const rd_core_args *ap,
         }
 #pragma unroll
         for (int s = 0; s <= RD_NS; s++) {
-            const float mag = hypotf(acc[s][0], acc[s][1]);
-            float2 v = make_float2(0.0f, 0.0f);
-            if (mag != 0.0f) { const float g = tanhf(mag) / mag; v = make_float2(acc[s][0] * g, acc[s][1] * g); }      // tanh(|x|) e^{j angle(x)} (radae.py:218, dsp.py:377)
+            const float2 v = pa_limit(make_float2(acc[s][0], acc[s][1]));                  // tanh(|x|) e^{j angle(x)} (radae.py:218, dsp.py:377)
             out[s * RD_SYM + RD_NCP + tid] = v;
             if (tid >= RD_M - RD_NCP) out[s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
         }
@@ -553,9 +551,7 @@ __global__ __launch_bounds__(CS_THREADS) void k_tx_frame3(const rd_core_args *ap
         }
 #pragma unroll
         for (int s = 0; s <= RD_NS; s++) {
-            const float mag = hypotf(acc[s][0], acc[s][1]);
-            float2 v = make_float2(0.0f, 0.0f);
-            if (mag != 0.0f) { const float g = tanhf(mag) / mag; v = make_float2(acc[s][0] * g, acc[s][1] * g); }      // tanh(|x|) e^{j angle(x)} (radae.py:218, dsp.py:377)
+            const float2 v = pa_limit(make_float2(acc[s][0], acc[s][1]));                  // tanh(|x|) e^{j angle(x)} (radae.py:218, dsp.py:377)
             out[s * RD_SYM + RD_NCP + tid] = v;
             if (tid >= RD_M - RD_NCP) out[s * RD_SYM + tid - (RD_M - RD_NCP)] = v;
         }

@@ -141,6 +141,17 @@ __device__ __forceinline__ float clamp1(float x) { return fminf(fmaxf(x, -1.0f),
 // gate activations of the GRU recurrences on the hardware exp2 / rcp units (about 1 ulp each): the recurrence is a
 // serial chain, so the libm-grade expf / tanhf / IEEE division sequences would dominate every time step
 __device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+// the transmitter's limiter tanh(|x|) e^{j angle(x)} = x tanh(|x|) / |x| (radae.py:218, dsp.py:377) for every kernel that synthesises a transmit sample: the magnitude on the
+// hardware square root, tanh on exp2 / rcp as the gates have it (absolute error of tanh ~1e-7, i.e. ~1e-7 |x| on the sample: the golden bar is 2e-5).  libm's hypotf + tanhf
+// + a division were as many instructions per sample as the 30-term IDFT in front of them.
+__device__ __forceinline__ float2 pa_limit(float2 x)
+{
+    const float mag = __builtin_amdgcn_sqrtf(fmaf(x.x, x.x, x.y * x.y));
+    if (mag == 0.0f) return make_float2(0.0f, 0.0f);
+    const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * mag);           // e^{-2 |x|}
+    const float g = (1.0f - e) * __builtin_amdgcn_rcpf((1.0f + e) * mag);
+    return make_float2(x.x * g, x.y * g);
+}
 __device__ __forceinline__ float gate_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
 __device__ __forceinline__ float2 ld2(const float (*p)[2], int i) { return make_float2(p[i][0], p[i][1]); }
 

@@ -609,13 +609,6 @@ extern "C" int rd_launch_carry_rows(float *x, int B, int Tcap, int W, int nhist,
 }
 
 // tanh(|x|) * exp(j*angle(x))   (radae.py:218, dsp.py:377)
-__device__ __forceinline__ float2 pa_limit(float2 x)
-{
-    const float mag = hypotf(x.x, x.y);
-    if (mag == 0.0f) return make_float2(0.0f, 0.0f);
-    const float g = tanhf(mag) / mag;                     // tanh(|x|) e^{j angle(x)} = x tanh(|x|)/|x|
-    return make_float2(x.x * g, x.y * g);
-}
 
 // one workgroup per (modem frame, stream): 5 symbols x 160 samples, 30-term IDFT per sample
 __global__ __launch_bounds__(192) void k_ofdm_mod(const rd_tables *tab, const float *z, float2 *tx, long tx_stride, int n_mf)
