@@ -7,8 +7,8 @@ Restates (numpy only, no Octave/scipy dependency at run time)
     `hf_gain = 1/sqrt(var(G1)+var(G2))` normalisation,
 and the synthetic 20-dim vocoder-feature generator fixed in SURVEY.md section 8(d).
 
-G is an *input* of the channel model (`radae/radae.py:529-539` takes it as a tensor), so the exact
-FIR design (Octave `fir2`) is not part of the parity contract; only the statistics matter.
+G is an *input* of the channel model (`radae/radae.py:529-539` takes it as a tensor).  The FIR design is
+`fir2`'s frequency-sampling recipe, pinned to rounding on scipy.signal.firwin2 (Octave cannot be run here).
 """
 from __future__ import annotations
 
@@ -23,26 +23,16 @@ PRESETS = {  # multipath_samples.m:10-16  (doppler spread Hz, path delay s)
 }
 
 
-def _fir_from_gaussian_psd(spread_hz: float, low_fs: float, ntaps: int = 100) -> np.ndarray:
-    """Frequency-sampling FIR design (same recipe as fir2: interpolate the desired magnitude on a
-    dense grid, inverse FFT, linear phase, Hamming window)."""
-    sigma = spread_hz / 2.0
-    npt = 512
-    f = np.linspace(0.0, low_fs / 2.0, npt + 1)
-    mag = (1.0 / (sigma * math.sqrt(2 * math.pi))) * np.exp(-(f ** 2) / (2 * sigma * sigma))
-    # linear-phase shift by (ntaps-1)/2 samples
-    k = np.arange(npt + 1)
-    spec = mag * np.exp(-1j * math.pi * k * (ntaps - 1) / (2.0 * npt))
-    h = np.fft.irfft(spec, 2 * npt)[:ntaps]
-    return h * np.hamming(ntaps)
-
-
 def fir2_from_gaussian_psd(spread_hz: float, low_fs: float, ntaps: int = 100) -> np.ndarray:
-    """The taps by `fir2`'s own recipe as `doppler_spread.m:27-29` calls it: the Gaussian sampled at the 51 points 0 : lowFs/100 : lowFs/2, LINEARLY interpolated
-    onto a 513-point grid, half-sample linear phase (an even number of taps: type II), inverse FFT, Hamming window.  Equal to scipy.signal.firwin2(100, f, m,
-    nfreqs=513) to rounding (tests/test_host_cpu.py) -- an independent implementation of the same algorithm; Octave itself cannot be run here.  The generator
-    above samples the Gaussian on the fine grid directly instead: its taps differ from these by 0.24 % of the largest tap (same test), which is what the
-    "statistics, not samples" contract of this module amounts to.  Kept as it is because the golden receiver traces were made with it."""
+    """The Doppler-spread filter's taps by `fir2`'s own recipe as `doppler_spread.m:27-29` calls it
+    (`fir2(Ntaps-1, x/(lowFs/2), y)`): the Gaussian sampled at the 51 points 0 : lowFs/100 : lowFs/2, LINEARLY
+    interpolated onto a 513-point grid, half-sample linear phase (an even number of taps: type II), inverse
+    FFT, Hamming window.  Equal to scipy.signal.firwin2(100, f, m, nfreqs=513) to rounding
+    (tests/test_host_cpu.py::test_doppler_filter_design_against_scipy_firwin2) -- an independent
+    implementation of the same algorithm; Octave itself cannot be run here.  Since round 5 this is THE design:
+    doppler_plan / doppler_spread / multipath_g, the device generator's taps, every golden fixture that carries
+    a generated G and bench.py's workload use it (rounds 1-4 sampled the Gaussian on the fine grid directly,
+    0.24 % of the largest tap away from it)."""
     sigma = spread_hz / 2.0
     npt = 512
     x = np.arange(51) * low_fs / 100.0
@@ -61,7 +51,7 @@ def doppler_plan(spread_hz: float, fs: int, nsam: int):
         m = math.floor(m)
         low_fs = fs / m
     m = int(m)
-    return _fir_from_gaussian_psd(spread_hz, low_fs, 100), m, max(math.ceil(nsam / m), 2)
+    return fir2_from_gaussian_psd(spread_hz, low_fs, 100), m, max(math.ceil(nsam / m), 2)
 
 
 def doppler_spread(spread_hz: float, fs: int, nsam: int, rng: np.random.Generator) -> np.ndarray:
@@ -74,7 +64,7 @@ def doppler_spread(spread_hz: float, fs: int, nsam: int, rng: np.random.Generato
         low_fs = fs / m
     m = int(m)
     nsam_low = max(math.ceil(nsam / m), 2)
-    b = _fir_from_gaussian_psd(spread_hz, low_fs, ntaps)
+    b = fir2_from_gaussian_psd(spread_hz, low_fs, ntaps)
     x = rng.standard_normal(nsam_low + ntaps) + 1j * rng.standard_normal(nsam_low + ntaps)
     y = np.convolve(x, b)[: nsam_low + ntaps][ntaps:]
     # linear interpolation (with extrapolation past the last low-rate point), Octave 1-based

@@ -713,7 +713,9 @@ def test_config3_full_size_mpp_vs_oracle(Engine, torch_dev, oracle, oracle_model
 def test_device_multipath_generator(Engine, torch_dev):
     """the Watterson / Doppler-spread generator on the device.  With the host generator's own low-rate
     noise as input it reproduces radae_amd.channel_tools.multipath_g (FIR, interpolation, hf_gain); from its Philox noise
-    the statistics are right: var G1 + var G2 = 1 per stream and the Gaussian-PSD autocorrelation exp(-2 pi^2 sigma^2 tau^2)."""
+    the statistics are right: var G1 + var G2 = 1 per stream and the autocorrelation exp(-(pi sigma tau)^2) of a process whose filter has the Gaussian
+    AMPLITUDE response exp(-f^2 / (2 sigma^2)) (doppler_spread.m:20-27).  The host generator's taps are fir2's recipe pinned on scipy.signal.firwin2
+    (tests/test_host_cpu.py::test_doppler_filter_design_against_scipy_firwin2)."""
     import torch
     from radae_amd.channel_tools import multipath_g, doppler_plan, PRESETS
     B, n = 6, 40 * 960
@@ -733,10 +735,10 @@ def test_device_multipath_generator(Engine, torch_dev):
     for b in range(Bs):
         assert abs(np.var(G[b, :, 0]) + np.var(G[b, :, 1]) - 1.0) < 1e-5
     sigma = PRESETS["mpp"][0] / 2.0
-    for tau, tol in ((0.1, 0.08), (0.5, 0.25)):
+    for tau, tol in ((0.1, 0.05), (0.5, 0.2)):
         lag = int(tau * 8000)
         num = np.mean([np.real(np.vdot(G[b, :-lag, p], G[b, lag:, p])) / np.real(np.vdot(G[b, :, p], G[b, :, p])) for b in range(Bs) for p in range(2)])
-        assert abs(num - np.exp(-2 * np.pi ** 2 * sigma ** 2 * tau ** 2)) < tol, (tau, num)
+        assert abs(num - np.exp(-(np.pi * sigma * tau) ** 2)) < tol, (tau, num)
     assert np.abs(G[0] - G[1]).max() > 0.1                 # streams are independent
     eng.close()
 

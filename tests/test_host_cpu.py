@@ -461,14 +461,14 @@ def test_refine_moment_expansion_is_complex128_accurate():
 
 
 def test_doppler_filter_design_against_scipy_firwin2():
-    """the reference designs its Doppler-spread filter with Octave's fir2 (doppler_spread.m:27-29), which cannot be run here.  scipy's
-    firwin2 is an independent implementation of the same frequency-sampling algorithm: the module's restatement of fir2's recipe equals it to rounding,
-    and the taps the generator actually uses (Gaussian sampled on the fine grid instead of interpolated from 51 points) are within 0.3 % of the largest tap
-    of it, for the three channel presets' spreads."""
+    """the reference designs its Doppler-spread filter with Octave's fir2 (doppler_spread.m:27-29: `fir2(Ntaps-1, x/(lowFs/2), y)`), which
+    cannot be run here.  scipy's firwin2 is an independent implementation of the same frequency-sampling algorithm: the module's restatement of fir2's recipe
+    equals it to rounding for the three channel presets' spreads, and it is the design IN USE: doppler_plan (the device generator's taps) returns exactly these
+    taps, and doppler_spread / multipath_g (every golden G, bench.py's workload) filter with them."""
     import math
     import scipy.signal as ss
-    from radae_amd.channel_tools import PRESETS, _fir_from_gaussian_psd, fir2_from_gaussian_psd, doppler_plan
-    for name, (spread, _) in PRESETS.items():
+    from radae_amd import channel_tools as ct
+    for name, (spread, _) in ct.PRESETS.items():
         low_fs = math.ceil(10 * spread); m = 8000 / low_fs
         if m != math.floor(m):
             low_fs = 8000 / math.floor(m)
@@ -478,8 +478,30 @@ def test_doppler_filter_design_against_scipy_firwin2():
         assert y[-1] < 1e-20                      # (firwin2 insists on exactly zero gain at Nyquist for an even number of taps)
         y[-1] = 0.0
         ref = ss.firwin2(100, x / (low_fs / 2.0), y, nfreqs=513, window="hamming")
-        ours = fir2_from_gaussian_psd(spread, low_fs, 100)
-        used = _fir_from_gaussian_psd(spread, low_fs, 100)
+        ours = ct.fir2_from_gaussian_psd(spread, low_fs, 100)
         assert np.abs(ours - ref).max() < 1e-12 * np.abs(ref).max(), name
-        assert np.abs(used - ref).max() < 3e-3 * np.abs(ref).max(), name
-        assert np.array_equal(doppler_plan(spread, 8000, 16000)[0], used)
+        taps, ratio, n_low = ct.doppler_plan(spread, 8000, 16000)
+        assert np.array_equal(taps, ours) and ratio == int(8000 / low_fs)
+        # doppler_spread() filters with the same taps: rebuild its output from its own noise draw
+        rng = np.random.default_rng(11); g = ct.doppler_spread(spread, 8000, 16000, rng)
+        rng = np.random.default_rng(11); xs = rng.standard_normal(n_low + 100) + 1j * rng.standard_normal(n_low + 100)
+        ylow = np.convolve(xs, ref)[: n_low + 100][100:]
+        pos = np.arange(16000) / ratio; i0 = np.minimum(np.floor(pos).astype(np.int64), n_low - 2)
+        want = ylow[i0] + (ylow[i0 + 1] - ylow[i0]) * (pos - i0)
+        assert np.abs(g - want).max() < 1e-9 * np.abs(want).max(), name
+
+
+def test_doppler_process_statistics():
+    """multipath_samples.m:10-31 / doppler_spread.m:7-50: the filter's AMPLITUDE response is the Gaussian exp(-f^2 / (2 sigma^2)), sigma = spread / 2
+    (doppler_spread.m:20-27), so the generated path gains have the power spectrum exp(-f^2 / sigma^2) and the autocorrelation R(tau) = exp(-(pi sigma tau)^2);
+    hf_gain normalises var G1 + var G2 to 1."""
+    from radae_amd import channel_tools as ct
+    spread = ct.PRESETS["mpd"][0]; n = 8000 * 400                      # 400 s at 2 Hz spread: ~800 coherence times
+    G = ct.multipath_g("mpd", 8000, n, 5).astype(np.complex128)
+    assert np.var(G[:, 0]) + np.var(G[:, 1]) == pytest.approx(1.0, rel=1e-3)
+    g = G[::80, 0]; g = g - g.mean()                                    # 100 Hz is plenty for a 2 Hz process
+    for lag_s in (0.05, 0.1, 0.2, 0.3):
+        k = int(round(lag_s * 100))
+        r = np.real(np.vdot(g[:-k], g[k:]) / np.vdot(g, g))
+        want = np.exp(-(np.pi * (spread / 2.0) * lag_s) ** 2)
+        assert abs(r - want) < 0.03, (lag_s, r, want)
