@@ -53,6 +53,9 @@ extern "C" {
 #define RADE_USE_C_DECODER 0x2
 #define RADE_FOFF_TEST     0x4   /* inject a 10 Hz error on first sync (UW false-sync test) */
 #define RADE_VERBOSE_0     0x8   /* quiet */
+/* Extension (not in the reference's header): rade_open() also honours RADE_BATCH_TX_BPF (0x400, include/rade_batch.h) -- the reference's
+ * radae_tx(..., txbpf_en=True) / `radae_tx.py --txbpf` (radae_txe.py:74-83), which the reference's C API has no switch for: rade_tx() and
+ * rade_tx_eoo() then return band-pass filtered and magnitude-clipped samples (the filter state carried from call to call). */
 
 struct rade;
 

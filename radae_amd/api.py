@@ -15,6 +15,7 @@ import numpy as np
 from . import engine
 
 RADE_USE_C_ENCODER, RADE_USE_C_DECODER, RADE_FOFF_TEST, RADE_VERBOSE_0 = 0x1, 0x2, 0x4, 0x8
+RADE_BATCH_TX_BPF = 0x400          # include/rade_batch.h: honoured by rade_open() too (the reference's txbpf_en)
 
 
 def _bind():
@@ -57,10 +58,14 @@ class Rade:
 
 
 class radae_tx:
-    """radae_txe.radae_tx: 12 feature frames x 36 floats in -> 960 IQ samples out per call."""
+    """radae_txe.radae_tx: 12 feature frames x 36 floats in -> 960 IQ samples out per call.  `txbpf_en` as in radae_txe.py:47-83: every frame and
+    the end-of-over frame through the Tx band-pass filter and the magnitude clip (a handle passed in must have been opened with RADE_BATCH_TX_BPF)."""
 
-    def __init__(self, model_name: str = "", handle: Rade | None = None, flags: int = RADE_VERBOSE_0):
+    def __init__(self, model_name: str = "", handle: Rade | None = None, flags: int = RADE_VERBOSE_0, txbpf_en: bool = False):
+        if txbpf_en:
+            flags |= RADE_BATCH_TX_BPF
         self.h = handle or Rade(model_name, flags)
+        self.txbpf_en = bool(txbpf_en)
         L, r = self.h.L, self.h.r
         self.n_floats_in = L.rade_n_features_in_out(r)
         self.Nmf = L.rade_n_tx_out(r)

@@ -13,6 +13,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
 
+#include <pthread.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,15 +48,18 @@ double rade_host_cpu_quota(void)
 int rade_sync_policy(int engines_open, double cpu_quota) { return (double)engines_open > cpu_quota; }
 /* $RADE_SYNC_PEERS = processes that share this process's CPUs and hold as many engines each (one process per GPU under torchrun: the quota is the
  * container's, the engine count this process's -- bench.py sets it to LOCAL_WORLD_SIZE): the policy then compares engines x peers with the quota */
+static int g_sync_mode = 2, g_sync_peers = 1; static double g_sync_quota = 1.0;    /* written once (pthread_once), read by every engine's host thread */
+static pthread_once_t g_sync_once = PTHREAD_ONCE_INIT;
+static void sync_policy_init(void)
+{
+    const char *e = getenv("RADE_SYNC"), *p = getenv("RADE_SYNC_PEERS");
+    g_sync_quota = rade_host_cpu_quota(); g_sync_peers = p && atoi(p) > 1 ? atoi(p) : 1;
+    g_sync_mode = e && !strcmp(e, "block") ? 1 : (e && !strcmp(e, "spin") ? 0 : 2);
+}
 static int sync_blocking_now(void)
 {
-    static int mode = -1, peers = 1; static double quota;
-    if (mode < 0) {
-        const char *e = getenv("RADE_SYNC"), *p = getenv("RADE_SYNC_PEERS");
-        quota = rade_host_cpu_quota(); peers = p && atoi(p) > 1 ? atoi(p) : 1;
-        __atomic_store_n(&mode, e && !strcmp(e, "block") ? 1 : (e && !strcmp(e, "spin") ? 0 : 2), __ATOMIC_RELEASE);
-    }
-    return mode == 2 ? rade_sync_policy(__atomic_load_n(&g_engines_open, __ATOMIC_RELAXED) * peers, quota) : mode;
+    pthread_once(&g_sync_once, sync_policy_init);
+    return g_sync_mode == 2 ? rade_sync_policy(__atomic_load_n(&g_engines_open, __ATOMIC_RELAXED) * g_sync_peers, g_sync_quota) : g_sync_mode;
 }
 
 typedef struct { float *wp, *bias; unsigned short *wp16, *wa16; float *wscale, *wscale16; int N, K; } dev_lin;   /* wscale16: column scales when wp16 is one plane of integers */
@@ -81,7 +85,7 @@ struct rade_batch {
     /* transmit side */
     float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
     /* optional Tx band-pass filter + clip (RADE_BATCH_TX_BPF; radae_txe.py:74-83): filter state per stream, its initial value, the modulator's raw output, block phases */
-    rd_bpf_state *tx_bpf, *tx_bpf_init; void *tx_raw; float *tx_chain;
+    rd_bpf_state *tx_bpf, *tx_bpf_init; void *tx_raw; float *tx_chain; float *eoo_filt;   /* eoo_filt [B][Neoo] c64: the end-of-over frame as transmitted (filtered + clipped) for the channel's with_eoo */
     void *chan_scratch; void *chan_mp;        /* chan_mp [B][max_tx_mf * 960] c64: multipath output of the fused modulator (rade_batch_tx_channel), allocated on first use */
     /* receive side */
     rd_rx_stream *rx_st; rd_rx_round *rx_round;
@@ -231,6 +235,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     if (rd_model_parse(blob, blob_len, &m)) return NULL;
     have_model = 1;
     h = calloc(1, sizeof *h);
+    if (!h) { rd_model_free(&m); return NULL; }
     __atomic_add_fetch(&g_engines_open, 1, __ATOMIC_RELAXED);
     h->B = cfg->n_streams; h->max_tx_mf = cfg->max_tx_mf; h->device = cfg->device; h->flags = cfg->flags;
     h->trace_cap = cfg->rx_trace_calls; h->Tcap = 3 * cfg->max_tx_mf;
@@ -317,7 +322,8 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         free(init);
         h->tx_raw = dev_zeros(sizeof(float) * 2 * B * nraw);
         h->tx_chain = dev_zeros(sizeof(float) * 2 * B * (cfg->max_tx_mf + 8));
-        if (!h->tx_bpf_init || !h->tx_bpf || !h->tx_raw || !h->tx_chain) goto fail;
+        h->eoo_filt = dev_zeros(sizeof(float) * 2 * B * RD_NEOO);
+        if (!h->tx_bpf_init || !h->tx_bpf || !h->tx_raw || !h->tx_chain || !h->eoo_filt) goto fail;
     }
     h->chan_scratch = dev_zeros(sizeof(double) * B * (1 + (cfg->max_tx_mf > 64 ? cfg->max_tx_mf : 64)) * 2);   /* rd_chan_args.scratch */
     h->enc_h[0] = dev_zeros(sizeof(float) * 5 * B * 64); h->dec_h[0] = dev_zeros(sizeof(float) * 5 * B * 96);
@@ -395,7 +401,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail,
-                     h->rx_progress /* + rx_acc, rx_status */, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
+                     h->rx_progress /* + rx_acc, rx_status */, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->eoo_filt, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -601,6 +607,11 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
     a.eoo = h->eoo; a.scratch = h->chan_scratch; a.B = h->B; a.n_sig = p->n_sig; a.n_pre = p->n_pre; a.n_post = p->n_post; a.with_eoo = p->with_eoo;
     a.sigma = p->sigma; a.freq_offset = p->freq_offset; a.df_dt = p->df_dt; a.seed = p->seed;
     a.sine_amp = p->sine_amp; a.sine_freq = p->sine_freq; a.rx_gain = p->rx_gain != 0.0f ? p->rx_gain : 1.0f;
+    if (h->tx_bpf && p->with_eoo) {        /* what radae_tx --txbpf transmits after the last frame: the end-of-over frame through the Tx band-pass filter and the clip,
+                                            * the filter state carried on from the frames before it (radae_txe.py:138-144) */
+        if (rade_batch_tx_eoo(h, h->eoo_filt, RD_NEOO, stream) != RD_NEOO) return -1;
+        a.eoo = h->eoo_filt;
+    }
     PROF_BEGIN(h, stream);
     if (rd_launch_channel(&a, stream)) return -1;
     PROF_END(h, stream, RADE_PROF_CHAN, 0.0);

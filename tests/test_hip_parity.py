@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 INT_KEYS = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tmax", "f_ind_max", "valid_count", "uw_errors", "synced_count", "snr_int"]
 RX_CASES = ["awgn", "mpp", "slip_plus", "slip_minus", "foff"]
@@ -221,6 +222,52 @@ def test_tx_bpf_and_clip_golden(Engine, torch_dev, golden, oracle, oracle_model)
     plain = Engine(2, max_tx_mf=n_mf)
     assert rms(plain.tx(torch.tensor(f2, device=torch_dev)).cpu().numpy()[0], g["tx"]) > 1e-2      # the option is off by default
     plain.close()
+
+
+def test_tx_bpf_single_stream_c_abi_and_channel_eoo(Engine, torch_dev, golden):
+    """The Tx band-pass filter + clip through the OTHER two doors: (i) the single-stream C ABI -- radae_amd.api.radae_tx(txbpf_en=True) = rade_open(flags |
+    RADE_BATCH_TX_BPF), rade_tx() per frame and rade_tx_eoo() against the reference's own radae_tx(txbpf_en=True) output (tests/golden/txbpf.npz; radae_txe.py:74-83,
+    :130-132, :141-143); (ii) the channel's with_eoo: the end-of-over frame a receiver sees behind the last frame is the FILTERED one, the filter state carried
+    over from the frames (what `radae_tx.py --txbpf | ch` hands to the receiver), both through rade_batch_tx + rade_batch_channel and rade_batch_tx_channel."""
+    import torch
+    from radae_amd import api
+    g = golden("txbpf"); n_mf = 6
+    tx = api.radae_tx(txbpf_en=True)
+    out = np.zeros(960, np.complex64); eo = np.zeros(1152, np.complex64)
+    for k in range(n_mf):
+        tx.do_radae_tx(g["features"][12 * k:12 * k + 12].ravel(), out)
+        assert np.abs(out - g["tx"][960 * k:960 * k + 960]).max() < 2e-5, k
+    tx.do_eoo(eo)
+    assert np.abs(eo - g["eoo"]).max() < 2e-5 and np.abs(eo).max() <= 1.0 + 1e-6
+    tx.h.close()
+    f1 = torch.tensor(g["features"][None], device=torch_dev)
+    eng = Engine(1, max_tx_mf=n_mf, flags=0x400)
+    iq = eng.tx(f1)
+    rx = eng.channel(iq, 0.0, 0.0, n_pre=0, n_post=0, with_eoo=True).cpu().numpy()[0]        # no noise, no offset, no multipath: gain 1 is not implied, so compare shapes
+    gain = np.vdot(g["tx"], rx[:n_mf * 960]) / np.vdot(g["tx"], g["tx"])                      # the channel's power normalisation of the signal part
+    assert abs(gain.imag) < 1e-6 and np.abs(rx[:n_mf * 960] - gain.real * g["tx"]).max() < 3e-5
+    assert np.abs(rx[n_mf * 960:n_mf * 960 + 1152] - gain.real * g["eoo"]).max() < 3e-5      # the EOO frame behind it: filtered + clipped, state carried on
+    eng.tx_reset()
+    rx2 = eng.tx_channel(f1, 0.0, 0.0, n_pre=0, n_post=0, with_eoo=True).cpu().numpy()[0]
+    assert np.array_equal(rx2, rx)
+    eng.close()
+
+
+def test_blocking_wait_equals_spinning():
+    """The host path an 8-GPU job takes under a 16-core quota (8 ranks x 3 engines > CPUs): rade_batch_rx sleeps on a hipEventBlockingSync event instead of
+    spinning (rade_engine.c: sync_blocking_now).  Three engines on three streams / host threads, two steps each: RADE_SYNC=block returns bit for bit what
+    RADE_SYNC=spin returns, the waits are counted as blocking, and RADE_SYNC_PEERS=64 makes the automatic policy choose blocking by itself."""
+    import json, subprocess, sys
+    def run(**env):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "sync_mode_check.py")], env=e, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    spin, block, auto = run(RADE_SYNC="spin"), run(RADE_SYNC="block"), run(RADE_SYNC_PEERS="64")
+    assert spin["rx_waits_blocking"] == 0 and spin["rx_waits_spinning"] > 0
+    assert block["rx_waits_blocking"] > 0 and block["rx_waits_spinning"] == 0
+    assert auto["rx_waits_blocking"] > 0 and auto["rx_waits_spinning"] == 0
+    assert spin["sha256"] == block["sha256"] == auto["sha256"] and spin["decoded"] > 0
 
 
 def test_rx_call_chunking_is_invariant(Engine, torch_dev, golden, monkeypatch):
