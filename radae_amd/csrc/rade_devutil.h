@@ -48,13 +48,18 @@ __device__ __forceinline__ double dgrid_nc(double start, int i, double delta)
     return start + p;
 }
 
-// one term of the modulator's 30-term IDFT as two packed FMAs (v_pk_fma_f32: both components of a sample in one instruction; the scalar form,
-// 720 FMAs per thread, was half of k_ofdm_mod_mp's time): acc += s.re (w.re, w.im); acc += s.im (-w.im, w.re).  Every place that synthesises a
+// one term of the modulator's 30-term IDFT: acc += s.re (w.re, w.im); acc += s.im (-w.im, w.re), as four fused multiply-adds.  Every place that synthesises a
 // transmit sample uses this one form, so the same sample comes out the same bits wherever it is computed.
+// Round 4 issued the four as two v_pk_fma_f32 (both components of a sample in one instruction, the (s.re, s.re) / (-w.im, w.re) operands formed by the
+// instruction's op_sel / neg_lo modifiers): 10 us faster per modulator launch, and NOT reproducible -- under load (three batches in flight) about one 16-sample
+// block in 15,000 frames came out different from run to run, always lanes 48..63 of a wavefront, always a data symbol, the encoder's latents bit-identical
+// (tools/tx_determinism.py: 125..283 differing blocks per 3.8 M frames with the packed form, 0 in 19 M frames with this one; profiles/r05_tx_determinism.txt).
+// The plain packed FMAs of the encoder's GRU scan (no operand modifiers) do not show it (same runs: z identical).
 __device__ __forceinline__ f32x2 idft_term(f32x2 acc, float2 sy, float2 w)
 {
-    acc = __builtin_elementwise_fma((f32x2){ sy.x, sy.x }, (f32x2){ w.x, w.y }, acc);
-    return __builtin_elementwise_fma((f32x2){ sy.y, sy.y }, (f32x2){ -w.y, w.x }, acc);
+    acc[0] = fmaf(sy.x, w.x, acc[0]); acc[1] = fmaf(sy.x, w.y, acc[1]);
+    acc[0] = fmaf(sy.y, -w.y, acc[0]); acc[1] = fmaf(sy.y, w.x, acc[1]);
+    return acc;
 }
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }

@@ -1252,7 +1252,10 @@ __device__ __forceinline__ void rx2_bpf_own(RxShared2 *sh, const rd_sync_args &a
 template <int CTRL> __device__ __forceinline__ float dpp_f32(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
 #define DPP_ROW_HALF_MIRROR 0x141   /* lane i <-> 7 - i inside every group of eight lanes */
 
-__global__ __launch_bounds__(NT2, 2) void k_rx_sync2(rd_sync_args a)
+#ifndef RX2_WG_PER_CU
+#define RX2_WG_PER_CU 2          /* developer switch: the register budget of a build that would hold three workgroups per CU (168 VGPRs) */
+#endif
+__global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     RxShared2 *sh = (RxShared2 *)smem_raw;

@@ -253,6 +253,17 @@ def test_tx_bpf_single_stream_c_abi_and_channel_eoo(Engine, torch_dev, golden):
     eng.close()
 
 
+def test_transmit_side_is_bit_reproducible_under_load():
+    """Three engines on three HIP streams / host threads (bench.py's pipeline) run the same utterances step after step: every step's transmit samples and
+    received samples are bit-identical to the first step's.  (Round 5: with the modulator's IDFT on v_pk_fma_f32 with operand modifiers, one 16-sample block
+    in ~15,000 frames differed from run to run under exactly this load -- ~40 blocks in this test's 64 x 42 x 15 frames; rade_devutil.h: idft_term.)"""
+    import json, subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "tx_determinism.py"), "6", "64", "504"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["frames_checked"] == 3 * 5 * 64 * 42 and d["mismatching_blocks"] == 0, d["detail"][:4]
+
+
 def test_blocking_wait_equals_spinning():
     """The host path an 8-GPU job takes under a 16-core quota (8 ranks x 3 engines > CPUs): rade_batch_rx sleeps on a hipEventBlockingSync event instead of
     spinning (rade_engine.c: sync_blocking_now).  Three engines on three streams / host threads, two steps each: RADE_SYNC=block returns bit for bit what
