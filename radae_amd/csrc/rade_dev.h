@@ -23,6 +23,7 @@ extern "C" {
 #define RD_NEOO     1152
 #define RD_RXBUF    2112  /* 2*Nmf + M + Ncp */
 #define RD_NFC      40    /* coarse frequency bins */
+#define RD_NQ       16    /* polynomial moments of the two-stage pilot correlator (rade_host.c: rd_corrq16_table_fill) */
 #define RD_NTAP     101
 #define RD_NINMAX   1120
 #define RD_LATENT   80
@@ -192,7 +193,8 @@ typedef struct {
     rd_decs_args dec;                                    /* the decoder runs inside the stream's workgroup (rx_decode_pending) */
     float *features_out; long feat_stride;               /* [B][cap][432] */
     int feat_cap;                                        /* valid modem frames features_out holds per stream: a stream stops making calls once it has produced that many */
-    const unsigned short *corr16;                        /* rd_corr16_table_fill(): [5][10][2][64][8] binary16 */
+    const unsigned short *corr16;                        /* rd_corr16_table_fill(): [5][10][2][64][8] binary16 (the one-stage correlator: -DRX2_ONE_STAGE builds) */
+    const unsigned short *corrq16, *corra16;             /* rd_corrq16_table_fill() [2][10][2][64][8] / rd_corra16_table_fill() [5][2][64][8]: the two-stage pilot correlator */
     float *zrows;                                        /* [B][dec_rows][80] */
     float *dtcache;                                      /* [B][960][40] |Dt2| surface of the previous detect_pilots call */
     int *status;                                         /* [B][4]: nin, sync, snr_int, state */

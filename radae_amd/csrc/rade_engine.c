@@ -74,7 +74,7 @@ struct rade_batch {
     int B, max_tx_mf, device, flags, trace_cap, Tcap;
     int R, dec_rows;                      /* do_radae_rx calls per stream per sync launch; 3R decoder slots */
     int unsync_off_after;                 /* int(disable_unsync * Fs / Nmf) or -1 */
-    unsigned short *corr16, *wfwd16, *bpf16; double *vm; int rx_lds, rx_census;   /* dynamic LDS of a receiver launch; phase mask of the -DRX2_CENSUS developer build */
+    unsigned short *corr16, *corrq16, *corra16, *wfwd16, *bpf16; double *vm; int rx_lds, rx_census;   /* dynamic LDS of a receiver launch; phase mask of the -DRX2_CENSUS developer build */
     int feat_in, enc_kpad, bottleneck1;   /* 84 (model19: 4x21) or 80 (model05/bbfm: 4x20); tanh on z when bottleneck 1 */
     float *dec2_x, *dec2_gi, *dec2_hbuf, *dec2_h[5];   /* stand-alone decoder (rade_batch_decode) */
     rd_tables *d_tab;
@@ -260,6 +260,14 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
         unsigned short *c16 = malloc(sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8);
         if (c16) { rd_corr16_table_fill(tab, c16); h->corr16 = dev_upload(c16, sizeof(unsigned short) * 5 * 10 * 2 * 64 * 8); free(c16); }
     }
+    {   /* the same correlator in two stages: 16 polynomial moments, then their expansion to the 40 frequencies (rade_host.c) */
+        unsigned short *q16 = malloc(sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8), *a16 = malloc(sizeof(unsigned short) * 5 * 2 * 64 * 8);
+        if (q16 && a16) {
+            rd_corrq16_table_fill(tab, q16); h->corrq16 = dev_upload(q16, sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8);
+            rd_corra16_table_fill(tab, a16); h->corra16 = dev_upload(a16, sizeof(unsigned short) * 5 * 2 * 64 * 8);
+        }
+        free(q16); free(a16);
+    }
     {   /* the demodulator DFT matrix as matrix-core operands (k_rx_sync2) */
         unsigned short *w16 = malloc(sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8);
         if (w16) { rd_wfwd16_table_fill(tab, w16); h->wfwd16 = dev_upload(w16, sizeof(unsigned short) * 2 * 10 * 2 * 64 * 8); free(w16); }
@@ -279,7 +287,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
      * (developer switch) asks for more than half a CU's LDS, i.e. one workgroup per CU. */
     h->rx_lds = rd_rx_sync_prepare(getenv("RADE_RX2_SOLO") != NULL);
     h->rx_census = getenv("RADE_RX2_CENSUS") ? atoi(getenv("RADE_RX2_CENSUS")) : 0;      /* only acts in -DRX2_CENSUS builds */
-    if (!h->d_tab || !h->corr16 || !h->vm || !h->wfwd16 || !h->bpf16 || h->rx_lds <= 0) goto fail;
+    if (!h->d_tab || !h->corr16 || !h->corrq16 || !h->corra16 || !h->vm || !h->wfwd16 || !h->bpf16 || h->rx_lds <= 0) goto fail;
 
     int err = 0;
     h->feat_in = m.enc_dense1.n_in; h->enc_kpad = (h->feat_in + 15) & ~15; h->bottleneck1 = (cfg->flags & RADE_BATCH_BOTTLENECK1) != 0;
@@ -401,7 +409,7 @@ void rade_batch_close(rade_batch *h)
     if (!h) return;
     ON_DEV(h);
     void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail,
-                     h->rx_progress /* + rx_acc, rx_status */, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->eoo_filt, h->corr16, h->vm, h->chan_mp, h->wfwd16 };
+                     h->rx_progress /* + rx_acc, rx_status */, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->eoo_filt, h->corr16, h->corrq16, h->corra16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
     for (int l = 0; l < 5; l++) {
@@ -771,7 +779,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     memset(&sa, 0, sizeof sa);
     sa.tab = h->d_tab; sa.st = h->rx_st; sa.round = h->rx_round; sa.rx = rx_dev; sa.rx_stride = rx_stride; sa.rxf = h->rx_filt; sa.rxf_stride = h->filt_cap; sa.bpf16 = h->bpf16; sa.bpf_chain = h->bpf_chain; sa.chain_stride = h->chain_stride; sa.avail = h->rx_avail; sa.acc = h->rx_acc;
     sa.max_calls = max_calls; sa.round_calls = h->R; sa.dec_rows = h->dec_rows; sa.unsync_off_after = h->unsync_off_after;
-    sa.corr16 = h->corr16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
+    sa.corr16 = h->corr16; sa.corrq16 = h->corrq16; sa.corra16 = h->corra16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_census << 8; sa.lds_bytes = h->rx_lds;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
     sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */

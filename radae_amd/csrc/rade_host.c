@@ -472,6 +472,101 @@ void rd_corr16_table_fill(const rd_tables *T, unsigned short *out /* [5][10][2][
                 }
 }
 
+/* ---- the pilot correlator in two stages (round 5) -------------------------------------------------------------------------------------------
+ * p_w[m][f] = p[m] e^{j w_f m} for the 40 coarse frequencies |f| <= 50 Hz spans a window of 160 samples: the phase e^{j w_f (m - 79.5)} moves by at most
+ * +-pi across it, i.e. as a function of x = (m - 79.5) / 80 it is band-limited to a time-bandwidth product of 2 and is reproduced to 1.7e-10 by its
+ * projection on the first RD_NQ = 16 polynomials q_r orthonormal on the 160 grid points (14: 1.8e-8, 12: 1.5e-6):
+ *     p_w[m][f] = sum_r alpha[r][f] s_r[m],   s_r[m] = p[m] q_r(x_m),   alpha[r][f] = e^{j w_f 79.5} sum_m q_r(x_m) e^{j w_f (m - 79.5)}
+ * so Dt[t][f] = sum_m conj(rx[t + m]) p_w[m][f] = sum_r alpha[r][f] Mom_r[t] with the 16 "moments" Mom_r[t] = sum_m conj(rx[t + m]) s_r[m]: the big
+ * product (K = 320 real) has 32 rows (two 16-row tiles) instead of 80 (five), and a second product with K = 32 expands the moments to the 40 frequencies.
+ * On v_mfma_f32_16x16x32_f16: 2 x 10 x 3 + 5 x 5 = 85 matrix instructions per tile of 16 timings instead of 5 x 10 x 3 = 150.
+ * rd_corrq16_table_fill: stage 1, the realified s_r (rows n' = 2 r + c', k = 2 m + c as in rd_corr16_table_fill), 2^12-scaled, two binary16 planes,
+ *                        A-operand order: out[tile][s][plane][lane][j]
+ * rd_corra16_table_fill: stage 2, A2[n = 2 f + c''][n'] = {ar, -ai; ai, ar} of alpha[r][f], 2^10-scaled, two planes.  Its K axis is ordered the way
+ *                        stage 1's accumulators lie in a lane (C layout of two 16-row tiles: lane group g holds rows 4 g .. 4 g + 3 of either tile), so that
+ *                        the moments go from accumulator registers to B-operand registers without leaving the lane:
+ *                        k-slot (g, j): n' = 4 g + j (j < 4), 16 + 4 g + (j - 4) (j >= 4).   out[tile][plane][lane][j] */
+static void corr_basis(const rd_tables *T, double q[RD_NQ][RD_M], double alr[RD_NQ][RD_NFC], double ali[RD_NQ][RD_NFC])
+{
+    /* orthonormal polynomials on x_m = (m - 79.5) / 80: Legendre recurrence, then two passes of modified Gram-Schmidt on the grid */
+    double x[RD_M];
+    for (int m = 0; m < RD_M; m++) x[m] = ((double)m - 79.5) / 80.0;
+    for (int m = 0; m < RD_M; m++) { q[0][m] = 1.0; q[1][m] = x[m]; }
+    for (int r = 1; r + 1 < RD_NQ; r++)
+        for (int m = 0; m < RD_M; m++) q[r + 1][m] = ((2.0 * r + 1.0) * x[m] * q[r][m] - (double)r * q[r - 1][m]) / (r + 1.0);
+    for (int r = 0; r < RD_NQ; r++) {
+        for (int pass = 0; pass < 2; pass++)
+            for (int u = 0; u < r; u++) {
+                double d = 0.0;
+                for (int m = 0; m < RD_M; m++) d += q[u][m] * q[r][m];
+                for (int m = 0; m < RD_M; m++) q[r][m] -= d * q[u][m];
+            }
+        double n2 = 0.0;
+        for (int m = 0; m < RD_M; m++) n2 += q[r][m] * q[r][m];
+        const double inv = 1.0 / sqrt(n2);
+        for (int m = 0; m < RD_M; m++) q[r][m] *= inv;
+    }
+    for (int f = 0; f < RD_NFC; f++) {
+        const double wf = 2.0 * PI_D * T->fcoarse[f] / 8000.0, cr = cos(wf * 79.5), ci = sin(wf * 79.5);
+        for (int r = 0; r < RD_NQ; r++) {
+            double ar = 0.0, ai = 0.0;
+            for (int m = 0; m < RD_M; m++) { ar += q[r][m] * cos(wf * ((double)m - 79.5)); ai += q[r][m] * sin(wf * ((double)m - 79.5)); }
+            alr[r][f] = ar * cr - ai * ci; ali[r][f] = ar * ci + ai * cr;
+        }
+    }
+}
+void rd_corrq16_table_fill(const rd_tables *T, unsigned short *out /* [2][10][2][64][8] */)
+{
+    static double q[RD_NQ][RD_M], alr[RD_NQ][RD_NFC], ali[RD_NQ][RD_NFC];
+    corr_basis(T, q, alr, ali);
+    for (int nt = 0; nt < 2; nt++)
+        for (int s = 0; s < 10; s++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int j = 0; j < 8; j++) {
+                    const int n = 16 * nt + (lane & 15), r = n >> 1, cp = n & 1;
+                    const int k = 32 * s + 8 * (lane >> 4) + j, m = k >> 1, c = k & 1;
+                    const double sr = (double)T->p[m][0] * q[r][m], si = (double)T->p[m][1] * q[r][m];
+                    const float v = (float)(4096.0 * (cp == 0 ? (c == 0 ? sr : si) : (c == 0 ? si : -sr)));
+                    const unsigned short hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                    unsigned short *o = out + ((((size_t)nt * 10 + s) * 2) * 64 + lane) * 8 + j;
+                    o[0] = hi; o[64 * 8] = lo;
+                }
+}
+void rd_corra16_table_fill(const rd_tables *T, unsigned short *out /* [5][2][64][8] */)
+{
+    static double q[RD_NQ][RD_M], alr[RD_NQ][RD_NFC], ali[RD_NQ][RD_NFC];
+    corr_basis(T, q, alr, ali);
+    for (int nt = 0; nt < 5; nt++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int j = 0; j < 8; j++) {
+                const int n = 16 * nt + (lane & 15), f = n >> 1, cpp = n & 1;
+                const int g = lane >> 4, np_ = j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4), r = np_ >> 1, cp = np_ & 1;
+                const double ar = alr[r][f], ai = ali[r][f];
+                const float v = (float)(1024.0 * (cpp == 0 ? (cp == 0 ? ar : -ai) : (cp == 0 ? ai : ar)));
+                const unsigned short hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
+                unsigned short *o = out + (((size_t)nt * 2) * 64 + lane) * 8 + j;
+                o[0] = hi; o[64 * 8] = lo;
+            }
+}
+/* test aid (tests/test_host_cpu.py): the two tables multiplied back together on the host, out[m][f] (re, im) ~ p_w[m][f]: max |difference| is returned */
+double rd_corr_tables_check(const rd_tables *T)
+{
+    static double q[RD_NQ][RD_M], alr[RD_NQ][RD_NFC], ali[RD_NQ][RD_NFC];
+    corr_basis(T, q, alr, ali);
+    double worst = 0.0;
+    for (int m = 0; m < RD_M; m++)
+        for (int f = 0; f < RD_NFC; f++) {
+            double re = 0.0, im = 0.0;
+            for (int r = 0; r < RD_NQ; r++) {
+                const double sr = (double)T->p[m][0] * q[r][m], si = (double)T->p[m][1] * q[r][m];
+                re += alr[r][f] * sr - ali[r][f] * si; im += alr[r][f] * si + ali[r][f] * sr;
+            }
+            const double d = hypot(re - (double)T->p_w[m][f][0], im - (double)T->p_w[m][f][1]);
+            if (d > worst) worst = d;
+        }
+    return worst;
+}
+
 /* The demodulator DFT of k_rx_sync2 on the f16 matrix cores (receiver_one, dsp.py:487-526: sym[s][c] = sum_n x_s[n] Wfwd[n][c]).  With the row
  * R[c][2n + comp] = (wr, -wi)[comp] the real part is R . (xr, xi) and the imaginary part R . (xi, -xr): ONE 32-row operand (30 carriers) serves both, the two
  * variants of the window are two groups of B columns.  Two binary16 planes in the A-operand order of v_mfma_f32_16x16x32_f16 like the pilot table above:

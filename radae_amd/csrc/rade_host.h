@@ -29,6 +29,9 @@ void rd_model_free(rd_model *m);
 
 long rd_packed16_size(int N, int K);
 void rd_corr16_table_fill(const rd_tables *T, unsigned short *out);
+void rd_corrq16_table_fill(const rd_tables *T, unsigned short *out);     /* [2][10][2][64][8]: stage 1 of the two-stage pilot correlator (rade_host.c) */
+void rd_corra16_table_fill(const rd_tables *T, unsigned short *out);     /* [5][2][64][8]: stage 2 */
+double rd_corr_tables_check(const rd_tables *T);
 void rd_wfwd16_table_fill(const rd_tables *T, unsigned short *out);
 void rd_bpf16_table_fill(const rd_tables *T, unsigned short *out);   /* [4][2][64][8] */
 long rd_pack_weights_f16x2(const float *W, int N, int K, unsigned short *out);

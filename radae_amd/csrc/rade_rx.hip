@@ -10,6 +10,7 @@
 // Rounds 2-3 carried a second receiver kernel (k_rx_sync: 512 threads, one stream per CU) that this one was forked from; it is gone: one
 // receiver, every fix lands once.
 #include "rade_devutil.h"
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- decoder stage inside the receiver: LDS layout helpers and product descriptors ----
 #define DQ_XB 96                 // 8-half blocks per x row
@@ -60,6 +61,9 @@ __device__ static constexpr uint32_t LCG_A[48] = { 1664525u, 389569705u, 2940799
 __device__ static constexpr uint32_t LCG_C[48] = { 1013904223u, 1196435762u, 3519870697u, 2868466484u, 1649599747u, 2670642822u, 1476291629u, 2748932008u, 2180890343u, 2498801434u, 3421909937u, 3167820124u, 2636375307u, 3801544430u, 28987765u, 2210837584u, 3039689583u, 1338634754u, 1649346937u, 2768872580u, 2254235155u, 2326606934u, 1719328701u, 1061592568u, 53332215u, 1140036074u, 4224358465u, 2629538988u, 1946028059u, 573775550u, 1473591045u, 95141024u, 1592739711u, 1618554578u, 4257218569u, 2685635028u, 2617994019u, 740185638u, 4194465613u, 2426187848u, 967350023u, 366635194u, 2557108433u, 3503432700u, 353185579u, 706247310u, 408928405u, 1855199472u };
 
 #define NT2 256
+#ifndef RX2_WSPLIT
+#define RX2_WSPLIT 896           /* check_pilots phase: frequency-corrected window samples [0, RX2_WSPLIT) on wavefronts 2 / 3, the rest on 0 / 1 (which run the matrix part) */
+#endif
 // thread index rebuilt from the lane counter and the wavefront's index (held in a scalar register): three instructions wherever it
 // is needed, instead of one value that stays live -- and gets spilled -- across the whole receive call (rx_tid() keeps threadIdx.x
 // alive the same way)
@@ -515,10 +519,9 @@ struct RxShared2 {
             float eqP[RD_NC]; float2 eqPmat[RD_NC][2][3], eqrot[RD_NC]; float eq_pg, eq_snrc1, eq_snrc2, eq_pad;
             union {
               struct {
-                unsigned rxh[RD_RXBUF], rxl[RD_RXBUF];          // check_pilots: rx_buf in two binary16 planes
+                u32x2 rxhl[RD_RXBUF];                           // check_pilots: rx_buf in two binary16 planes, a sample's (high, low) words side by side: one 8-byte read brings both
                 double rmom[2][2][64][4];                       // refine(), in-sync grid: partial moment tiles [half of the samples][frame]
                 double mtot[2][16][16];                         // the moments [frame][2 m + (re | im)][t]
-                float absd2[96][2];                             // check_pilots: row sums of |Dt| over the two frequency-tile groups
               };
               struct {                                          // refine() on sync entry (+-10 Hz): direct sums
                 double2 rtw[80], rrot80[80], rt80[80];
@@ -526,9 +529,10 @@ struct RxShared2 {
               };
             };
           };
-          struct {                                              // search / candidate state: pilot correlator on the matrix cores (rx2_detect_mfma)
-            __attribute__((aligned(16))) _Float16 sA[2][5 * 2 * 64 * 8];   // the correlation table's A operands of one k-step, double-buffered (2 x 10 KB)
-            unsigned srxh[RD_RXBUF], srxl[RD_RXBUF];            // rx_buf in two binary16 planes (as rxh / rxl in the synchronised state)
+          struct {                                              // search / candidate state: two-stage pilot correlator on the matrix cores (rx2_detect_q)
+            __attribute__((aligned(16))) _Float16 sA[2][2 * 2 * 2 * 64 * 8];   // stage 1's A operands (moment table) of TWO k-steps, double-buffered (2 x 8 KB)
+            __attribute__((aligned(16))) _Float16 sA2[5 * 2 * 64 * 8];         // stage 2's A operands (moments -> 40 frequencies), whole: 10 KB
+            unsigned srxh[RD_RXBUF], srxl[RD_RXBUF];            // rx_buf in two binary16 planes
           };
         };
       };
@@ -593,48 +597,77 @@ __device__ float sigma_r_from_rowsums2(RxShared2 *sh)
 
 
 // ---- |Dt| surfaces on the matrix cores ----------------------------------------------------------------------------------------------
-// acquisition.detect_pilots (dsp.py:178-231): Dt[t, f] = sum_m conj(rx[t + m]) p_w[m, f] for all 960 timings x 40 frequencies of a frame.
-// k_rx_sync does this by FFT convolution on the vector ALU (one 2048-point inverse transform per frequency): 52 % of ALL vector
-// instructions of a k_rx_sync2 launch on the bench workload although only one call in eight is in the search state (tools/rx2_census.sh),
-// and with two workgroups per CU the vector ALU is the shared resource.  Here the same sums are the real GEMM check_pilots already runs
-// for its 48 rows -- [80 = (f, re | im)] x [320 = (m, re | im)] times the Toeplitz matrix rx[t + m] -- on v_mfma_f32_16x16x32_f16 with both
-// operands in two binary16 planes (hi hi + hi lo + lo hi: 22 bits): 9000 instructions per surface, 36 k cycles per SIMD, and under 10 %
-// of the FFT form's vector instructions (the |.|, the row sums and the running arg-max are all that is left).
-//   * a wavefront owns 15 timing tiles (240 timings) and walks them in groups of RT = 5 against all five frequency tiles: 25 accumulators;
-//   * the A operands (table, 100 KB: too big for LDS) are staged one k-step (10 KB) at a time by the whole workgroup, double-buffered,
-//     one barrier per k-step: 300 KB of L2 reads per surface and workgroup instead of 1.2 MB if every wavefront fetched its own;
-//   * the B operand of (timing tile T, k-step s) is the fragment of (T + s, 0): the window slides by one tile per k-step, so a group
-//     reads RT + 9 fragments from the planes instead of 10 RT.
-// Outputs: |Dt2| (and |Dt1| when not cached) to the stream's cache in HBM, the row sums to rowsum1 / rowsum2, and the lane's best
-// (Dt1 + Dt2, t, f) with the earliest t and lowest f on ties, to be reduced by block_argmax2.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void rx2_detect_mfma(RxShared2 *sh, const unsigned short *corr16_, float *cache_, int cached, int oldb, int newb, float rx_unsc,
-                                                float &best, int &bt, int &bfi)
+// acquisition.detect_pilots (dsp.py:178-231): Dt[t, f] = sum_m conj(rx[t + m]) p_w[m, f] for all 960 timings x 40 frequencies of a frame: a real GEMM
+// [(row, re | im)] x [320 = (m, re | im)] times the Toeplitz matrix rx[t + m] on v_mfma_f32_16x16x32_f16, both operands in two binary16 planes
+// (hi hi + hi lo + lo hi: 22 bits).
+//   * a wavefront owns 15 timing tiles (240 timings) and walks them in groups of RT = 5;
+//   * the A operands (table) are staged through LDS by the whole workgroup, double-buffered, one barrier per stage;
+//   * the B operand of (timing tile T, k-step s) is the fragment of (T + s, 0): the window slides by one tile per k-step, so a group reads RT + 9 fragments
+//     from the planes instead of 10 RT.
+// (Rounds 3-4 multiplied by the 80 rows of p_w itself: tools/experiments/rx2_search_one_stage.inc.)
+// ---- the pilot correlator in two stages (round 5; the tables and the algebra: rade_host.c, rd_corrq16_table_fill) ----------------------------------
+// Dt[t][f] = sum_r alpha[r][f] Mom_r[t]: stage 1 is the product above with the 32 rows (r, re | im) of the moment table instead of the 80 rows (f, re | im)
+// of p_w -- two row tiles instead of five, 60 matrix instructions per tile of 16 timings instead of 150 --, stage 2 expands the 16 complex moments of a timing
+// tile to the 40 frequencies with ONE k-step (K = 32) per frequency tile.  Stage 1's accumulators ARE stage 2's B operand: the C layout of two 16-row tiles
+// gives lane group g rows 4 g .. 4 g + 3 of either tile, and the host orders stage 2's K axis exactly so (rd_corra16_table_fill) -- the moments are scaled,
+// split into three binary16 planes (33 bits: stage 2 adds nothing to stage 1's rounding) and fed back without leaving the lane.
+struct MomPlanes { f16x8 h, m, l; };
+__device__ __forceinline__ MomPlanes mom_split(const f32x4 a0, const f32x4 a1)
+{
+    MomPlanes p;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {      // |moment| <= 2^8 sqrt(2) x the table row's L1 norm (3545 x 2^... : rade_host.c) -> 2^-7 of it is below 7100, far inside binary16
+        const float v = 0x1p-7f * (j < 4 ? a0[j & 3] : a1[j & 3]);
+        const _Float16 h = (_Float16)v; const float r1 = v - (float)h;
+        const _Float16 m = (_Float16)r1; const float r2 = r1 - (float)m;
+        p.h[j] = h; p.m[j] = m; p.l[j] = (_Float16)r2;
+    }
+    return p;
+}
+// one frequency tile (8 frequencies x (re, im)) of Dt for the 16 timings whose moments are in p: smallest partial products first
+__device__ __forceinline__ f32x4 mom_expand(const f16x8 ah, const f16x8 al, const MomPlanes &p)
+{
+    f32x4 c = { 0.0f, 0.0f, 0.0f, 0.0f };
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, p.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, p.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, p.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, p.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, p.h, c, 0, 0, 0);
+    return c;
+}
+// acquisition.detect_pilots' surfaces by the two-stage correlator: same contract as rx2_detect_mfma (outputs: |Dt2| -- and |Dt1| when not cached -- to the stream's
+// cache in HBM, the row sums to rowsum1 / rowsum2, the lane's best (Dt1 + Dt2, t, f)).  rx_unsc undoes the scales of the rx planes and the stage-1 table; the
+// 2^-7 of the moments and the 2^10 of the stage-2 table are undone here.
+__device__ __forceinline__ void rx2_detect_q(RxShared2 *sh, const unsigned short *corrq16_, const unsigned short *corra16_, float *cache_, int cached, int oldb, int newb,
+                                             float rx_unsc_, float &best, int &bt, int &bfi)
 {
     constexpr int RT = 5, NTF = 5, TPW = 15;
     static_assert(TPW * NW2 * 16 == RD_NMF && TPW % RT == 0, "timing tiles per wavefront");
-    typedef const __attribute__((address_space(1))) f16x8 glb_f16x8_t;
     const int tid = rx_tid(), wave = rx2_wave(), lane = tid & 63, i = lane & 15, g = lane >> 4;
-    // chunk c = 128 nt + 64 plane + lane of a k-step (640 x 16 B): thread tid takes c = tid, tid + 256 and (wavefronts 0 / 1) tid + 512, i.e. the
-    // same lane offset under three uniform bases
-    // Buffer loads (uniform descriptor + 32-bit lane offset + scalar offset): with plain pointers the compiler keeps one 64-bit address
-    // per (base, k-step) in VGPRs, spills them, and every k-step starts with scratch reloads under s_waitcnt vmcnt(0).
-    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corr16_), 0, 5 * 10 * 2048, 0x00020000);
-    const int vo = (((tid >> 7) * 10) * 128 + (tid & 127)) * 16;
-    const bool third = wave < 2;                       // wave-uniform
-    u32x4 stg[3];
-    auto stage_load = [&](int sidx) {
-        stg[0] = __builtin_amdgcn_raw_buffer_load_b128(crs, vo, sidx * 2048, 0); stg[1] = __builtin_amdgcn_raw_buffer_load_b128(crs, vo, sidx * 2048 + 2 * 10 * 2048, 0);
-        if (third) stg[2] = __builtin_amdgcn_raw_buffer_load_b128(crs, vo, sidx * 2048 + 4 * 10 * 2048, 0);
+    const float rx_unsc = rx_unsc_ * 0x1p-3f;
+    // stage 1's table [tile][k-step][plane][lane] (16 B per lane): a stage buffer holds two k-steps of both tiles, chunk u = 256 tile + 128 (k-step & 1) + 64 plane + lane,
+    // i.e. thread tid brings chunks tid and 256 + tid: one lane offset under two uniform bases
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corrq16_), 0, 2 * 10 * 2048, 0x00020000);
+    const int vo = tid * 16;
+    u32x4 stg[2];
+    auto stage_load = [&](int sb) {
+        stg[0] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, sb * 4096, 0); stg[1] = __builtin_amdgcn_raw_buffer_load_b128(qrs, vo, sb * 4096 + 10 * 2048, 0);
     };
-    auto stage_store = [&](int buf) {
-        _Float16 *d = &sh->sA[buf][tid * 8];
-        *(u32x4 *)d = stg[0]; *(u32x4 *)(d + 256 * 8) = stg[1];
-        if (third) *(u32x4 *)(d + 512 * 8) = stg[2];
-    };
+    auto stage_store = [&](int buf) { _Float16 *d = &sh->sA[buf][tid * 8]; *(u32x4 *)d = stg[0]; *(u32x4 *)(d + 256 * 8) = stg[1]; };
     PH2_T0();
-    float lbest = best; int lkey = 0x7fffffff;                      // (t << 6) | f of the best; callers start from best = -1, which the first sum replaces
-    stage_load(0); stage_store(0);
+    {   // stage 2's table, whole (640 x 16 B)
+        const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corra16_), 0, 5 * 2048, 0x00020000);
+        const u32x4 t0 = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, 0, 0), t1 = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, 4096, 0);
+        u32x4 t2 = { 0u, 0u, 0u, 0u };
+        if (wave < 2) t2 = __builtin_amdgcn_raw_buffer_load_b128(ars, vo, 8192, 0);
+        stage_load(0);
+        _Float16 *d = &sh->sA2[tid * 8];
+        *(u32x4 *)d = t0; *(u32x4 *)(d + 256 * 8) = t1;
+        if (wave < 2) *(u32x4 *)(d + 512 * 8) = t2;
+        stage_store(0);
+    }
+    float lbest = best; int lkey = 0x7fffffff;
+    int pb = 0;                                                 // the stage buffer being read: flips every stage (five stages per group: the parity runs on across groups)
     __syncthreads();
     PH2(15);
 #pragma unroll 1
@@ -646,75 +679,78 @@ __device__ __forceinline__ void rx2_detect_mfma(RxShared2 *sh, const unsigned sh
 #pragma unroll 1
         for (int grp = 0; grp < TPW / RT; grp++) {
             const int T0 = wave * TPW + grp * RT;
-            f32x4 acc[RT][NTF];
+            f32x4 acc1[RT][2];
 #pragma unroll
-            for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                for (int q = 0; q < NTF; q++) acc[rt][q] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int rt = 0; rt < RT; rt++) { acc1[rt][0] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; acc1[rt][1] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; }
             u32x4 wh[RT + 1], wl[RT + 1];
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) { wh[rt][j] = ph[16 * (T0 + rt) + j]; wl[rt][j] = pl[16 * (T0 + rt) + j]; }
 #pragma unroll
-            for (int sidx = 0; sidx < 10; sidx++) {
-                stage_load(sidx == 9 ? 0 : sidx + 1);
-                if (sidx < 9) {
+            for (int sb = 0; sb < 5; sb++) {
+                stage_load(sb == 4 ? 0 : sb + 1);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { wh[RT][j] = ph[16 * (T0 + RT + sidx) + j]; wl[RT][j] = pl[16 * (T0 + RT + sidx) + j]; }
-                }
-                const _Float16 *Ab = &sh->sA[sidx & 1][lane * 8];
-                // the next frequency tile's fragments are in flight while this one's 15 instructions issue (left to itself the compiler
-                // reads each fragment right before its use and waits for it: ten exposed LDS latencies per k-step, half the phase)
-                f16x8 ch[2], cl[2];
-                ch[0] = *(const f16x8 *)(Ab); cl[0] = *(const f16x8 *)(Ab + 512);
+                for (int ds = 0; ds < 2; ds++) {
+                    const int sidx = 2 * sb + ds;
+                    if (sidx < 9) {
 #pragma unroll
-                for (int q = 0; q < NTF; q++) {
-                    if (q + 1 < NTF) { ch[(q + 1) & 1] = *(const f16x8 *)(Ab + ((q + 1) * 2) * 512); cl[(q + 1) & 1] = *(const f16x8 *)(Ab + ((q + 1) * 2 + 1) * 512); }
+                        for (int j = 0; j < 4; j++) { wh[RT][j] = ph[16 * (T0 + RT + sidx) + j]; wl[RT][j] = pl[16 * (T0 + RT + sidx) + j]; }
+                    }
+                    const _Float16 *Ab = &sh->sA[pb][lane * 8];
+                    const f16x8 a0h = *(const f16x8 *)(Ab + ((0 * 2 + ds) * 2 + 0) * 512), a0l = *(const f16x8 *)(Ab + ((0 * 2 + ds) * 2 + 1) * 512);
+                    const f16x8 a1h = *(const f16x8 *)(Ab + ((1 * 2 + ds) * 2 + 0) * 512), a1l = *(const f16x8 *)(Ab + ((1 * 2 + ds) * 2 + 1) * 512);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q & 1], __builtin_bit_cast(f16x8, wh[rt]), acc[rt][q], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][0], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q & 1], __builtin_bit_cast(f16x8, wl[rt]), acc[rt][q], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][1], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q & 1], __builtin_bit_cast(f16x8, wh[rt]), acc[rt][q], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, __builtin_bit_cast(f16x8, wl[rt]), acc1[rt][0], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, __builtin_bit_cast(f16x8, wl[rt]), acc1[rt][1], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][0], 0, 0, 0);
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][1], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                }
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) { wh[rt] = wh[rt + 1]; wl[rt] = wl[rt + 1]; }
-                stage_store((sidx & 1) ^ 1);
+                    for (int rt = 0; rt < RT; rt++) { wh[rt] = wh[rt + 1]; wl[rt] = wl[rt + 1]; }
+                }
+                stage_store(pb ^ 1);
+                pb ^= 1;
                 __syncthreads();
             }
             PH2(16);
-            // C layout: column = lane & 15 (timing), rows 4 g + r = (re, im) of f = 8 q + 2 g and f + 1
-            const int tb = 16 * T0 + i;
-            // The surfaces in the stream's HBM cache are only ever read back by the lane that wrote them (|Dt2| of this call is |Dt1| of the
-            // next), so their layout is the lane's: per (wavefront, group) 64 lanes x 50 values (rt-major, then frequency tile, then the two
-            // frequencies) as twelve 16-byte vectors [k][lane] + one 8-byte vector [lane].  13 fully coalesced instructions per group and
-            // direction instead of 50 single dwords (store ISSUE was the epilogue: ~10 k cycles per group).
-            const int gb = (wave * (TPW / RT) + grp) * 64 * 2 * RT * NTF * 4;     // byte offset of the group's block
-            // all of the group's |Dt1| (HBM latency) are requested before any arithmetic; the accumulators turn into |Dt2| in place (4 -> 2
-            // registers per tile), which is what makes room for them
-            float pv[RT * 2 * NTF];
-            if (pass) {
+            // ---- stage 2 and the epilogue, one timing tile at a time.  The surfaces in the stream's HBM cache are only ever read back by the lane that wrote them
+            // (|Dt2| of this call is |Dt1| of the next), so their layout is the lane's: per (wavefront, group, timing tile) 64 lanes x 10 values (frequency tile,
+            // then the two frequencies) as two 16-byte vectors [lane] + one 8-byte vector [lane]: fully coalesced.
+            f16x8 A2h[NTF], A2l[NTF];
 #pragma unroll
-                for (int k = 0; k < 12; k++) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, gb + k * 1024, 0);
-                    pv[4 * k] = __uint_as_float(v[0]); pv[4 * k + 1] = __uint_as_float(v[1]); pv[4 * k + 2] = __uint_as_float(v[2]); pv[4 * k + 3] = __uint_as_float(v[3]);
-                }
-                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(prs, lane * 8, gb + 12 * 1024, 0);
-                pv[48] = __uint_as_float(v[0]); pv[49] = __uint_as_float(v[1]);
-            }
-            float dd[RT * 2 * NTF], rsum[RT];
+            for (int q = 0; q < NTF; q++) { A2h[q] = *(const f16x8 *)&sh->sA2[((q * 2) * 64 + lane) * 8]; A2l[q] = *(const f16x8 *)&sh->sA2[((q * 2 + 1) * 64 + lane) * 8]; }
+            const int gb = (wave * (TPW / RT) + grp) * RT * 2560;         // byte offset of the group's block; 2560 B per timing tile
+            float pv[2][2 * NTF];
+            auto pv_load = [&](int slot, int rt) {
+                const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, gb + rt * 2560, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(prs, lane * 16, gb + rt * 2560 + 1024, 0);
+                const u32x2 v2 = __builtin_amdgcn_raw_buffer_load_b64(prs, lane * 8, gb + rt * 2560 + 2048, 0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { pv[slot][k] = __uint_as_float(v0[k]); pv[slot][4 + k] = __uint_as_float(v1[k]); }
+                pv[slot][8] = __uint_as_float(v2[0]); pv[slot][9] = __uint_as_float(v2[1]);
+            };
+            if (pass) pv_load(0, 0);
+            const int tb = 16 * T0 + i;
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                float rs = 0.0f;
+                if (pass && rt + 1 < RT) pv_load((rt + 1) & 1, rt + 1);
+                const MomPlanes mp = mom_split(acc1[rt][0], acc1[rt][1]);
+                float dd[2 * NTF], rs = 0.0f;
 #pragma unroll
                 for (int q = 0; q < NTF; q++) {
-                    const f32x4 c = acc[rt][q];
+                    // C layout: column = lane & 15 (timing), rows 4 g + r = (re, im) of f = 8 q + 2 g and f + 1
+                    const f32x4 c = mom_expand(A2h[q], A2l[q], mp);
                     const float d0 = rx_unsc * __builtin_amdgcn_sqrtf(fmaf(c[0], c[0], c[1] * c[1])), d1 = rx_unsc * __builtin_amdgcn_sqrtf(fmaf(c[2], c[2], c[3] * c[3]));
                     rs += d0; rs += d1;
-                    dd[rt * 2 * NTF + 2 * q] = d0; dd[rt * 2 * NTF + 2 * q + 1] = d1;
+                    dd[2 * q] = d0; dd[2 * q + 1] = d1;
                 }
                 {   // the other three lane groups hold the row's other frequencies: v_permlane16/32_swap (vector ALU, no LDS round trip)
                     const auto p16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
@@ -722,28 +758,22 @@ __device__ __forceinline__ void rx2_detect_mfma(RxShared2 *sh, const unsigned sh
                     const auto p32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
                     rs = __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
                 }
-                rsum[rt] = rs;
-            }
-#pragma unroll
-            for (int k = 0; k < 12; k++)
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){ __float_as_uint(dd[4 * k]), __float_as_uint(dd[4 * k + 1]), __float_as_uint(dd[4 * k + 2]), __float_as_uint(dd[4 * k + 3]) }, drs, lane * 16, gb + k * 1024, 0);
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2){ __float_as_uint(dd[48]), __float_as_uint(dd[49]) }, drs, lane * 8, gb + 12 * 1024, 0);
-            // every lane keeps its own best (t ascending, then f ascending, strict >: the earliest wins); block_argmax2 orders the lanes the same
-            // way.  Branch-free, (t, f) packed in one register: as conditional blocks the compiler kept the three in scratch memory and every
-            // one of the 50 updates was a store + load under s_waitcnt vmcnt(0).
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){ __float_as_uint(dd[0]), __float_as_uint(dd[1]), __float_as_uint(dd[2]), __float_as_uint(dd[3]) }, drs, lane * 16, gb + rt * 2560, 0);
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){ __float_as_uint(dd[4]), __float_as_uint(dd[5]), __float_as_uint(dd[6]), __float_as_uint(dd[7]) }, drs, lane * 16, gb + rt * 2560 + 1024, 0);
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){ __float_as_uint(dd[8]), __float_as_uint(dd[9]) }, drs, lane * 8, gb + rt * 2560 + 2048, 0);
+                // every lane keeps its own best (t ascending, then f ascending, strict >: the earliest wins); block_argmax2 orders the lanes the same way.  Branch-free,
+                // (t, f) packed in one register
                 const int t = tb + 16 * rt;
                 if (pass) {
 #pragma unroll
                     for (int q = 0; q < NTF; q++) {
                         const int k0 = (t << 6) | (8 * q + 2 * g);
-                        const float s0 = pv[rt * 2 * NTF + 2 * q] + dd[rt * 2 * NTF + 2 * q], s1 = pv[rt * 2 * NTF + 2 * q + 1] + dd[rt * 2 * NTF + 2 * q + 1];
+                        const float s0 = pv[rt & 1][2 * q] + dd[2 * q], s1 = pv[rt & 1][2 * q + 1] + dd[2 * q + 1];
                         const bool c0 = s0 > lbest; lbest = c0 ? s0 : lbest; lkey = c0 ? k0 : lkey;
                         const bool c1 = s1 > lbest; lbest = c1 ? s1 : lbest; lkey = c1 ? k0 + 1 : lkey;
                     }
                 }
-                if (g == 0) rowsum[t] = rsum[rt];
+                if (g == 0) rowsum[t] = rs;
             }
             PH2(17);
         }
@@ -1035,74 +1065,85 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
     __syncthreads();
 }
 
-// check_pilots' row refresh for one (modem frame, group of NTN frequency tiles): as check_rows_tiles, but the |Dt| values are summed
-// over the group's frequencies in registers (lanes 16 apart hold the other frequency pairs) instead of going through a 15 KB table
-template <int NTN>
-__device__ __forceinline__ void check2_rows_tiles(RxShared2 *sh, const unsigned short *corr16, int frame, int nt_base, int grp, int lane, float rx_unsc)
+// check_pilots' 48 row refreshes of ONE modem frame on ONE wavefront, by the two-stage correlator (rx2_detect_q's algebra): the three tiles of 16 row draws against the
+// moment table (A fragments straight from L2, two k-steps ahead: 40 KB per call and wavefront instead of 60 + 40 over the two wavefronts a frame had), the moments
+// expanded to the 40 frequencies, |Dt| summed over them in the wavefront -> rowsum1 / rowsum2 directly (rounds 3-4: partial sums of two wavefronts through a table and
+// a second barrier).  The gathers: lane (row draw i, group g) needs samples 16 s + 4 g .. + 3 of its window in k-step s, and the windows start at random offsets, so the
+// lanes of a read hit banks at random whatever the layout.  What the layout decides is how many LDS cycles that costs: with a sample's two plane words side by side
+// one ds_read_b64 (64 banks, 2 cycles conflict-free) brings what took two ds_read_b32 (32 banks, 2 cycles each) -- measured by bank model over random draws: 6.6 against
+// 13.1 LDS cycles per sample and wave-instruction -- and every window is read by ONE wavefront, not two.
+typedef __attribute__((address_space(3))) const u32x2 lds_cu32x2;
+__device__ __forceinline__ void check2_rows_q(RxShared2 *sh, const unsigned short *corrq16_, const unsigned short *corra16_, int frame, int lane, float rx_unsc_)
 {
     const int i = lane & 15, g = lane >> 4;
-    const unsigned *xh[3], *xl[3];
-#pragma unroll
-    for (int rt = 0; rt < 3; rt++) { const int o = sh->rows48[rt * 16 + i] + frame * RD_NMF + 4 * g; xh[rt] = sh->rxh + o; xl[rt] = sh->rxl + o; }
-    const unsigned short *pt = corr16 + ((size_t)nt_base * 10 * 2 * 64 + lane) * 8;
-    f32x4 acc[3][NTN];
-#pragma unroll
-    for (int rt = 0; rt < 3; rt++)
-#pragma unroll
-        for (int q = 0; q < NTN; q++) acc[rt][q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    f16x8 p0h[NTN], p0l[NTN], p1h[NTN], p1l[NTN];
-    auto fetch = [&](f16x8 (&ph)[NTN], f16x8 (&pl)[NTN], int sidx) {
-#pragma unroll
-        for (int q = 0; q < NTN; q++) {
-            ph[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2) * 64 * 8);
-            pl[q] = *(const f16x8 *)(pt + ((size_t)(q * 10 + sidx) * 2 + 1) * 64 * 8);
-        }
-    };
-    // the rx fragments of k-step s + 1 (24 gathered LDS reads) are requested before the matrix instructions of k-step s: read at the top of their
-    // own k-step they were ten exposed LDS round trips per call
-    f16x8 ah[2][3], al[2][3];
-    auto rows = [&](int slot, int sidx) {
-#pragma unroll
-        for (int rt = 0; rt < 3; rt++) {
-            u32x4 vh, vl;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { vh[j] = xh[rt][16 * sidx + j]; vl[j] = xl[rt][16 * sidx + j]; }
-            ah[slot][rt] = __builtin_bit_cast(f16x8, vh); al[slot][rt] = __builtin_bit_cast(f16x8, vl);
-        }
-    };
-    auto kstep = [&](const f16x8 (&ch)[NTN], const f16x8 (&cl)[NTN], int sidx) {
-        if (sidx + 1 < 10) rows((sidx + 1) & 1, sidx + 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < NTN; q++) {
-#pragma unroll
-            for (int rt = 0; rt < 3; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cl[q], ah[sidx & 1][rt], acc[rt][q], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 3; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], al[sidx & 1][rt], acc[rt][q], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 3; rt++) acc[rt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ch[q], ah[sidx & 1][rt], acc[rt][q], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    rows(0, 0);
-    fetch(p0h, p0l, 0); fetch(p1h, p1l, 1);
-#pragma unroll
-    for (int sidx = 0; sidx < 10; sidx += 2) {
-        kstep(p0h, p0l, sidx);
-        if (sidx + 2 < 10) fetch(p0h, p0l, sidx + 2);
-        kstep(p1h, p1l, sidx + 1);
-        if (sidx + 3 < 10) fetch(p1h, p1l, sidx + 3);
-    }
-    // C layout: column = lane & 15 (row draw), rows 4 (lane >> 4) + r = (re, im) of f = 8 nt + 2 g and f + 1: this lane's frequencies
-    // in ascending order, then the other three lane groups (g ascending) -- one fixed order per row
+    const float rx_unsc = rx_unsc_ * 0x1p-3f;
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corrq16_), 0, 2 * 10 * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corra16_), 0, 5 * 2048, 0x00020000);
+    // four address registers per row tile that the compiler cannot see through: merged into ds_read2_b64 (or an unaligned ds_read_b128) the reads would run at half rate
+    lds_cu32x2 *px[3][4];
 #pragma unroll
     for (int rt = 0; rt < 3; rt++) {
+        lds_cu32x2 *b0 = (lds_cu32x2 *)&sh->rxhl[0] + (sh->rows48[rt * 16 + i] + frame * RD_NMF + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { px[rt][j] = b0 + j; asm volatile("" : "+v"(px[rt][j])); }
+    }
+    f32x4 acc1[3][2];
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++) { acc1[rt][0] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; acc1[rt][1] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; }
+    u32x4 A[2][4];                                             // [k-step parity][2 tile + plane]
+    auto fetchA = [&](int slot, int s) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) A[slot][u] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane * 16, (((u >> 1) * 10 + s) * 2 + (u & 1)) * 1024, 0);
+    };
+    u32x4 bh[2][3], bl[2][3];
+    auto rows = [&](int slot, int s) {
+#pragma unroll
+        for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const u32x2 v = px[rt][j][16 * s]; bh[slot][rt][j] = v[0]; bl[slot][rt][j] = v[1]; }
+    };
+    rows(0, 0);
+    fetchA(0, 0); fetchA(1, 1);
+    u32x4 A2[2 * 5];                                           // stage 2's fragments [2 q + plane]: requested under the last k-steps
+#pragma unroll
+    for (int s = 0; s < 10; s++) {
+        if (s + 1 < 10) rows((s + 1) & 1, s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, A[s & 1][2 * nt]), al = __builtin_bit_cast(f16x8, A[s & 1][2 * nt + 1]);
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, __builtin_bit_cast(f16x8, bh[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, bl[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, bh[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < 10) fetchA(s & 1, s + 2);
+        if (s == 8) {
+#pragma unroll
+            for (int u = 0; u < 10; u++) A2[u] = __builtin_amdgcn_raw_buffer_load_b128(ars, lane * 16, u * 1024, 0);
+        }
+    }
+    float *rowsum = frame ? sh->rowsum2 : sh->rowsum1;
+#pragma unroll
+    for (int rt = 0; rt < 3; rt++) {
+        const MomPlanes mp = mom_split(acc1[rt][0], acc1[rt][1]);
         float s = 0.0f;
 #pragma unroll
-        for (int q = 0; q < NTN; q++)      // (operands are scaled to 2^7 .. 2^8 per sample: no hypotf() range handling needed)
-            s += rx_unsc * __builtin_amdgcn_sqrtf(fmaf(acc[rt][q][0], acc[rt][q][0], acc[rt][q][1] * acc[rt][q][1])) + rx_unsc * __builtin_amdgcn_sqrtf(fmaf(acc[rt][q][2], acc[rt][q][2], acc[rt][q][3] * acc[rt][q][3]));
-        const float s1 = __shfl(s, i + 16), s2 = __shfl(s, i + 32), s3 = __shfl(s, i + 48), s0 = __shfl(s, i);
-        if (g == 0) sh->absd2[2 * (rt * 16 + i) + frame][grp] = ((s0 + s1) + s2) + s3;
+        for (int q = 0; q < 5; q++) {      // C layout: column = lane & 15 (row draw), rows 4 g + r = (re, im) of f = 8 q + 2 g and f + 1
+            const f32x4 c = mom_expand(__builtin_bit_cast(f16x8, A2[2 * q]), __builtin_bit_cast(f16x8, A2[2 * q + 1]), mp);
+            s += rx_unsc * __builtin_amdgcn_sqrtf(fmaf(c[0], c[0], c[1] * c[1])) + rx_unsc * __builtin_amdgcn_sqrtf(fmaf(c[2], c[2], c[3] * c[3]));
+        }
+        {   // the other three lane groups hold the row's other frequencies
+            const auto p16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            s = __uint_as_float(p16[0]) + __uint_as_float(p16[1]);
+            const auto p32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+            s = __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
+        }
+        // (two draws of the same row compute the same sum from the same samples: whichever store lands last, the value is the same)
+        if (g == 0) rowsum[sh->rows48[rt * 16 + i]] = s;
     }
 }
 
@@ -1423,8 +1464,8 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
                     sh->srxl[i] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
                 }
             }
-            if (CENSUS(512)) { float b_ = -1.0f; int t_ = 0x7fffffff, f_ = 0; rx2_detect_mfma(sh, a.corr16, cache, cached ? 1 : 0, oldb, newb, rx_unsc, b_, t_, f_); asm volatile("" :: "v"(b_), "v"(t_), "v"(f_)); }
-            rx2_detect_mfma(sh, a.corr16, cache, cached ? 1 : 0, oldb, newb, rx_unsc, best, bt, bfi);
+            if (CENSUS(512)) { float b_ = -1.0f; int t_ = 0x7fffffff, f_ = 0; rx2_detect_q(sh, a.corrq16, a.corra16, cache, cached ? 1 : 0, oldb, newb, rx_unsc, b_, t_, f_); asm volatile("" :: "v"(b_), "v"(t_), "v"(f_)); }
+            rx2_detect_q(sh, a.corrq16, a.corra16, cache, cached ? 1 : 0, oldb, newb, rx_unsc, best, bt, bfi);
             PH2(7);
             block_argmax2(sh, best, bt, bfi);
             const float Dmax = best; const int tbest = bt, fbest = bfi;
@@ -1472,8 +1513,8 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
                         float2 v = sh->rxb[i]; v.x *= rx_sc; v.y *= rx_sc;
                         const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y;
                         const _Float16 l0 = (_Float16)(v.x - (float)h0), l1 = (_Float16)(v.y - (float)h1);
-                        sh->rxh[i] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                        sh->rxl[i] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                        sh->rxhl[i] = (u32x2){ (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16),
+                                               (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16) };
                     }
                 }
                 if (CENSUS(16)) { int t_ = tm; double f_ = fm; rx2_refine(sh, a.vm, &t_, &f_, t0, tm + 8 - t0, fm - 1.0, fm + 1.0, 0.1, true); __syncthreads(); }
@@ -1490,12 +1531,11 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
                 const float rx_unsc = sh->redf[12];
                 for (int rep = CENSUS_REPS(32); rep > 0; rep--) {
                     asm volatile("" ::: "memory");
-                if (wave < 2) check2_rows_tiles<3>(sh, a.corr16, wave & 1, 0, 0, lane, rx_unsc);
-                else check2_rows_tiles<2>(sh, a.corr16, wave & 1, 3, 1, lane, rx_unsc);
+                if (wave < 2) check2_rows_q(sh, a.corrq16, a.corra16, wave, lane, rx_unsc);
                 }
                 PH2(8);
                 const int tm = tm_ref; const double w = 2.0 * PI_D * fm_ref / 8000.0;
-                // (the two wavefronts with two frequency tiles finish the matrix part first: they take the correlations and two thirds of the window)
+                // (the wavefronts 2 and 3 have no matrix part: they take the correlations and most of the window)
                 {
                     double cr[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
                     for (int rep = CENSUS_REPS(64); rep > 0; rep--)
@@ -1531,9 +1571,9 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
                 const float dx_sc = 0x1p-12f / rx_unsc;           // = the planes' 2^(7 - E): a power of two, the division is exact
                 // rx_phase e^{-jw(n+1)} (complex128 in the reference) = e^{j(theta - w(n+1))}: one reduced-angle evaluation per sample, and the
                 // per-call advance is theta -= w Neoo instead of a double-precision sincos on the serial path beside the demodulator
-                // window samples [0, 768) on wavefronts 2 / 3 (six each), [768, 1152) on 0 / 1 (three each)
+                // window samples [0, RX2_WSPLIT) on wavefronts 2 / 3 (which have no matrix part), the rest on 0 / 1
                 for (int rep = CENSUS_REPS(128); rep > 0; rep--)
-                for (int n = wave >= 2 ? tid - 128 : 768 + tid; n < (wave >= 2 ? 768 : RD_NEOO); n += 128) {
+                for (int n = wave >= 2 ? tid - 128 : RX2_WSPLIT + tid; n < (wave >= 2 ? RX2_WSPLIT : RD_NEOO); n += 128) {
                     asm volatile("" ::: "memory");
                     float2 v = cmul(sh->rxb[t2 - RD_NCP + n], cis_reduced(rph_th - w * (double)(n + 1)));
                     v.x *= dx_sc; v.y *= dx_sc;
@@ -1544,13 +1584,6 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
                 }
             }
             PH2(11);
-            __syncthreads();
-            tid = rx2_tid(wv);
-            if (tid < 96) {
-                const float s = sh->absd2[tid][0] + sh->absd2[tid][1];
-                const int t = sh->rows48[tid >> 1];
-                if (tid & 1) sh->rowsum2[t] = s; else sh->rowsum1[t] = s;
-            }
             __syncthreads();
             tid = rx2_tid(wv);
             PH2(10);

@@ -184,6 +184,44 @@ def test_demodulator_dft_matrix_as_matrix_core_operands(lib, golden):
     assert np.abs(((R @ v0)[:30] + 1j * (R @ v1)[:30]) - ref).max() < 3e-6 * np.abs(ref).max()
 
 
+def test_two_stage_pilot_correlator_tables(lib, golden):
+    """rd_corrq16_table_fill / rd_corra16_table_fill (rade_host.c): acquisition.p_w (dsp.py:166-173) factored as 16 polynomial moments x their expansion to the 40
+    coarse frequencies.  Un-permuted from the matrix-core operand order (stage 2's K axis in the accumulator order of stage 1) and multiplied back together on the
+    CPU, the two tables give the reference's p_w to the planes' 22 bits; applied in two stages to a random window they give the reference's Dt
+    (dsp.py:207-208) -- and the exact factorisation (before the binary16 split) reproduces p_w to 1e-8."""
+    c = golden("consts")
+    T = Tables()
+    lib.rd_tables_fill.argtypes = [C.POINTER(Tables)]; lib.rd_tables_fill(C.byref(T))
+    lib.rd_corr_tables_check.argtypes = [C.POINTER(Tables)]; lib.rd_corr_tables_check.restype = C.c_double
+    assert lib.rd_corr_tables_check(C.byref(T)) < 1e-8            # (p_w itself is rounded to float32: 0.124 x 6e-8)
+    q16 = np.zeros(2 * 10 * 2 * 64 * 8, np.uint16); a16 = np.zeros(5 * 2 * 64 * 8, np.uint16)
+    for fn, buf in (("rd_corrq16_table_fill", q16), ("rd_corra16_table_fill", a16)):
+        getattr(lib, fn).argtypes = [C.POINTER(Tables), C.c_void_p]; getattr(lib, fn).restype = None
+        getattr(lib, fn)(C.byref(T), buf.ctypes.data_as(C.c_void_p))
+    tq = q16.view(np.float16).astype(np.float64).reshape(2, 10, 2, 64, 8); ta = a16.view(np.float16).astype(np.float64).reshape(5, 2, 64, 8)
+    Q1 = np.zeros((32, 320)); A2 = np.zeros((80, 32))
+    for tile in range(2):
+        for s in range(10):
+            for lane in range(64):
+                Q1[16 * tile + (lane & 15), 32 * s + 8 * (lane >> 4):32 * s + 8 * (lane >> 4) + 8] = (tq[tile, s, 0, lane] + tq[tile, s, 1, lane]) / 4096.0
+    for tile in range(5):
+        for lane in range(64):
+            g = lane >> 4
+            for j in range(8):
+                A2[16 * tile + (lane & 15), (4 * g + j) if j < 4 else (16 + 4 * g + j - 4)] = (ta[tile, 0, lane, j] + ta[tile, 1, lane, j]) / 1024.0
+    # the product of the two real matrices is the realified p_w: rows (f, re | im), columns (m, re | im) as in rd_corr16_table_fill
+    pw = c["acq_p_w"].astype(np.complex128)                        # [m][f]
+    P = np.zeros((80, 320)); P[0::2, 0::2] = pw.real.T; P[0::2, 1::2] = pw.imag.T; P[1::2, 0::2] = pw.imag.T; P[1::2, 1::2] = -pw.real.T
+    assert np.abs(A2 @ Q1 - P).max() < 4e-7 * np.abs(P).max()
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(160) + 1j * rng.standard_normal(160)
+    v = np.empty(320); v[0::2] = x.real; v[1::2] = x.imag
+    d = A2 @ (Q1 @ v)
+    ref = np.conj(x) @ pw                                          # Dt[t, :] = matmul(conj(rx[t:t+M]), p_w)
+    assert np.abs((d[0::2] + 1j * d[1::2]) - ref).max() < 4e-7 * np.abs(ref).max()
+    assert np.abs(A2[:, 28:]).max() < 1e-4 * np.abs(A2).max()     # the highest moments carry next to nothing: 16 are plenty
+
+
 def test_bandpass_taps_as_matrix_core_operands(lib, golden):
     """rd_bpf16_table_fill: complex_bpf's 101 taps as the Toeplitz A operand of the matrix-core FIR (k_rx_bpf), two binary16 planes in the lane order of
     v_mfma_f32_16x16x32_f16.  Un-permuted and applied (CPU, float64) to the Hankel matrix of a random window it must reproduce the direct FIR sums of
