@@ -61,9 +61,6 @@ __device__ static constexpr uint32_t LCG_A[48] = { 1664525u, 389569705u, 2940799
 __device__ static constexpr uint32_t LCG_C[48] = { 1013904223u, 1196435762u, 3519870697u, 2868466484u, 1649599747u, 2670642822u, 1476291629u, 2748932008u, 2180890343u, 2498801434u, 3421909937u, 3167820124u, 2636375307u, 3801544430u, 28987765u, 2210837584u, 3039689583u, 1338634754u, 1649346937u, 2768872580u, 2254235155u, 2326606934u, 1719328701u, 1061592568u, 53332215u, 1140036074u, 4224358465u, 2629538988u, 1946028059u, 573775550u, 1473591045u, 95141024u, 1592739711u, 1618554578u, 4257218569u, 2685635028u, 2617994019u, 740185638u, 4194465613u, 2426187848u, 967350023u, 366635194u, 2557108433u, 3503432700u, 353185579u, 706247310u, 408928405u, 1855199472u };
 
 #define NT2 256
-#ifndef RX2_WSPLIT
-#define RX2_WSPLIT 896           /* check_pilots phase: frequency-corrected window samples [0, RX2_WSPLIT) on wavefronts 2 / 3, the rest on 0 / 1 (which run the matrix part) */
-#endif
 // thread index rebuilt from the lane counter and the wavefront's index (held in a scalar register): three instructions wherever it
 // is needed, instead of one value that stays live -- and gets spilled -- across the whole receive call (rx_tid() keeps threadIdx.x
 // alive the same way)
@@ -517,6 +514,7 @@ struct RxShared2 {
             double2 pd[RD_M], pendd[RD_M];                      // pilot / end-of-over replicas as doubles (reloaded with the state: S.lds_sync)
             float2 sym[6][RD_NC]; float2 rp[2][RD_NC];
             float eqP[RD_NC]; float2 eqPmat[RD_NC][2][3], eqrot[RD_NC]; float eq_pg, eq_snrc1, eq_snrc2, eq_pad;
+            float2 cisA[2][18], cisB[2][64];                    // the frequency-corrected window's phasor e^{j(theta - w (n + 1))} = cisA[n >> 6] cisB[n & 63], one copy per wavefront that cuts the window
             union {
               struct {
                 u32x2 rxhl[RD_RXBUF];                           // check_pilots: rx_buf in two binary16 planes, a sample's (high, low) words side by side: one 8-byte read brings both
@@ -1065,7 +1063,7 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
     __syncthreads();
 }
 
-// check_pilots' 48 row refreshes of ONE modem frame on ONE wavefront, by the two-stage correlator (rx2_detect_q's algebra): the three tiles of 16 row draws against the
+// check_pilots' row refreshes of one modem frame, NRT tiles of 16 row draws per wavefront, by the two-stage correlator (rx2_detect_q's algebra): the three tiles of 16 row draws against the
 // moment table (A fragments straight from L2, two k-steps ahead: 40 KB per call and wavefront instead of 60 + 40 over the two wavefronts a frame had), the moments
 // expanded to the 40 frequencies, |Dt| summed over them in the wavefront -> rowsum1 / rowsum2 directly (rounds 3-4: partial sums of two wavefronts through a table and
 // a second barrier).  The gathers: lane (row draw i, group g) needs samples 16 s + 4 g .. + 3 of its window in k-step s, and the windows start at random offsets, so the
@@ -1073,37 +1071,43 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
 // one ds_read_b64 (64 banks, 2 cycles conflict-free) brings what took two ds_read_b32 (32 banks, 2 cycles each) -- measured by bank model over random draws: 6.6 against
 // 13.1 LDS cycles per sample and wave-instruction -- and every window is read by ONE wavefront, not two.
 typedef __attribute__((address_space(3))) const u32x2 lds_cu32x2;
-__device__ __forceinline__ void check2_rows_q(RxShared2 *sh, const unsigned short *corrq16_, const unsigned short *corra16_, int frame, int lane, float rx_unsc_)
+// pre() runs once behind the first table requests, side(s) behind the matrix instructions of k-step s: work of the caller's that does not depend on this
+// function's results, placed where the wavefront would otherwise wait for table fragments from L2 (6 NRT matrix instructions per k-step cover 100-200 cycles of
+// a round trip of 800)
+template <int NRT, int DA, class Pre, class Side>
+__device__ __forceinline__ void check2_rows_q(RxShared2 *sh, const unsigned short *corrq16_, const unsigned short *corra16_, int frame, int rt0, int lane, float rx_unsc_, Pre pre, Side side)
 {
     const int i = lane & 15, g = lane >> 4;
     const float rx_unsc = rx_unsc_ * 0x1p-3f;
     const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corrq16_), 0, 2 * 10 * 2048, 0x00020000);
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void *)uni_ptr(corra16_), 0, 5 * 2048, 0x00020000);
     // four address registers per row tile that the compiler cannot see through: merged into ds_read2_b64 (or an unaligned ds_read_b128) the reads would run at half rate
-    lds_cu32x2 *px[3][4];
+    lds_cu32x2 *px[NRT][4];
 #pragma unroll
-    for (int rt = 0; rt < 3; rt++) {
-        lds_cu32x2 *b0 = (lds_cu32x2 *)&sh->rxhl[0] + (sh->rows48[rt * 16 + i] + frame * RD_NMF + 4 * g);
+    for (int rt = 0; rt < NRT; rt++) {
+        lds_cu32x2 *b0 = (lds_cu32x2 *)&sh->rxhl[0] + (sh->rows48[(rt0 + rt) * 16 + i] + frame * RD_NMF + 4 * g);
 #pragma unroll
         for (int j = 0; j < 4; j++) { px[rt][j] = b0 + j; asm volatile("" : "+v"(px[rt][j])); }
     }
-    f32x4 acc1[3][2];
+    f32x4 acc1[NRT][2];
 #pragma unroll
-    for (int rt = 0; rt < 3; rt++) { acc1[rt][0] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; acc1[rt][1] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; }
-    u32x4 A[2][4];                                             // [k-step parity][2 tile + plane]
+    for (int rt = 0; rt < NRT; rt++) { acc1[rt][0] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; acc1[rt][1] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f }; }
+    u32x4 A[DA][4];                                            // [k-step mod DA][2 tile + plane]: DA k-steps of table fragments in flight
     auto fetchA = [&](int slot, int s) {
 #pragma unroll
         for (int u = 0; u < 4; u++) A[slot][u] = __builtin_amdgcn_raw_buffer_load_b128(qrs, lane * 16, (((u >> 1) * 10 + s) * 2 + (u & 1)) * 1024, 0);
     };
-    u32x4 bh[2][3], bl[2][3];
+    u32x4 bh[2][NRT], bl[2][NRT];
     auto rows = [&](int slot, int s) {
 #pragma unroll
-        for (int rt = 0; rt < 3; rt++)
+        for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
             for (int j = 0; j < 4; j++) { const u32x2 v = px[rt][j][16 * s]; bh[slot][rt][j] = v[0]; bl[slot][rt][j] = v[1]; }
     };
+#pragma unroll
+    for (int d = 0; d < DA; d++) fetchA(d, d);
+    pre();
     rows(0, 0);
-    fetchA(0, 0); fetchA(1, 1);
     u32x4 A2[2 * 5];                                           // stage 2's fragments [2 q + plane]: requested under the last k-steps
 #pragma unroll
     for (int s = 0; s < 10; s++) {
@@ -1111,24 +1115,26 @@ __device__ __forceinline__ void check2_rows_q(RxShared2 *sh, const unsigned shor
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int nt = 0; nt < 2; nt++) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, A[s & 1][2 * nt]), al = __builtin_bit_cast(f16x8, A[s & 1][2 * nt + 1]);
+            const f16x8 ah = __builtin_bit_cast(f16x8, A[s % DA][2 * nt]), al = __builtin_bit_cast(f16x8, A[s % DA][2 * nt + 1]);
 #pragma unroll
-            for (int rt = 0; rt < 3; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, __builtin_bit_cast(f16x8, bh[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, __builtin_bit_cast(f16x8, bh[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 3; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, bl[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, bl[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 3; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, bh[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; rt++) acc1[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, __builtin_bit_cast(f16x8, bh[s & 1][rt]), acc1[rt][nt], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 2 < 10) fetchA(s & 1, s + 2);
-        if (s == 8) {
+        if (s + DA < 10) fetchA(s % DA, s + DA);
+        if (s == 10 - DA) {
 #pragma unroll
             for (int u = 0; u < 10; u++) A2[u] = __builtin_amdgcn_raw_buffer_load_b128(ars, lane * 16, u * 1024, 0);
         }
+        side(s);
+        __builtin_amdgcn_sched_barrier(0);
     }
     float *rowsum = frame ? sh->rowsum2 : sh->rowsum1;
 #pragma unroll
-    for (int rt = 0; rt < 3; rt++) {
+    for (int rt = 0; rt < NRT; rt++) {
         const MomPlanes mp = mom_split(acc1[rt][0], acc1[rt][1]);
         float s = 0.0f;
 #pragma unroll
@@ -1143,7 +1149,7 @@ __device__ __forceinline__ void check2_rows_q(RxShared2 *sh, const unsigned shor
             s = __uint_as_float(p32[0]) + __uint_as_float(p32[1]);
         }
         // (two draws of the same row compute the same sum from the same samples: whichever store lands last, the value is the same)
-        if (g == 0) rowsum[sh->rows48[rt * 16 + i]] = s;
+        if (g == 0) rowsum[sh->rows48[(rt0 + rt) * 16 + i]] = s;
     }
 }
 
@@ -1529,14 +1535,24 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
             {
                 const int wave = tid >> 6, lane = tid & 63;
                 const float rx_unsc = sh->redf[12];
-                for (int rep = CENSUS_REPS(32); rep > 0; rep--) {
-                    asm volatile("" ::: "memory");
-                if (wave < 2) check2_rows_q(sh, a.corrq16, a.corra16, wave, lane, rx_unsc);
-                }
-                PH2(8);
+                // wavefronts 0 / 1: frame 0 / 1, row tiles 0 and 1; wavefronts 2 / 3: frame 0 / 1, row tile 2, and everything else of the phase -- the four correlations at
+                // (tmax, fmax) behind the first table requests, one slice of the frequency-corrected window behind the matrix instructions of every k-step
                 const int tm = tm_ref; const double w = 2.0 * PI_D * fm_ref / 8000.0;
-                // (the wavefronts 2 and 3 have no matrix part: they take the correlations and most of the window)
-                {
+                int t2 = tm;
+                if (t2 >= RD_NMF - RD_M) t2 -= RD_M;
+                if (t2 < RD_M) t2 += RD_M;
+                const double rph_th = S->rph_th;
+                float2 *cA = sh->cisA[wave & 1], *cB = sh->cisB[wave & 1];
+                unsigned *dxh = (unsigned *)sh->xm, *dxl = dxh + 1200;
+                const float dx_sc = 0x1p-12f / rx_unsc;           // = the planes' 2^(7 - E): a power of two, the division is exact
+                auto pre23 = [=]() {      // (captures by VALUE: by reference the captured locals -- tid among them, reassigned all over the call loop -- stay in scratch memory for the whole kernel: 1700 spills)
+                    // rx_phase e^{-jw(n+1)} (complex128 in the reference) = e^{j(theta - w(n+1))} for the 1152 window samples as the product of two small tables --
+                    // cisA[a] = e^{j(theta - w(64 a + 1))}, cisB[b] = e^{-j w b}, 82 reduced-angle evaluations per wavefront (each wavefront builds its own copy: no
+                    // barrier) -- instead of one evaluation per sample (rounds 2-4: sincosf and the double-precision angle were 1.2 k cycles per 128 samples, more
+                    // than half of this phase's wave-cycles)
+                    cB[lane] = cis_reduced(-w * (double)lane);
+                    if (lane < 18) cA[lane] = cis_reduced(rph_th - w * (double)(64 * lane + 1));
+                    // the four correlations at (tmax, fmax): 160 samples over the two wavefronts
                     double cr[8] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };
                     for (int rep = CENSUS_REPS(64); rep > 0; rep--)
                     for (int n = tid - 128; n >= 0 && n < RD_M; n += 128) {
@@ -1560,28 +1576,26 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
 #pragma unroll
                         for (int q = 0; q < 8; q++) sh->corrp[wave][q] = cr[q];
                     }
-                }
-                int t2 = tm;
-                if (t2 >= RD_NMF - RD_M) t2 -= RD_M;
-                if (t2 < RD_M) t2 += RD_M;
-                const double rph_th = S->rph_th;
-                // the corrected window goes straight into two binary16 planes (same power-of-two scale as the rx_buf planes): the demodulator DFT reads
-                // them as matrix-core operands.  Sample n sits at n + (n >> 5): the six symbols' fragments then start in different banks.
-                unsigned *dxh = (unsigned *)sh->xm, *dxl = dxh + 1200;
-                const float dx_sc = 0x1p-12f / rx_unsc;           // = the planes' 2^(7 - E): a power of two, the division is exact
-                // rx_phase e^{-jw(n+1)} (complex128 in the reference) = e^{j(theta - w(n+1))}: one reduced-angle evaluation per sample, and the
-                // per-call advance is theta -= w Neoo instead of a double-precision sincos on the serial path beside the demodulator
-                // window samples [0, RX2_WSPLIT) on wavefronts 2 / 3 (which have no matrix part), the rest on 0 / 1
-                for (int rep = CENSUS_REPS(128); rep > 0; rep--)
-                for (int n = wave >= 2 ? tid - 128 : RX2_WSPLIT + tid; n < (wave >= 2 ? RX2_WSPLIT : RD_NEOO); n += 128) {
-                    asm volatile("" ::: "memory");
-                    float2 v = cmul(sh->rxb[t2 - RD_NCP + n], cis_reduced(rph_th - w * (double)(n + 1)));
+                };
+                // the corrected window goes straight into two binary16 planes (same power-of-two scale as the rx_buf planes): the demodulator DFT reads them as
+                // matrix-core operands.  Sample n sits at n + (n >> 5): the six symbols' fragments then start in different banks.  Slice s = samples
+                // 128 s + (tid - 128), s = 0..8 (9 x 128 = 1152)
+                auto side23 = [=](int sl) {
+                    if (sl >= RD_NEOO / 128) return;
+                    const int n = 128 * sl + (tid - 128);
+                    float2 v = cmul(sh->rxb[t2 - RD_NCP + n], cmul(cA[n >> 6], cB[n & 63]));
                     v.x *= dx_sc; v.y *= dx_sc;
                     const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y;
                     const _Float16 l0 = (_Float16)(v.x - (float)h0), l1 = (_Float16)(v.y - (float)h1);
                     dxh[n + (n >> 5)] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
                     dxl[n + (n >> 5)] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                };
+                for (int rep = CENSUS_REPS(32); rep > 0; rep--) {
+                    asm volatile("" ::: "memory");
+                    if (wave < 2) check2_rows_q<2, 5>(sh, a.corrq16, a.corra16, wave, 0, lane, rx_unsc, []() {}, [](int) {});
+                    else check2_rows_q<1, 4>(sh, a.corrq16, a.corra16, wave - 2, 2, lane, rx_unsc, pre23, side23);
                 }
+                PH2(8);
             }
             PH2(11);
             __syncthreads();
@@ -1600,7 +1614,7 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
                     const int tm = S->tmax;
                     double red[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) red[q] = ((sh->corrp[0][q] + sh->corrp[1][q]) + sh->corrp[2][q]) + sh->corrp[3][q];
+                    for (int q = 0; q < 8; q++) red[q] = sh->corrp[2][q] + sh->corrp[3][q];      // (the two wavefronts that cut the correlations: rx2 check phase)
                     const float sr = sigma_r_from_sums(r0, r1);
                     const double D = sqrt(red[0] * red[0] + red[1] * red[1]) + sqrt(red[2] * red[2] + red[3] * red[3]);     // (well inside double's range: no hypot() scaling)
                     const double De = sqrt(red[4] * red[4] + red[5] * red[5]) + sqrt(red[6] * red[6] + red[7] * red[7]);

@@ -10,7 +10,8 @@ the FIRST variant (the baseline), the PAIRED per-round difference: its median, i
                      the differences themselves is the yardstick, as the verdict asked)  ->  "faster" / "slower";  otherwise "no decision".
 
 A variant is a library (`name=path/to/lib.so`, loaded through $RADE_LIBRADEHIP), optionally with environment switches (`name=path.so,VAR=value,...`;
-`name=,VAR=value` = the default library with a switch).  What is measured is chosen by --metric:
+`name=,VAR=value` = the default library with a switch) and a command prefix (`name=,VAR=value,@taskset -c 0,1`: everything after the `@` is put in front of the
+command -- note that the prefix may contain commas, so it must come last).  What is measured is chosen by --metric:
     bench    bench.py --no-cpu-baseline --no-roofline --no-parity --steps S  ->  M frames/s (higher is better)          [default]
     rx512    tools/rx_only.py 8 2 512 -> ms of ONE receiver launch of 512 streams (lower is better)
     cycles   tools/stream_cycles.py -> mean per-stream cycles of the receiver launch (lower is better)
@@ -34,15 +35,16 @@ def mad(xs):
     return statistics.median([abs(x - m) for x in xs])
 
 
-def run_one(metric, lib, envs, steps, extra):
+def run_one(metric, lib, envs, steps, extra, prefix=()):
     env = dict(os.environ)
     if lib:
         env["RADE_LIBRADEHIP"] = lib if os.path.isabs(lib) else os.path.join(R, lib)
     env.update(envs)
     if metric == "bench":
-        cmd = [sys.executable, os.path.join(R, "bench.py"), "--no-cpu-baseline", "--no-roofline", "--no-parity", "--steps", str(steps)] + extra
+        cmd = list(prefix) + [sys.executable, os.path.join(R, "bench.py"), "--no-cpu-baseline", "--no-roofline", "--no-parity", "--steps", str(steps)] + extra
         out = subprocess.run(cmd, env=env, capture_output=True, text=True).stdout
         d = json.loads(out.strip().splitlines()[-1])
+        run_one.last_host = d.get("host")
         return d["value"] / 1e6
     if metric.startswith("class:"):
         cmd = [sys.executable, os.path.join(R, "bench.py"), "--no-cpu-baseline", "--no-parity", "--steps", str(steps)] + extra
@@ -84,41 +86,49 @@ def main():
     variants = []
     for v in args.variants:
         name, _, rest = v.partition("=")
-        parts = rest.split(",") if rest else [""]
+        rest, _, pre = rest.partition("@")
+        parts = rest.rstrip(",").split(",") if rest else [""]
         lib = parts[0]
         envs = dict(p.split("=", 1) for p in parts[1:] if p)
-        variants.append((name, lib, envs))
+        variants.append((name, lib, envs, tuple(pre.split()) if pre else ()))
     higher = args.metric == "bench"
     unit = {"bench": "M frames/s", "rx512": "ms", "cycles": "cycles"}.get(args.metric, "ms")
-    res = {name: [] for name, _, _ in variants}
+    res = {name: [] for name, _, _, _ in variants}; hosts = {name: [] for name, _, _, _ in variants}
     lines = []
 
     def emit(s):
         print(s, flush=True); lines.append(s)
 
     emit(f"# tools/ab_bench.py  metric={args.metric} ({unit}, {'higher' if higher else 'lower'} is better)  rounds={args.rounds}  steps={args.steps}  extra={extra}")
-    emit("# variants: " + "; ".join(f"{n} = {l or '(default library)'} {e or ''}" for n, l, e in variants))
+    emit("# variants: " + "; ".join(f"{n} = {l or '(default library)'} {e or ''} {' '.join(pf)}" for n, l, e, pf in variants))
     t0 = time.time()
     for r in range(args.rounds):
         order = variants[r % len(variants):] + variants[:r % len(variants)]      # rotate the order: no variant always runs first (coldest) or last
-        for name, lib, envs in order:
+        for name, lib, envs, pre in order:
             try:
-                x = run_one(args.metric, lib, envs, args.steps, extra)
+                run_one.last_host = None
+                x = run_one(args.metric, lib, envs, args.steps, extra, pre)
+                if run_one.last_host: hosts[name].append(run_one.last_host)
             except Exception as e:          # a crashed run is recorded, not silently dropped
                 emit(f"round {r + 1} {name}: FAILED {type(e).__name__} {e}")
                 x = float("nan")
             res[name].append(x)
-        emit(f"round {r + 1:2d}  " + "  ".join(f"{n} {res[n][-1]:.3f}" for n, _, _ in variants))
+        emit(f"round {r + 1:2d}  " + "  ".join(f"{n} {res[n][-1]:.3f}" for n, _, _, _ in variants))
     emit(f"# {time.time() - t0:.0f} s")
     base_name = variants[0][0]
     ok = [i for i in range(args.rounds) if all(res[n][i] == res[n][i] for n in res)]
     emit(f"# rounds used: {len(ok)} of {args.rounds}")
     summary = {}
-    for name, _, _ in variants:
+    for name, _, _, _ in variants:
         xs = [res[name][i] for i in ok]
         summary[name] = {"median": statistics.median(xs), "mad": mad(xs), "min": min(xs), "max": max(xs)}
         emit(f"{name:>14s}: median {summary[name]['median']:.3f} {unit}  MAD {summary[name]['mad']:.3f} ({100 * summary[name]['mad'] / summary[name]['median']:.2f} %)  range {min(xs):.3f} .. {max(xs):.3f}")
-    for name, _, _ in variants[1:]:
+        if hosts[name]:
+            hh = hosts[name]
+            summary[name]["host"] = {"cpu_cores_busy_median": statistics.median(h["cpu_cores_busy"] for h in hh), "logical_cpus": hh[0]["logical_cpus"],
+                                     "rx_waits_blocking": hh[0]["rx_waits_blocking"], "rx_waits_spinning": hh[0]["rx_waits_spinning"]}
+            emit(f"{'':>14s}  host: {summary[name]['host']}")
+    for name, _, _, _ in variants[1:]:
         med, sp, verdict, _ = decide([res[base_name][i] for i in ok], [res[name][i] for i in ok], higher)
         summary[name].update({"paired_diff_pct_median": med, "paired_diff_pct_mad": sp, "verdict": verdict})
         emit(f"{name:>14s} vs {base_name}: paired difference median {med:+.2f} %  MAD {sp:.2f} %  -> {verdict.upper()}  (rule: |median| >= 2 x MAD)")
