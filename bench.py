@@ -17,9 +17,9 @@ latency-bound by construction) and prints its own line.
 roofline block: `frac` prices the dominant kernel's work in its CHEAPEST known formulation (pilot search as one
 |Dt| surface by FFT convolution, decoder, in-sync DSP -- the constants below) at the f32 peak, over the time that kernel is busy in
 the TIMED configuration (launches of the batches in flight overlap); `alone` = one launch by itself, `whole_job` = every kernel's
-work x frames/s.  The receiver kernels actually evaluate the search surface as a split-binary16 GEMM on the matrix cores (49 MFLOP
-f32-equivalent per call instead of the FFT form's 5.1): pricing THAT would inflate the fraction ten-fold for the search calls, so
-the FFT count stays.  The reference-formulation figure (98 MFLOP of GEMM per search call) is reported separately as
+work x frames/s.  The receiver kernel actually evaluates the search surface as split-binary16 GEMMs on the matrix cores (since round 5 in
+two stages -- 16 polynomial moments, then their expansion to the 40 frequencies: 28 MFLOP f32-equivalent per call, 49 in rounds 3-4 --
+instead of the FFT form's 5.1): pricing THAT would inflate the fraction several-fold for the search calls, so the FFT count stays.  The reference-formulation figure (98 MFLOP of GEMM per search call) is reported separately as
 `equiv_ref_formulation` and is not a roofline.
 """
 import argparse
@@ -55,7 +55,7 @@ REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation o
 ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
 RX_ALGO_BYTES_PER_FRAME = 640 + 144              # the receiver kernel's share: IQ in + features out
 RX_KERNEL_NAME = "k_rx_sync2"                     # the receiver kernel (rade_rx.hip): the PMC summary is looked up under this name
-PROFILE_TAG = "r04"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
+PROFILE_TAG = "r05"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
 
 
 def executed_flop(search_calls, sync_calls, decoded_mf):
@@ -375,7 +375,7 @@ def roofline_leg(eng, step, steps, B, T, value, world):
     r["limiter"] = "latency (s_waitcnt/s_barrier) + valu-issue"
     r["traffic"] = None
     try:
-        tag = next(t for t in (PROFILE_TAG, "r03") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
+        tag = next(t for t in (PROFILE_TAG, "r04", "r03") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
         pm = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")))
         k = pm["kernels"][{"rx_sync": RX_KERNEL_NAME}.get(dom, dom)]
         raw = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
