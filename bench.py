@@ -8,13 +8,13 @@ A "step" = that whole batch once, starting from reset encoder/receiver state, in
 already resident in HBM.  `--gpus N` > 1: one process per GPU -- started by this script itself under
 torch.distributed.run, or by the caller (WORLD_SIZE must then equal --gpus) -- utterances sharded with no data-path
 collective; the only collective is the RCCL broadcast of the weight blob.
-Defaults: the receiver kernel with two streams per CU (k_rx_sync2) and three batches in flight (DESIGN.md 3.7, 5).
+Defaults: the receiver kernel with two streams per CU (k_rx_sync2) and three batches in flight (DESIGN.md 3.5, 5).
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
 `--config 2` instead measures BASELINE.json configs[1] (one stream through the rade_core.h-level encoder / decoder,
 latency-bound by construction) and prints its own line.
 
-roofline block (DESIGN.md 3.5): `frac` prices the dominant kernel's work in its CHEAPEST known formulation (pilot search as one
+roofline block (DESIGN.md 5): `frac` prices the dominant kernel's work in its CHEAPEST known formulation (pilot search as one
 |Dt| surface by FFT convolution, decoder, in-sync DSP -- the constants below) at the f32 peak, over the time that kernel is busy in
 the TIMED configuration (launches of the batches in flight overlap); `alone` = one launch by itself, `whole_job` = every kernel's
 work x frames/s.  The receiver kernel actually evaluates the search surface as split-binary16 GEMMs on the matrix cores (since round 5 in

@@ -6,7 +6,7 @@
  *
  * With --pipeline P (default 3, what bench.py times) every device keeps P batches in flight: P engines with their own state, each on its own
  * HIP stream and host thread, the steps dealt to them in turn (the receiver kernel takes half a CU per stream, so the workgroups of two
- * batches share a CU: DESIGN.md 3.7).  --pipeline 1 is the plain one-engine-per-device loop.
+ * batches share a CU: DESIGN.md 3.5).  --pipeline 1 is the plain one-engine-per-device loop.
  *
  * usage: rade_multi_bench [--gpus N | --mask HEX] [--streams-per-gpu B] [--frames T] [--steps K] [--warmup W] [--pipeline P] [weights.bin]
  */

@@ -54,7 +54,10 @@ __device__ __forceinline__ double dgrid_nc(double start, int i, double delta)
 // instruction's op_sel / neg_lo modifiers): 10 us faster per modulator launch, and NOT reproducible -- under load (three batches in flight) about one 16-sample
 // block in 15,000 frames came out different from run to run, always lanes 48..63 of a wavefront, always a data symbol, the encoder's latents bit-identical
 // (tools/tx_determinism.py: 125..283 differing blocks per 3.8 M frames with the packed form, 0 in 19 M frames with this one; profiles/r05_tx_determinism.txt).
-// The plain packed FMAs of the encoder's GRU scan (no operand modifiers) do not show it (same runs: z identical).
+// The plain packed FMAs of the encoder's GRU scan (no operand modifiers) do not show it (same runs: z identical).  It is the hazard round 3 met in the receiver's FIR
+// (HISTORY.md 3.7: "a dense sequence of packed-f32 FMAs with op_sel operands misbehaves in the last quarter-wave when the SIMD's other wavefront belongs to a different
+// workgroup running matrix instructions") -- which is exactly where a modulator wavefront runs in the pipelined bench.  Rule for this code base: NO v_pk_*_f32 with op_sel / neg
+// modifiers in any kernel that can share a SIMD with another kernel's wavefronts; tests/test_hip_parity.py::test_transmit_side_is_bit_reproducible_under_load holds the line.
 __device__ __forceinline__ f32x2 idft_term(f32x2 acc, float2 sy, float2 w)
 {
     acc[0] = fmaf(sy.x, w.x, acc[0]); acc[1] = fmaf(sy.x, w.y, acc[1]);

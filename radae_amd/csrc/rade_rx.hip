@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
                 // planes, a.wfwd16 from L2) and the B operand twelve columns: the six symbols' window planes as they are, and with every (re, im) pair turned into
                 // (im, -re) in registers (exact).  hi hi + hi lo + lo hi as in check_pilots: 30 matrix instructions per 16-row tile in three independent chains,
                 // one tile each on wavefronts 0 and 1.  (As vector FMAs -- five lanes per carrier, 32 samples each -- this phase was 9 k cycles, and beside a
-                // second workgroup the vector ALU is what the two compete for: DESIGN.md 3.9.)
+                // second workgroup the vector ALU is what the two compete for: HISTORY.md 3.9.)
                 typedef const __attribute__((address_space(1))) f16x8 glb_f16x8_t;
                 const int wave = tid >> 6, lane = tid & 63, col = lane & 15, g = lane >> 4;
                 const int sc_ = col < 6 ? col : min(col - 6, 5);

@@ -1130,7 +1130,7 @@ def test_tx_channel_one_pass_equals_two_calls(Engine, torch_dev, oracle, oracle_
 
 def test_rx2_replicas_agree_when_two_workgroups_share_a_cu(Engine, torch_dev, golden, monkeypatch):
     """300 copies of one stream: more workgroups than CUs, so 44 CUs run two of them side by side -- the situation k_rx_sync2 exists
-    for, and the one in which packed f32 FMAs in its band-pass filter corrupted lanes 48..63.  Bit-identical in every
+    for, and the one in which packed f32 FMAs in its band-pass filter corrupted lanes 48..63 (HISTORY.md 3.7).  Bit-identical in every
     slot, three fresh launches, and equal to the one-stream-per-CU kernel's discrete outputs."""
     import torch
     g = golden("rxtrace_mpp")

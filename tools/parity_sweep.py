@@ -40,7 +40,7 @@ for case in range(N):
         first = {k: int(np.argmax(t[k] != d[k])) for k in INT_KEYS if not np.array_equal(t[k], d[k])}
         dfm = float(np.abs(t["fmax"] - d["fmax"]).max()) if len(t["fmax"]) == len(d["fmax"]) else -1.0
         # discrete outputs all equal but fmax moved by a grid step.  Rounds 2-3 read this as a refine() tie (two 0.1 Hz bins equal to within the float rounding of
-        # the complex128 sums); it was the device searching a 20-point grid where the reference's np.arange had 21 points and has not occurred
+        # the complex128 sums); it was the device searching a 20-point grid where the reference's np.arange had 21 points (HISTORY.md 4) and has not occurred
         # since that was fixed -- the class stays so that a regression shows up under its old name
         tie = not first and 0.0 < dfm < 0.0501
         if tie:
