@@ -86,6 +86,9 @@ extern "C" void rd_debug_phase_cycles2(long long *out) { hipMemcpyFromSymbol(out
 #define PH2(i) do { } while (0)
 #endif
 #define DQ2_ROWS 12
+#ifndef RX2_DQ_D3
+#define RX2_DQ_D3 4
+#endif
 
 struct DecShared2 {
     __attribute__((aligned(16))) _Float16 xh[DQ2_ROWS + 2][DQ_XB * 8];   // physical row 0: conv history, 1..12: the chunk, 13: zeros
@@ -101,7 +104,7 @@ struct DecShared2 {
 template <int NT, bool SINGLE>
 __device__ __forceinline__ void dq2_gemm_tiles_(DecShared2 *sh_, const DqGemm g_, int ct_, int Tb_, unsigned rstmask_)
 {
-    constexpr int D = NT == 1 ? 12 : 4;                                // k-steps of weights in flight
+    constexpr int D = NT == 1 ? 12 : ((NT == 3 && SINGLE) ? RX2_DQ_D3 : 4);   // k-steps of weights in flight (one plane of a three-tile product: 48 registers at 4, 96 at 8)
     const int ct = uni(ct_), Tb = uni(Tb_); const unsigned rstmask = (unsigned)uni((int)rstmask_);
     const int nct = uni(g_.nct), N = uni(g_.N), from_hb = uni(g_.from_hb), ktap = uni(g_.ktap), ks0 = uni(g_.ks0), nks = uni(g_.nks), init_gi = uni(g_.init_gi),
               outk = uni(g_.out), ocol = uni(g_.ocol), act = uni(g_.act), gstride = uni(g_.gstride);
