@@ -16,6 +16,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define DQ_XB 96                 // 8-half blocks per x row
 #define DQ_HB 16                 // blocks per GRU-output row (12 used)
 #define DQ_PEND_MAX 64           // pending rows a stream can hold (engine: dec_rows <= 63)
+// floats per row of the GRU-input sums in LDS: 288 + 4.  With 288 (= 9 x 32) every row started on the same bank, and the 16-byte accesses of a product's epilogue -- lanes = rows --
+// were 8-way conflicts: two thirds of ALL bank-conflict cycles of the kernel (tools/rx2_lds_conflicts.sh, round 5); with 292 a row starts 16 bytes further on.
+#ifndef DQ_GIS
+#define DQ_GIS 292
+#endif
 // half index of x[logical row t][col] inside a plane; the history row is logical -1 (swizzle key 15), the zero row needs no key
 __device__ __forceinline__ int dq_xoff(int t, int col) { return (t + 1) * (DQ_XB * 8) + ((((col >> 3) ^ (t & 15)) << 3) | (col & 7)); }
 __device__ __forceinline__ int dq_hoff(int t, int col) { return t * (DQ_HB * 8) + ((((col >> 3) ^ (t & 15)) << 3) | (col & 7)); }
@@ -93,7 +98,7 @@ extern "C" void rd_debug_phase_cycles2(long long *out) { hipMemcpyFromSymbol(out
 struct DecShared2 {
     __attribute__((aligned(16))) _Float16 xh[DQ2_ROWS + 2][DQ_XB * 8];   // physical row 0: conv history, 1..12: the chunk, 13: zeros
     __attribute__((aligned(16))) _Float16 xl[DQ2_ROWS + 2][DQ_XB * 8];
-    __attribute__((aligned(16))) float gi[DQ2_ROWS][288];
+    __attribute__((aligned(16))) float gi[DQ2_ROWS][DQ_GIS];
     __attribute__((aligned(16))) _Float16 hbh[DQ2_ROWS][DQ_HB * 8], hbl[DQ2_ROWS][DQ_HB * 8];
     __attribute__((aligned(16))) float hs[2][96];
     int rst[DQ_PEND_MAX];
@@ -192,8 +197,8 @@ __device__ __forceinline__ void dq2_gemm_tiles_(DecShared2 *sh_, const DqGemm g_
         for (int i = 0; i < NT; i++) {
             const int n = n0 + 16 * i, tt = t;
             f32x4 v = acc0[i] * scl[i] + bias[i];
-            if (init_gi) v += *(const __attribute__((address_space(3))) f32x4 *)(gi + tt * 288 + n);
-            if (outk == DQ_OUT_GI) { *(__attribute__((address_space(3))) f32x4 *)(gi + tt * 288 + n) = v; continue; }
+            if (init_gi) v += *(const __attribute__((address_space(3))) f32x4 *)(gi + tt * DQ_GIS + n);
+            if (outk == DQ_OUT_GI) { *(__attribute__((address_space(3))) f32x4 *)(gi + tt * DQ_GIS + n) = v; continue; }
             if (outk == DQ_OUT_GLOBAL) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) if (n + r < N) gout[(size_t)tt * gstride + n + r] = v[r];
@@ -287,7 +292,7 @@ __device__ void dq2_scan(DecShared2 *sh, const float *Whh, const float *bhh, flo
             if (on && p == 0) sh->hs[cur][j] = 0.0f;
             __syncthreads();
         }
-        const float *gn_ = gi + (size_t)min(t + 1, Tb - 1) * 288;
+        const float *gn_ = gi + (size_t)min(t + 1, Tb - 1) * DQ_GIS;
         const float g1r = gn_[0], g1z = gn_[H], g1n = gn_[2 * H];          // next step's inputs: their LDS latency hides under this step
         f32x2 ar = { 0.0f, 0.0f }, az = { 0.0f, 0.0f }, an = { 0.0f, 0.0f }, ar2 = { 0.0f, 0.0f }, az2 = { 0.0f, 0.0f }, an2 = { 0.0f, 0.0f };
         const float *hp = sh->hs[cur] + p * KP;
@@ -366,7 +371,7 @@ __device__ __forceinline__ void dq2_scan_mfma_body(DecShared2 *sh, const unsigne
             hj = 0.0f; if (finl) { hp[cur][0][ju] = (_Float16)0.0f; hp[cur][1][ju] = (_Float16)0.0f; }
             __syncthreads();
         }
-        const float *gn_ = gi + (size_t)min(t + 1, Tb - 1) * 288;
+        const float *gn_ = gi + (size_t)min(t + 1, Tb - 1) * DQ_GIS;
         float g1[3];
 #pragma unroll
         for (int gate = 0; gate < 3; gate++) g1[gate] = gn_[gate * H + ju];
