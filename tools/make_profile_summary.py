@@ -12,12 +12,12 @@ if pp: shutil.copy(pp[0], os.path.join(dst, tag + "_bench_pipelined_kernel_stats
 pc = glob.glob(os.path.join(src, "stats_c2", "**", "c2_kernel_stats.csv"), recursive=True)
 if pc: shutil.copy(pc[0], os.path.join(dst, tag + "_config2_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "config_rates.json")): shutil.copy(os.path.join(src, "config_rates.json"), os.path.join(dst, tag + "_config_rates.json"))
-for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles", "bench_config2", "bench_p1", "bench_p2", "bench_p4", "bench_two_pass_channel", "c_host_pipeline3", "single_stream_latency"):
+for name in ("bench_under_rocprof", "bench_pipelined_under_rocprof", "bench_line", "stream_cycles", "bench_config2", "bench_p1", "bench_p2", "bench_p4", "bench_two_pass_channel", "c_host_pipeline3"):
     if not os.path.exists(os.path.join(src, name + ".json")): continue
     line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_{name}.json"), "w"), indent=1)
 
-for name, ext in (("rx2_census", "json"), ("rx2_counters", "json"), ("phase_timing_rx2", "txt"), ("rx2_census", "txt")):
+for name, ext in (("rx2_census", "json"), ("rx2_counters", "json"), ("phase_timing_rx2", "txt"), ("rx2_census", "txt"), ("single_stream_latency", "txt")):
     f = os.path.join(src, f"{name}.{ext}")
     if os.path.exists(f): shutil.copy(f, os.path.join(dst, f"{tag}_{name}.{ext}"))
 
