@@ -699,29 +699,32 @@ __device__ __forceinline__ void rx2_detect_q(RxShared2 *sh, const unsigned short
 #pragma unroll
                 for (int ds = 0; ds < 2; ds++) {
                     const int sidx = 2 * sb + ds;
+                    // fragment F of the sliding window lives in slot (F - T0) mod (RT + 1): tile rt reads slot (rt + sidx) mod (RT + 1), the fragment the NEXT k-step adds goes
+                    // into the slot the first tile just left (all indices are compile-time: the loops are unrolled).  Rounds 3-4 shifted the window through the registers
+                    // instead: 40 moves per k-step behind the matrix instructions
                     if (sidx < 9) {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) { wh[RT][j] = ph[16 * (T0 + RT + sidx) + j]; wl[RT][j] = pl[16 * (T0 + RT + sidx) + j]; }
+                        for (int j = 0; j < 4; j++) { wh[(RT + sidx) % (RT + 1)][j] = ph[16 * (T0 + RT + sidx) + j]; wl[(RT + sidx) % (RT + 1)][j] = pl[16 * (T0 + RT + sidx) + j]; }
                     }
                     const _Float16 *Ab = &sh->sA[pb][lane * 8];
                     const f16x8 a0h = *(const f16x8 *)(Ab + ((0 * 2 + ds) * 2 + 0) * 512), a0l = *(const f16x8 *)(Ab + ((0 * 2 + ds) * 2 + 1) * 512);
                     const f16x8 a1h = *(const f16x8 *)(Ab + ((1 * 2 + ds) * 2 + 0) * 512), a1l = *(const f16x8 *)(Ab + ((1 * 2 + ds) * 2 + 1) * 512);
                     __builtin_amdgcn_sched_barrier(0);
+#define WSL(rt) (((rt) + sidx) % (RT + 1))
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][0], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, __builtin_bit_cast(f16x8, wh[WSL(rt)]), acc1[rt][0], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][1], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, __builtin_bit_cast(f16x8, wh[WSL(rt)]), acc1[rt][1], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, __builtin_bit_cast(f16x8, wl[rt]), acc1[rt][0], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, __builtin_bit_cast(f16x8, wl[WSL(rt)]), acc1[rt][0], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, __builtin_bit_cast(f16x8, wl[rt]), acc1[rt][1], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, __builtin_bit_cast(f16x8, wl[WSL(rt)]), acc1[rt][1], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][0], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, __builtin_bit_cast(f16x8, wh[WSL(rt)]), acc1[rt][0], 0, 0, 0);
 #pragma unroll
-                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, __builtin_bit_cast(f16x8, wh[rt]), acc1[rt][1], 0, 0, 0);
+                    for (int rt = 0; rt < RT; rt++) acc1[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, __builtin_bit_cast(f16x8, wh[WSL(rt)]), acc1[rt][1], 0, 0, 0);
+#undef WSL
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++) { wh[rt] = wh[rt + 1]; wl[rt] = wl[rt + 1]; }
                 }
                 stage_store(pb ^ 1);
                 pb ^= 1;
