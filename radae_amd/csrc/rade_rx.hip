@@ -105,9 +105,11 @@ struct DecShared2 {
     int err[DQ_PEND_MAX];
 };
 
-// NT adjacent column tiles of a product for rows [0, Tb), Tb <= 12: ONE 16-row tile (k_rx_sync's version carries two)
+// NT adjacent column tiles of a product for rows [0, Tb), Tb <= 12: ONE 16-row tile (k_rx_sync's version carries two).
+// sync_first: the barrier that separates this product from the phase before it is taken HERE, behind the first weight requests (which depend on nothing the phase before
+// wrote): the round trip to L2 (~800 cycles, once per phase: five phases per layer and chunk) runs while the workgroup's other wavefronts arrive, instead of after them
 template <int NT, bool SINGLE>
-__device__ __forceinline__ void dq2_gemm_tiles_(DecShared2 *sh_, const DqGemm g_, int ct_, int Tb_, unsigned rstmask_)
+__device__ __forceinline__ void dq2_gemm_tiles_(DecShared2 *sh_, const DqGemm g_, int ct_, int Tb_, unsigned rstmask_, int sync_first)
 {
     constexpr int D = NT == 1 ? 12 : ((NT == 3 && SINGLE) ? RX2_DQ_D3 : 4);   // k-steps of weights in flight (one plane of a three-tile product: 48 registers at 4, 96 at 8)
     const int ct = uni(ct_), Tb = uni(Tb_); const unsigned rstmask = (unsigned)uni((int)rstmask_);
@@ -145,6 +147,7 @@ __device__ __forceinline__ void dq2_gemm_tiles_(DecShared2 *sh_, const DqGemm g_
     };
 #pragma unroll
     for (int d = 0; d < D; d++) fetch(d, d);
+    if (sync_first) __syncthreads();
     f16x8 nha, nla;
     auto rows = [&](int kidx) {
         const int kk = ks0 + min(kidx, nks - 1);
@@ -220,10 +223,10 @@ __device__ __forceinline__ void dq2_gemm_tiles_(DecShared2 *sh_, const DqGemm g_
     }
 }
 template <int NT>
-__device__ __forceinline__ void dq2_gemm_tiles(DecShared2 *sh, const DqGemm g, int ct, int Tb, unsigned rstmask)
+__device__ __forceinline__ void dq2_gemm_tiles(DecShared2 *sh, const DqGemm g, int ct, int Tb, unsigned rstmask, int sync_first)
 {
-    if (uni_ptr(g.wscale) != nullptr) dq2_gemm_tiles_<NT, true>(sh, g, ct, Tb, rstmask);
-    else dq2_gemm_tiles_<NT, false>(sh, g, ct, Tb, rstmask);
+    if (uni_ptr(g.wscale) != nullptr) dq2_gemm_tiles_<NT, true>(sh, g, ct, Tb, rstmask, sync_first);
+    else dq2_gemm_tiles_<NT, false>(sh, g, ct, Tb, rstmask, sync_first);
 }
 
 // dense1 on the f32 matrix cores (see dq_dense1): three wavefronts, 32 columns each
@@ -280,6 +283,7 @@ __device__ void dq2_scan(DecShared2 *sh, const float *Whh, const float *bhh, flo
     }
     const float br = bhh[j], bz = bhh[H + j], bn = bhh[2 * H + j];
     float hj = hstate[j];
+    __syncthreads();                                   // (the barrier behind the input projection / fix-up that wrote gi: taken behind this function's global loads)
     if (on && p == 0) sh->hs[0][j] = hj;
     const float *gi = &sh->gi[0][0] + j;
     float g0r = gi[0], g0z = gi[H], g0n = gi[2 * H];
@@ -319,7 +323,7 @@ __device__ void dq2_scan(DecShared2 *sh, const float *Whh, const float *bhh, flo
         }
         g0r = g1r; g0z = g1z; g0n = g1n;
         cur ^= 1;
-        __syncthreads();
+        if (t + 1 < Tb) __syncthreads();               // (the last step's barrier is the consumer's: dq2_gemm_tiles(..., sync_first))
     }
     if (on && p == 0) hstate[j] = hj;
 }
@@ -357,6 +361,7 @@ __device__ __forceinline__ void dq2_scan_mfma_body(DecShared2 *sh, const unsigne
 #pragma unroll
     for (int gate = 0; gate < 3; gate++) { sc[gate] = whs[gate * H + ju] * 0x1p-8f; bb[gate] = bhh[gate * H + ju]; }
     float hj = hstate[ju];
+    __syncthreads();                                   // (the barrier behind the input projection / fix-up that wrote gi: taken behind the 9 / 18 weight fragments' round trip to L2)
     _Float16 (*hp)[2][H] = (_Float16 (*)[2][H])&sh->hs[0][0];           // [buffer][plane][k]: 2^8 h_{t-1} = hi + lo
     if (finl) { _Float16 a, b; dq_split(hj, a, b); hp[0][0][ju] = a; hp[0][1][ju] = b; }
     const float *gi = &sh->gi[0][0];
@@ -418,7 +423,7 @@ __device__ __forceinline__ void dq2_scan_mfma_body(DecShared2 *sh, const unsigne
 #pragma unroll
         for (int gate = 0; gate < 3; gate++) g0[gate] = g1[gate];
         cur ^= 1;
-        __syncthreads();
+        if (t + 1 < Tb) __syncthreads();               // (the last step's barrier is the consumer's: dq2_gemm_tiles(..., sync_first))
     }
     if (finl) hstate[ju] = hj;
 }
@@ -448,25 +453,24 @@ __device__ void dq2_layers(DecShared2 *sh, const rd_decs_args &a, int b, const f
         for (int c = tid; c < DQ_XB * 8; c += NT2) { sh->xh[DQ2_ROWS + 1][c] = (_Float16)0.0f; sh->xl[DQ2_ROWS + 1][c] = (_Float16)0.0f; }
     }
     dq2_dense1(sh, z, a.dense1, Tb);
-    __syncthreads();
     DqGemm g;
+    // Barriers: every product phase takes the barrier that separates it from the phase before it INSIDE its first dq2_gemm_tiles call (sync_first), behind that call's
+    // first weight requests; the recurrences do the same behind their weight fragments.  A wavefront that has no product in a phase takes the barrier bare.
     // 18 column tiles of an input projection over four wavefronts: 5 + 5 + 4 + 4
     const int ct18 = wave < 2 ? 5 * wave : 10 + 4 * (wave - 2);
     g = (DqGemm){ a.gin[0].wa16, 18, a.gin[0].bias, 288, a.gin[0].wscale, 0, 0, 0, 3, 0, DQ_OUT_GI, 0, 0, nullptr, 0 };
-    if (wave < 2) dq2_gemm_tiles<5>(sh, g, ct18, Tb, rstmask); else dq2_gemm_tiles<4>(sh, g, ct18, Tb, rstmask);
-    __syncthreads();
+    if (wave < 2) dq2_gemm_tiles<5>(sh, g, ct18, Tb, rstmask, 1); else dq2_gemm_tiles<4>(sh, g, ct18, Tb, rstmask, 1);
     PH2(20);
 #pragma unroll 1
     for (int l = 0; l < 5; l++) {
         const int in = 96 + 128 * l, cin = in + 96;
-        if (census_noscan) { }
+        if (census_noscan) __syncthreads();
         else if (a.whq[l]) dq2_scan_mfma(sh, a.whq[l], a.whs[l], a.bhh[l], a.h[l] + (size_t)b * 96, Tb, rstmask);
         else dq2_scan(sh, a.whh[l], a.bhh[l], a.h[l] + (size_t)b * 96, Tb, rstmask);
         PH2(21);
         // GLU gates: 6 column tiles, K = 96: 2 + 2 + 1 + 1
         g = (DqGemm){ a.glu[l].wa16, 6, nullptr, 96, a.glu[l].wscale, 1, 0, 0, 3, 0, DQ_OUT_X, in, 2, nullptr, 0 };
-        if (wave < 2) dq2_gemm_tiles<2>(sh, g, 2 * wave, Tb, rstmask); else dq2_gemm_tiles<1>(sh, g, 2 + wave, Tb, rstmask);
-        __syncthreads();
+        if (wave < 2) dq2_gemm_tiles<2>(sh, g, 2 * wave, Tb, rstmask, 1); else dq2_gemm_tiles<1>(sh, g, 2 + wave, Tb, rstmask, 1);
         PH2(22);
         // conv (2 tiles, K = 2 cin) beside the columns of the next product that are already final (K = cin): in units of cin k-steps the
         // conv tiles weigh 2 each, a projection tile 1: wavefronts 0 / 1 = one conv tile + 3 projection tiles, 2 / 3 = 6 projection tiles;
@@ -477,23 +481,22 @@ __device__ void dq2_layers(DecShared2 *sh, const rd_decs_args &a, int b, const f
         const int nct = last ? 6 : 18;
         const DqGemm gm = (DqGemm){ nx.wa16, nct, nx.bias, last ? a.out_w : 288, nx.wscale, 0, 0, 0, cin / 32, 0, DQ_OUT_GI, 0, 0, nullptr, 0 };
         if (wave < 2) {
-            dq2_gemm_tiles<1>(sh, gc, wave, Tb, rstmask);
-            if (!last) dq2_gemm_tiles<3>(sh, gm, 3 * wave, Tb, rstmask);
-        } else if (last) dq2_gemm_tiles<3>(sh, gm, 3 * (wave - 2), Tb, rstmask);
+            dq2_gemm_tiles<1>(sh, gc, wave, Tb, rstmask, 1);
+            if (!last) dq2_gemm_tiles<3>(sh, gm, 3 * wave, Tb, rstmask, 0);
+        } else if (last) dq2_gemm_tiles<3>(sh, gm, 3 * (wave - 2), Tb, rstmask, 1);
         else {          // six projection tiles as two calls of three: with six tiles' fragments (4 k-steps x 6 x 4 registers) in flight the K loop spilled -- 20 scratch instructions per k-step
-            dq2_gemm_tiles<3>(sh, gm, 6 + 6 * (wave - 2), Tb, rstmask);
-            dq2_gemm_tiles<3>(sh, gm, 9 + 6 * (wave - 2), Tb, rstmask);
+            dq2_gemm_tiles<3>(sh, gm, 6 + 6 * (wave - 2), Tb, rstmask, 1);
+            dq2_gemm_tiles<3>(sh, gm, 9 + 6 * (wave - 2), Tb, rstmask, 0);
         }
-        __syncthreads();
         PH2(23);
         // fix-up: the conv's 32 new columns (one k-step) added onto the staged sums
         const DqGemm gf = (DqGemm){ nx.wa16, nct, nullptr, last ? a.out_w : 288, nx.wscale, 0, 0, cin / 32, 1, 1, last ? DQ_OUT_GLOBAL : DQ_OUT_GI, 0, 0, out, a.out_w };
-        if (last) { if (wave >= 2) dq2_gemm_tiles<3>(sh, gf, 3 * (wave - 2), Tb, rstmask); }
-        else if (wave < 2) dq2_gemm_tiles<5>(sh, gf, ct18, Tb, rstmask);
-        else dq2_gemm_tiles<4>(sh, gf, ct18, Tb, rstmask);
-        __syncthreads();
+        if (last) { if (wave >= 2) dq2_gemm_tiles<3>(sh, gf, 3 * (wave - 2), Tb, rstmask, 1); else __syncthreads(); }
+        else if (wave < 2) dq2_gemm_tiles<5>(sh, gf, ct18, Tb, rstmask, 1);
+        else dq2_gemm_tiles<4>(sh, gf, ct18, Tb, rstmask, 1);
         PH2(24);
     }
+    __syncthreads();                                   // (behind the last fix-up: the history row below reads what the last conv wrote)
     {
         unsigned *hist = (unsigned *)(a.x + (size_t)b * a.x_sb - RD_DEC_W);
         for (int c = tid; c < RD_DEC_W; c += NT2)
