@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <pthread.h>
+#include <time.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -107,6 +108,7 @@ struct rade_batch {
     int enc_chunks; hipStream_t enc_side; hipEvent_t ev_fork, ev_join, ev_scan[5];
     hipEvent_t ev_block;             /* hipEventBlockingSync: what rade_batch_rx waits on when the host has fewer CPUs than engines (sync_blocking_now) */
     long n_sync_block, n_sync_spin;  /* waits of either kind so far (rade_batch_sync_counts) */
+    double wait_est_us;              /* how long the sleeping wait of rade_batch_rx lasted lately (running average): the next one sleeps through most of that before it polls */
 };
 
 static const int ENC_IN[5] = { 64, 224, 384, 544, 704 };    /* GRU input widths (radae_base.py:240-248) */
@@ -735,6 +737,25 @@ int rade_batch_channel_symbol(rade_batch *h, const float *z_dev, const float *H_
     return rd_launch_chan_symbol(z_dev, H_dev, noise_dev, z_hat_dev, (long)h->B * n_steps * RD_LATENT, mode, p0, p1, seed, stream) ? -1 : n_steps;
 }
 
+/* The wait of rade_batch_rx when the host is short of CPUs (sync_blocking_now): SLEEP until the receiver launch is done.  hipEventSynchronize on a
+ * hipEventBlockingSync event does not do that on this runtime -- measured (tools/host_threads_cpu.py, round 5): a lane thread sitting in it burns its whole
+ * wall time, 3.0 cores busy for three engines against 3.8 with hipStreamSynchronize -- so the thread sleeps itself: through three quarters of what the last
+ * waits took (a receiver launch lasts milliseconds and as long as the one before it), then in short naps between hipEventQuery calls.  A nap costs a wake-up,
+ * not a core; the launch's end is noticed at most one nap (plus the timer slack) late, which the other engines' batches in flight cover. */
+static double now_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec; }
+static void nap_us(double us) { if (us > 0.0) { struct timespec t = { (time_t)(us / 1e6), (long)(1e3 * (us - 1e6 * (double)(time_t)(us / 1e6))) }; nanosleep(&t, NULL); } }
+static int sleep_until_event(rade_batch *h, hipEvent_t ev)
+{
+    const double t0 = now_us();
+    hipError_t e = hipEventQuery(ev);
+    if (e == hipErrorNotReady && h->wait_est_us > 150.0) { nap_us(0.75 * h->wait_est_us); e = hipEventQuery(ev); }
+    while (e == hipErrorNotReady) { nap_us(40.0); e = hipEventQuery(ev); }
+    if (e != hipSuccess) { fprintf(stderr, "rade: %s while waiting for the receiver launch\n", hipGetErrorString(e)); return -1; }
+    const double dt = now_us() - t0;
+    h->wait_est_us = h->wait_est_us > 0.0 ? 0.75 * h->wait_est_us + 0.25 * dt : dt;
+    return 0;
+}
+
 int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *n_avail_host, int max_calls,
                   float *features_out_dev, long feat_stride, float *eoo_out_dev, rade_rx_status *status_host, void *stream)
 {
@@ -793,7 +814,7 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
         PROF_END(h, st, RADE_PROF_SYNC, 0.0);
         /* progress word and (normally final) per-stream results come back in one transfer (one device block in the host copy's order) */
         CHK(hipMemcpyAsync(hs, h->rx_progress, sizeof(int) * (status_host ? 8 + 8 * (size_t)B : 4), hipMemcpyDeviceToHost, st));
-        if (sync_blocking_now()) { CHK(hipEventRecord(h->ev_block, st)); CHK(hipEventSynchronize(h->ev_block)); h->n_sync_block++; }
+        if (sync_blocking_now()) { CHK(hipEventRecord(h->ev_block, st)); if (sleep_until_event(h, h->ev_block)) goto fail; h->n_sync_block++; }
         else { CHK(hipStreamSynchronize(st)); h->n_sync_spin++; }
         if (hs[0] == 0 || hs[1] == 0) break;    /* nothing done, or no stream stopped at the per-launch limit */
     }
