@@ -283,7 +283,7 @@ def main():
     }
     if rank == 0:
         # host side of rank 0: CPU time its threads burnt per step (a spinning wait counts in full), the CPUs it may use, and how its engines waited
-        # (rade_batch_rx spins while engines <= CPUs, else sleeps on a blocking event: include/rade_batch.h; $RADE_SYNC overrides)
+        # (rade_batch_rx spins while engines <= CPUs, else sleeps: include/rade_batch.h; $RADE_SYNC overrides)
         ncpu, quota = cpu_quota()
         sc = [e.sync_counts() for e in engs]
         out["host"] = {"cpu_s_per_step": cpu_s / args.steps, "cpu_cores_busy": cpu_s / dt, "logical_cpus": ncpu, "cgroup_cpu_quota": quota,

@@ -220,7 +220,7 @@ int main(int argc, char **argv)
            "\"per_device_ms_per_step\": [", tot[0] / tmax, n_dev, j.steps, j.warmup, 1e3 * tmax, B * n_dev, j.T, n_dev, j.pipeline, rade_multi_transport(m));
     for (int i = 0; i < n_dev; i++) printf("%s%.4f", i ? ", " : "", 1e3 * j.t_step[i]);
     printf("], \"host\": {\"cpu_s_per_step\": %.6f, \"cpu_quota\": %.2f, \"engines_in_process\": %d, \"rx_wait\": \"%s\"}",
-           cpu_s / (j.steps + j.warmup), rade_host_cpu_quota(), n_dev * j.pipeline, rade_sync_policy(n_dev * j.pipeline, rade_host_cpu_quota()) ? "blocking event" : "spin");
+           cpu_s / (j.steps + j.warmup), rade_host_cpu_quota(), n_dev * j.pipeline, rade_sync_policy(n_dev * j.pipeline, rade_host_cpu_quota()) ? "sleep" : "spin");
     printf(", \"job_last_step\": {\"offered_frames\": %.0f, \"decoded_frames\": %.0f, \"rx_calls\": %.0f, \"sync_calls\": %.0f, \"eoo_detected_streams\": %.0f, \"samples_consumed\": %.0f}}\n",
            tot[0], tot[1], tot[2], tot[3], tot[4], tot[5]);
     rade_multi_close(m);

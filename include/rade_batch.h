@@ -160,7 +160,7 @@ int rade_batch_rx_get_trace(rade_batch *h, int b, rade_rx_trace *out, float *z_h
 
 /* Host-side wait policy of rade_batch_rx (the one call that waits for its stream): hipStreamSynchronize spins, which is right while every engine's
  * host thread has a core; when more engines are open in the process than the process has CPUs (affinity mask and cgroup quota: 8 GPUs x 3 batches
- * in flight = 24 threads under a 16-core quota) the wait sleeps on a hipEventBlockingSync event instead.  $RADE_SYNC=spin|block overrides; $RADE_SYNC_PEERS=n: n processes with as many engines each share these CPUs (one process per GPU: the count is engines x n).
+ * in flight = 24 threads under a 16-core quota) the wait SLEEPS instead (naps between hipEventQuery calls: rade_engine.c sleep_until_event; hipEventSynchronize on a hipEventBlockingSync event was measured to burn a core per waiting thread on this runtime).  $RADE_SYNC=spin|block overrides; $RADE_SYNC_PEERS=n: n processes with as many engines each share these CPUs (one process per GPU: the count is engines x n).
  * rade_sync_policy is the rule itself (1 = block); rade_host_cpu_quota what it is fed with; rade_batch_sync_counts what an engine did so far. */
 double rade_host_cpu_quota(void);
 int rade_sync_policy(int engines_open, double cpu_quota);

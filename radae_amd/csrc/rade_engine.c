@@ -31,7 +31,8 @@
  * hipStreamSynchronize spins by default: right for one engine per core, wrong when the host has fewer cores than engines in flight -- 8 GPUs x 3
  * batches in flight are 24 host threads, and a container's CPU quota may be 16 (seen on the 1-GPU lease) -- the spinning threads then take the
  * cores the other engines' launch paths need.  Policy: spin while the engines open in this process fit the CPUs the process may use, otherwise
- * wait on a hipEventBlockingSync event (the thread sleeps until the interrupt).  $RADE_SYNC=spin|block overrides. */
+ * sleep until the launch is done (sleep_until_event below: naps between hipEventQuery calls -- waiting on a hipEventBlockingSync event does not sleep on this runtime).
+ * $RADE_SYNC=spin|block overrides. */
 static int g_engines_open;                 /* engines alive in this process (atomic) */
 double rade_host_cpu_quota(void)
 {   /* CPUs this process may use: the smaller of its affinity mask and the cgroup v2 quota (cpu.max = "quota period" or "max period") */
@@ -45,7 +46,7 @@ double rade_host_cpu_quota(void)
     }
     return n;
 }
-/* 1 = wait on a blocking event, 0 = spin: a pure function of the two counts (tests/test_host_cpu.py) */
+/* 1 = sleep (sleep_until_event), 0 = spin: a pure function of the two counts (tests/test_host_cpu.py) */
 int rade_sync_policy(int engines_open, double cpu_quota) { return (double)engines_open > cpu_quota; }
 /* $RADE_SYNC_PEERS = processes that share this process's CPUs and hold as many engines each (one process per GPU under torchrun: the quota is the
  * container's, the engine count this process's -- bench.py sets it to LOCAL_WORLD_SIZE): the policy then compares engines x peers with the quota */
@@ -106,7 +107,7 @@ struct rade_batch {
     long rx_calls_search, rx_calls_sync;
     /* encoder in two time chunks on two HIP streams (encode_core): the side stream and the events that order the chunks */
     int enc_chunks; hipStream_t enc_side; hipEvent_t ev_fork, ev_join, ev_scan[5];
-    hipEvent_t ev_block;             /* hipEventBlockingSync: what rade_batch_rx waits on when the host has fewer CPUs than engines (sync_blocking_now) */
+    hipEvent_t ev_block;             /* the event rade_batch_rx sleeps on (sleep_until_event) when the host has fewer CPUs than engines (sync_blocking_now) */
     long n_sync_block, n_sync_spin;  /* waits of either kind so far (rade_batch_sync_counts) */
     double wait_est_us;              /* how long the sleeping wait of rade_batch_rx lasted lately (running average): the next one sleeps through most of that before it polls */
 };
@@ -831,7 +832,7 @@ fail:
     return -1;
 }
 
-/* how many of this engine's rade_batch_rx waits slept on the blocking event / spun (measurement aid) */
+/* how many of this engine's rade_batch_rx waits slept / spun (measurement aid) */
 void rade_batch_sync_counts(const rade_batch *h, long *blocking, long *spinning) { if (blocking) *blocking = h->n_sync_block; if (spinning) *spinning = h->n_sync_spin; }
 
 /* shader-clock cycles every stream's workgroup spent in the most recent receiver launch (measurement aid: the launch lasts as
