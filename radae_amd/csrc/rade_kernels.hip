@@ -205,12 +205,20 @@ __global__ __launch_bounds__(64) void k_gemm16(rd_gemm_args a)
 // block.  With the plane count a run-time flag every matrix instruction sat behind a uniform branch and the loads of the next
 // k-block could only be waited for all at once; here the compiler counts them (partial vmcnt waits) and a fetch has two k-blocks of
 // matrix work to complete.
+// GEMM16P_WPB wavefronts per workgroup = that many ADJACENT row tiles against the same column tiles (developer switch, 1 shipped): no LDS, no barrier, nothing shared
+// in the source -- the wavefronts of a workgroup start together on one CU and walk the same weight fragments within a few k-blocks of each other, so all but the first
+// find them in that CU's vector L1.  Measured (round 5, profiles/r05_ab_notes.txt): 2 / 4 / 8 per workgroup change nothing alone (+2.3 / +0.3 / +7.3 % GEMM time) and nothing
+// decidable in the pipeline (-0.2 / +1.3 / -10.5 % frames/s): the weight traffic (3.5 GB of the 5.9 GB a pass moves from L2 to L1) is not what these launches wait for.
+#ifndef GEMM16P_WPB
+#define GEMM16P_WPB 1
+#endif
 template <int NT, int RT, bool SINGLE>
-__global__ __launch_bounds__(64) void k_gemm16p(rd_gemm_args a)
+__global__ __launch_bounds__(64 * GEMM16P_WPB) void k_gemm16p(rd_gemm_args a)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int rows = a.B * a.T;
-    const int r0 = blockIdx.x * 32 * RT;
+    const int r0 = (blockIdx.x * GEMM16P_WPB + (int)(threadIdx.x >> 6)) * 32 * RT;
+    if (r0 >= rows) return;
     const int ntt = (a.N + 31) >> 5;
     const int nt0 = blockIdx.y * NT;
     const int half = lane >> 5;
@@ -421,9 +429,10 @@ extern "C" int rd_launch_gemm(const rd_gemm_args *a, rd_stream_t s)
             static int rt1 = -1; if (rt1 < 0) rt1 = getenv("RADE_GEMM_RT1") ? 1 : 0;
             // one 32-row tile per wavefront for the one-plane layers: 96 accumulator registers less, a third wavefront per SIMD
             // (0.711 -> 0.667 ms per step over the encoder's GEMMs); six column tiles per wavefront (activations read once) changed nothing
-            if (a->Wscale) { dim3 g1(gx, ntt / 3); hipLaunchKernelGGL((k_gemm16p<3, 1, true>), g1, block, 0, st, *a); return (int)hipGetLastError(); }
-            dim3 grid(gx2, ntt / 3);
-            hipLaunchKernelGGL((k_gemm16p<3, 2, false>), grid, block, 0, st, *a);
+            dim3 blockp(64 * GEMM16P_WPB);
+            if (a->Wscale) { dim3 g1((gx + GEMM16P_WPB - 1) / GEMM16P_WPB, ntt / 3); hipLaunchKernelGGL((k_gemm16p<3, 1, true>), g1, blockp, 0, st, *a); return (int)hipGetLastError(); }
+            dim3 grid((gx2 + GEMM16P_WPB - 1) / GEMM16P_WPB, ntt / 3);
+            hipLaunchKernelGGL((k_gemm16p<3, 2, false>), grid, blockp, 0, st, *a);
             return (int)hipGetLastError();
         }
         if (ntt % 3 == 0) { dim3 grid(gx2, ntt / 3); hipLaunchKernelGGL((k_gemm16<3, 2>), grid, block, 0, st, *a); }
