@@ -134,8 +134,37 @@ typedef struct {
     const int *reset; int reset_sb;       /* optional [B][reset_sb]: zero h before step */
     const int *n_rows;                    /* optional [B] */
     int B, T, H;
+    unsigned short *outf; int outf_NQ, outf_col;   /* optional (rade_enc.hip): clamp(h_t) as two binary16 planes into columns outf_col.. of the encoder's fragment buffer instead of out */
 } rd_scan_args;
 int rd_launch_gru_scan(const rd_scan_args *a, rd_stream_t s);
+
+/* ---- the batched encoder on activations stored as matrix-core operand fragments (rade_enc.hip) ----
+ * xf [B][NQ][RD_EF_TILE] binary16: per stream a history tile (rows 30, 31 = steps -2, -1) and one tile per 32 steps, a tile = [col / 16][plane hi / lo][(col % 16) / 8][t % 32][col % 8]
+ * of 2^8 x = hi + lo.  Y^T = W X^T: K0 columns of the rows dil steps earlier (0: none), then K1 columns of the rows themselves; outputs as float32 rows (y) or into columns ycol.. of
+ * the same kind of buffer (yf). */
+#define RD_EF_KB   (RD_ENC_W / 16)
+#define RD_EF_TILE (RD_EF_KB * 1024)
+typedef struct {
+    const unsigned short *xf; int NQ;
+    int B, T, K0, K1, dil;
+    const unsigned short *Wp16; const float *Wscale; const float *bias; int N, act;   /* as rd_gemm_args; act 0 none, 1 tanh + clamp */
+    float *y; long y_sb, y_st;
+    unsigned short *yf; int ycol;
+    const float *xin; int Kin; const float *Wp;     /* rd_launch_encf_dense1 only: float32 input rows [B][T][Kin], rd_pack_weights copy of dense_1 */
+} rd_encf_args;
+int rd_launch_encf_gemm(const rd_encf_args *a, rd_stream_t s);
+/* conv_l (2 x cin -> 96 columns at column cin of xf, taps dil steps apart, tanh) and the product over the cin + 96 columns that then exist (the next GRU's input
+ * projection: Ng = 192, one-plane weights; z_dense: Ng = 80, two planes) in one launch; y float32 rows */
+typedef struct {
+    unsigned short *xf; int NQ; int B, T, cin, dil;
+    const unsigned short *Wc; const float *Wc_scale, *Wc_bias;
+    const unsigned short *Wg; const float *Wg_scale, *Wg_bias; int Ng, g_act;
+    float *y; long y_sb, y_st;
+} rd_encf_fused_args;
+int rd_launch_encf_fused(const rd_encf_fused_args *a, rd_stream_t s);
+int rd_launch_encf_dense1(const rd_encf_args *a, rd_stream_t s);
+/* conv history between calls: dir 0 = the float32 history rows (x32 + b * x32_sb, 2 x RD_ENC_W) -> the history tile; dir 1 = steps T - 2, T - 1 -> history tile and float32 rows */
+int rd_launch_encf_hist(unsigned short *xf, int NQ, float *x32, long x32_sb, int B, int T, int dir, rd_stream_t s);
 
 /* encoder input packing: features [B][T*4][36] -> [B][T][88] = 4 x (20 feats, aux -1), zero pad */
 int rd_launch_enc_pack(const float *features, float *xin, int B, int T, rd_stream_t s);

@@ -86,6 +86,7 @@ struct rade_batch {
     unsigned short *dec_whq[5]; float *dec_whs[5];      /* decoder W_hh as matrix-core fragments (int8-exact) + row scales; NULL when the blob's recurrent weights are not int8 x scale */
     /* transmit side */
     float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
+    unsigned short *enc_xf; int enc_nq, enc_unfused;   /* the concat buffer as matrix-core operand fragments (rade_enc.hip: [B][enc_nq][RD_EF_TILE] binary16), engines with enough rows for the batched GEMMs only */
     /* optional Tx band-pass filter + clip (RADE_BATCH_TX_BPF; radae_txe.py:74-83): filter state per stream, its initial value, the modulator's raw output, block phases */
     rd_bpf_state *tx_bpf, *tx_bpf_init; void *tx_raw; float *tx_chain; float *eoo_filt;   /* eoo_filt [B][Neoo] c64: the end-of-over frame as transmitted (filtered + clipped) for the channel's with_eoo */
     void *chan_scratch; void *chan_mp;        /* chan_mp [B][max_tx_mf * 960] c64: multipath output of the fused modulator (rade_batch_tx_channel), allocated on first use */
@@ -321,6 +322,15 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->enc_xin = dev_zeros(sizeof(float) * B * T * RD_ENC_IN);
     h->enc_x = dev_zeros(sizeof(float) * B * (2 + T) * RD_ENC_W);
     h->enc_gi = dev_zeros(sizeof(float) * B * T * 192);
+    h->enc_nq = 1 + (h->Tcap + 31) / 32;
+    /* conv_l and the product behind it as separate launches, unless $RADE_ENCF_FUSED (read per engine) asks for k_encf_fused: 7 launches instead of 12 and 6 % less GEMM time
+     * alone, but 4-wavefront workgroups with 12 KB of LDS that find fewer places beside the receivers: -1.1 % +- 1.2 (124 registers) / -2.8 % +- 1.2 (152) frames/s in the
+     * pipelined bench against the separate launches (profiles/r05_ab_enc_fragments.txt) */
+    h->enc_unfused = getenv("RADE_ENCF_FUSED") == NULL;
+    if (B * T > 16384 && !getenv("RADE_ENC_ROWS")) {       /* $RADE_ENC_ROWS: the float32-row path (k_gemm16p) for every size: A/B and the equality test */
+        h->enc_xf = dev_zeros(sizeof(unsigned short) * B * h->enc_nq * RD_EF_TILE);
+        if (!h->enc_xf) err |= 1;
+    }
     h->enc_z = dev_zeros(sizeof(float) * B * T * RD_LATENT);
     h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
     h->eoo_bits = dev_zeros(sizeof(float) * B * RD_NEOOBITS);
@@ -411,7 +421,7 @@ void rade_batch_close(rade_batch *h)
 {
     if (!h) return;
     ON_DEV(h);
-    void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail,
+    void *bufs[] = { h->d_tab, h->enc_xin, h->enc_x, h->enc_xf, h->enc_gi, h->enc_z, h->eoo, h->eoo_bits, h->chan_scratch, h->rx_st, h->rx_round, h->rx_avail,
                      h->rx_progress /* + rx_acc, rx_status */, h->wg_cycles, h->zrows, h->dec_x, h->dec_gi, h->dec_hbuf, h->feat84, h->trace, h->trace_z, h->d_lcg_seeds, h->dtcache, h->dec2_x, h->dec2_gi, h->dec2_hbuf, h->rx_filt, h->bpf_chain, h->bpf16, h->tx_bpf, h->tx_bpf_init, h->tx_raw, h->tx_chain, h->eoo_filt, h->corr16, h->corrq16, h->corra16, h->vm, h->chan_mp, h->wfwd16 };
     for (size_t i = 0; i < sizeof bufs / sizeof bufs[0]; i++) if (bufs[i]) hipFree(bufs[i]);
     free_lin(&h->enc_dense1); free_lin(&h->enc_zdense); free_lin(&h->dec_dense1); free_lin(&h->dec_output);
@@ -506,9 +516,65 @@ static int gemm(rade_batch *hh, const dev_lin *w, const float *a1, long a1_sb, l
  * the conv history rows the first chunk leaves): chunk 0's GEMMs of layer l+1 then fill the chip while chunk 1's scan of layer l
  * waits on its serial chain, and vice versa.  No extra passes, same kernels, same arithmetic per row: results are bit-identical to
  * the one-chunk order ($RADE_ENC_CHUNKS=1). */
+/* The same pass with the concat buffer kept as matrix-core operand fragments (rade_enc.hip): taken when the call has enough rows for the batched GEMMs
+ * (the float32-row path below serves short calls with k_gemm_splitk); the conv history crosses calls in enc_x's two float32 rows either way. */
+static int encf_gemm(rade_batch *h, const dev_lin *w, int K1, int K0, int dil, float *y, long y_sb, long y_st, int ycol, int T, int act, void *stream)
+{
+    rd_encf_args g;
+    memset(&g, 0, sizeof g);
+    g.xf = h->enc_xf; g.NQ = h->enc_nq; g.B = h->B; g.T = T; g.K0 = K0; g.K1 = K1; g.dil = dil;
+    g.Wp16 = w->wp16; g.Wscale = w->wscale16; g.bias = w->bias; g.N = w->N; g.act = act;
+    g.y = y; g.y_sb = y_sb; g.y_st = y_st; if (!y) { g.yf = h->enc_xf; g.ycol = ycol; }
+    if (K0 + K1 != w->K || !w->wp16) { fprintf(stderr, "rade: internal GEMM shape error (%d+%d != %d)\n", K0, K1, w->K); return -1; }
+    PROF_BEGIN(h, stream);
+    const int rc = rd_launch_encf_gemm(&g, stream);
+    PROF_END(h, stream, RADE_PROF_GEMM, 2.0 * (double)h->B * T * (K0 + K1) * w->N);
+    return rc;
+}
+static int encode_core_frag(rade_batch *h, int T, float *z, void *stream)
+{
+    const int B = h->B;
+    int e = rd_launch_encf_hist(h->enc_xf, h->enc_nq, h->enc_x, (long)(2 + h->Tcap) * RD_ENC_W, B, T, 0, stream);
+    {
+        rd_encf_args g;
+        memset(&g, 0, sizeof g);
+        g.xf = h->enc_xf; g.NQ = h->enc_nq; g.B = B; g.T = T; g.bias = h->enc_dense1.bias; g.N = 64; g.act = 1; g.yf = h->enc_xf; g.ycol = 0;
+        g.xin = h->enc_xin; g.Kin = h->enc_kpad; g.Wp = h->enc_dense1.wp;
+        PROF_BEGIN(h, stream); e |= rd_launch_encf_dense1(&g, stream); PROF_END(h, stream, RADE_PROF_GEMM, 2.0 * (double)B * T * h->enc_kpad * 64);
+    }
+    const int unfused = h->enc_unfused;
+    e |= encf_gemm(h, &h->enc_gin[0], ENC_IN[0], 0, 0, h->enc_gi, (long)T * 192, 192, 0, T, 0, stream);
+    for (int l = 0; l < 5 && !e; l++) {
+        const int in = ENC_IN[l], cin = in + 64;
+        rd_scan_args s = { h->enc_gi, (long)T * 192, 192, h->enc_whh[l], h->enc_bhh[l], h->enc_h[l], NULL, 0, 0, NULL, 0, NULL, B, T, 64, h->enc_xf, h->enc_nq, in };
+        PROF_BEGIN(h, stream); e |= rd_launch_gru_scan(&s, stream); PROF_END(h, stream, RADE_PROF_SCAN, 2.0 * B * T * 192 * 64);
+        const dev_lin *nx = l < 4 ? &h->enc_gin[l + 1] : &h->enc_zdense;          /* what reads the conv's output next */
+        if (unfused) {
+            e |= encf_gemm(h, &h->enc_conv[l], cin, cin, ENC_DIL[l], NULL, 0, 0, cin, T, 1, stream);
+            if (l < 4) e |= encf_gemm(h, nx, ENC_IN[l + 1], 0, 0, h->enc_gi, (long)T * 192, 192, 0, T, 0, stream);
+            else e |= encf_gemm(h, nx, 864, 0, 0, z, (long)T * RD_LATENT, RD_LATENT, 0, T, h->bottleneck1 ? 1 : 0, stream);
+            continue;
+        }
+        rd_encf_fused_args f;
+        memset(&f, 0, sizeof f);
+        f.xf = h->enc_xf; f.NQ = h->enc_nq; f.B = B; f.T = T; f.cin = cin; f.dil = ENC_DIL[l];
+        f.Wc = h->enc_conv[l].wp16; f.Wc_scale = h->enc_conv[l].wscale16; f.Wc_bias = h->enc_conv[l].bias;
+        f.Wg = nx->wp16; f.Wg_scale = nx->wscale16; f.Wg_bias = nx->bias; f.Ng = nx->N;
+        if (l < 4) { f.y = h->enc_gi; f.y_sb = (long)T * 192; f.y_st = 192; }
+        else { f.y = z; f.y_sb = (long)T * RD_LATENT; f.y_st = RD_LATENT; f.g_act = h->bottleneck1 ? 1 : 0; }
+        if (h->enc_conv[l].K != 2 * cin || nx->K != cin + 96 || !f.Wc || !f.Wg) { fprintf(stderr, "rade: internal GEMM shape error (fused layer %d)\n", l); return -1; }
+        PROF_BEGIN(h, stream);
+        e |= rd_launch_encf_fused(&f, stream);
+        PROF_END(h, stream, RADE_PROF_GEMM, 2.0 * (double)B * T * ((double)2 * cin * 96 + (double)(cin + 96) * nx->N));
+    }
+    e |= rd_launch_encf_hist(h->enc_xf, h->enc_nq, h->enc_x, (long)(2 + h->Tcap) * RD_ENC_W, B, T, 1, stream);
+    return e;
+}
+
 static int encode_core(rade_batch *h, int T, float *z, void *stream)
 {
     const int B = h->B, W = RD_ENC_W;
+    if (h->enc_xf && (long)B * T > 16384 && h->enc_chunks != 2) return encode_core_frag(h, T, z, stream);
     const long xsb = (long)(2 + h->Tcap) * W;
     float *x0 = h->enc_x + 2 * W;              /* time row 0 of each stream; rows -2,-1 hold the conv history */
     hipStream_t S[2] = { (hipStream_t)stream, h->enc_side };

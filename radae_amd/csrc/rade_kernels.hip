@@ -479,6 +479,8 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
     if (a.reset) for (int i = tid; i < a.T && i < RD_DEC_ROWS_MAX; i += blockDim.x) rst[i] = a.reset[b * a.reset_sb + i];
     float hj = a.h[(size_t)b * H + j];
     if (p == 0) hs[0][j] = hj;
+    _Float16 *of = nullptr;                         // the batched encoder's fragment buffer (rade_enc.hip): unit j's slot in row 0 of the stream's history tile
+    if (a.outf) { const int col = a.outf_col + j; of = (_Float16 *)a.outf + (size_t)b * a.outf_NQ * RD_EF_TILE + (col >> 4) * 1024 + ((col >> 3) & 1) * 256 + (col & 7); }
     const float *gi = a.gi + (size_t)b * a.gi_sb + (p < 3 ? p * H + j : j);   // lane part p < 3 fetches gate p of unit j
     // gi is fetched four steps at a time into TWO register sets that take turns: a set is refilled right after its block of steps and consumed a whole
     // block later, so the loads land in the registers they are used from.  (Rounds 1-3 had one set and a copy "next -> current" at the end of a block: the
@@ -496,6 +498,16 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
     fetch(gA, 0); fetch(gB, 4);
     __syncthreads();
     int cur = 0;
+    // fragment output (the batched encoder): a step's h leaves one step later -- the conversion to two binary16 planes and the two 2-byte stores are not on the
+    // path between two barriers (on it they cost 40 ns per step: 0.39 -> 0.44 ms over the five scans of an encoder pass)
+    float pend = 0.0f; int tpend = -1;
+    auto store_frag = [&](int tp) {
+        if (p == 0) {
+            _Float16 *o = of + (size_t)(1 + (tp >> 5)) * RD_EF_TILE + (tp & 31) * 8;
+            const float x = 256.0f * clamp1(pend); const _Float16 hi = (_Float16)x;
+            o[0] = hi; o[512] = (_Float16)(x - (float)hi);
+        }
+    };
     auto block = [&](const float (&gq)[4], int t0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -518,6 +530,7 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
                 ar = __builtin_elementwise_fma((f32x2){ wr[k], wr[k + 1] }, h0, ar); az = __builtin_elementwise_fma((f32x2){ wz[k], wz[k + 1] }, h0, az); an = __builtin_elementwise_fma((f32x2){ wn[k], wn[k + 1] }, h0, an);
                 ar = __builtin_elementwise_fma((f32x2){ wr[k + 2], wr[k + 3] }, h1, ar); az = __builtin_elementwise_fma((f32x2){ wz[k + 2], wz[k + 3] }, h1, az); an = __builtin_elementwise_fma((f32x2){ wn[k + 2], wn[k + 3] }, h1, an);
             }
+            if (of && tpend >= 0) store_frag(tpend);       // the previous step's output: independent of this step's chain, issued behind its multiply-adds
             float sr = ar[0] + ar[1], sz = az[0] + az[1], sn = an[0] + an[1];
             sr += quad_dpp<QUAD_XOR1>(sr); sz += quad_dpp<QUAD_XOR1>(sz); sn += quad_dpp<QUAD_XOR1>(sn);
             sr += quad_dpp<QUAD_XOR2>(sr); sz += quad_dpp<QUAD_XOR2>(sz); sn += quad_dpp<QUAD_XOR2>(sn);
@@ -529,8 +542,9 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
             hj = (hj - n) * z + n;
             if (p == 0) {
                 hs[cur ^ 1][j] = hj;
-                a.out[(size_t)b * a.out_sb + (size_t)t * a.out_st + j] = clamp1(hj);
+                if (!of) a.out[(size_t)b * a.out_sb + (size_t)t * a.out_st + j] = clamp1(hj);
             }
+            pend = hj; tpend = t;
             cur ^= 1;
             __syncthreads();
         }
@@ -541,6 +555,7 @@ __global__ __launch_bounds__(4 * H) void k_gru_scan(rd_scan_args a)
         block(gB, t0 + 4);
         fetch(gB, t0 + 12);
     }
+    if (of && tpend >= 0) store_frag(tpend);
     if (p == 0) a.h[(size_t)b * H + j] = hj;
 }
 
