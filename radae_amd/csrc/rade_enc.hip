@@ -40,15 +40,25 @@ __device__ __forceinline__ void encf_emit(const rd_encf_args &a, int b, int t, i
     }
 }
 
-// One wavefront = RT time tiles of 32 rows of one stream x NT tiles of 32 output columns.  ST operand stages in flight: a stage is refilled right behind the
-// matrix instructions that read it (no register copies), so a load has ST - 1 k-blocks of matrix work to complete.
-template <int NT, int RT, bool SINGLE, int ST>
-__global__ __launch_bounds__(64) void k_encf_gemm(rd_encf_args a)
+// One wavefront = RT time tiles of 32 rows of one stream x NT tiles of 32 output columns.  Operands in flight: XS k-blocks of activations and WS k-blocks of
+// weights, XS a multiple of WS; a slot is refilled right behind the matrix instructions that read it (no register copies).  Shipped: XS = WS = 3 (124 registers).
+// Measured (profiles/r05_ab_enc_fragments.txt): the kernel waits on memory (61 % of its wave-cycles on s_waitcnt, 17 % matrix-pipe busy, two wavefronts per SIMD exist
+// per launch), but activations further ahead than weights (XS 4 / 6 / 8 over WS 2) are SLOWER alone (0.536 / 0.566 / 0.575 against 0.526 ms per pass) and in the
+// pipeline (-2.2 % +- 0.8, -1.3 % +- 0.4): loads return in order, so every wait for a young weight fragment is a wait for all older activation loads as well,
+// and the deeper ring only costs registers.  2 / 4 adjacent row tiles per workgroup (ENCF_WPB: weights of all but the first from L1): 0.526 / 0.519 against 0.531.
+#ifndef ENCF_WPB
+#define ENCF_WPB 1          /* wavefronts per workgroup = adjacent row tiles against the same column tiles (developer switch; nothing shared in the source) */
+#endif
+template <int NT, int RT, bool SINGLE, int XS, int WS>
+__global__ __launch_bounds__(64 * ENCF_WPB) void k_encf_gemm(rd_encf_args a)
 {
-    const int lane = threadIdx.x, r = lane & 31, half = lane >> 5;
+    static_assert(XS % WS == 0, "activation slots are a multiple of the weight slots");
+    const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
     const int tpq = (a.T + 31) >> 5;                     // time tiles with rows of this call
     const int tq = (tpq + RT - 1) / RT;
-    const int b = blockIdx.x / tq, qt0 = (blockIdx.x - b * tq) * RT;
+    const int wid = blockIdx.x * ENCF_WPB + (threadIdx.x >> 6);
+    if (wid >= a.B * tq) return;
+    const int b = wid / tq, qt0 = (wid - b * tq) * RT;
     const int ntt = (a.N + 31) >> 5;
     const int nt0 = blockIdx.y * NT;
     const _Float16 *sb = (const _Float16 *)a.xf + (size_t)b * a.NQ * EF_TILE;
@@ -71,47 +81,59 @@ __global__ __launch_bounds__(64) void k_encf_gemm(rd_encf_args a)
     constexpr int planes = SINGLE ? 1 : 2;
     const _Float16 *wbase = (const _Float16 *)a.Wp16 + ((size_t)nt0 * planes * 64 + lane) * 8;
     const size_t wstep = (size_t)ntt * planes * 64 * 8;
-    f16x8 xh[ST][RT], xl[ST][RT], wh[ST][NT], wl[ST][NT];
-    auto fetch = [&](int st, int kb_) {
+    f16x8 xh[XS][RT], xl[XS][RT], wh[WS][NT], wl[WS][NT];
+    auto fetch_x = [&](int st, int kb_) {
         const int kb = min(kb_, nkb - 1);
 #pragma unroll
         for (int q = 0; q < RT; q++) {
             const _Float16 *p = kb < nkb0 ? p0[q] + (size_t)kb * 1024 : p1[q] + (size_t)(kb - nkb0) * 1024;
             xh[st][q] = *(const f16x8 *)p; xl[st][q] = *(const f16x8 *)(p + 512);
         }
+    };
+    auto fetch_w = [&](int st, int kb_) {
+        const int kb = min(kb_, nkb - 1);
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             wh[st][i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * planes * 64 * 8);
             if (!SINGLE) wl[st][i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * 2 * 64 * 8 + 64 * 8);
         }
     };
-    auto products = [&](int st) {
+    auto products = [&](int sx, int sw) {
 #pragma unroll
         for (int q = 0; q < RT; q++)
 #pragma unroll
             for (int i = 0; i < NT; i++) {
-                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[st][i], xl[st][q], acc[q][i], 0, 0, 0);
-                if (!SINGLE) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[st][i], xh[st][q], acc[q][i], 0, 0, 0);
-                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[st][i], xh[st][q], acc[q][i], 0, 0, 0);
+                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][i], xl[sx][q], acc[q][i], 0, 0, 0);
+                if (!SINGLE) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[sw][i], xh[sx][q], acc[q][i], 0, 0, 0);
+                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][i], xh[sx][q], acc[q][i], 0, 0, 0);
             }
     };
 #pragma unroll
-    for (int s = 0; s < ST; s++) fetch(s, s);
+    for (int s = 0; s < XS; s++) fetch_x(s, s);
+#pragma unroll
+    for (int s = 0; s < WS; s++) fetch_w(s, s);
     int kb = 0;
 #pragma unroll 1
-    for (; kb + ST <= nkb; kb += ST) {
+    for (; kb + XS <= nkb; kb += XS) {
 #pragma unroll
-        for (int s = 0; s < ST; s++) {
+        for (int s = 0; s < XS; s++) {
             __builtin_amdgcn_sched_barrier(0);
-            products(s);
+            products(s, s % WS);
             __builtin_amdgcn_sched_barrier(0);
-            fetch(s, kb + ST + s);
+            fetch_x(s, kb + XS + s);
+            fetch_w(s % WS, kb + WS + s);
         }
     }
-    {   // the last nkb % ST k-blocks (their operands are in flight already)
+    {   // the last nkb % XS k-blocks: their activations are in flight already, the weights keep cycling through their slots
         const int rem = nkb - kb;
 #pragma unroll
-        for (int s = 0; s < ST - 1; s++) if (s < rem) products(s);
+        for (int s = 0; s < XS - 1; s++)
+            if (s < rem) {
+                __builtin_amdgcn_sched_barrier(0);
+                products(s, s % WS);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + WS < XS - 1) fetch_w(s % WS, kb + WS + s);
+            }
     }
     // epilogue: lane (row r, k-half) holds channels 32 i + 8 g + 4 half + c of its row in acc[.][i][4 g + c]
 #pragma unroll
@@ -420,17 +442,15 @@ extern "C" int rd_launch_encf_gemm(const rd_encf_args *a, rd_stream_t s)
     const int ntt = (a->N + 31) >> 5, tpq = (a->T + 31) >> 5;
     if ((a->K0 & 15) || (a->K1 & 15) || ntt % 3 || (a->N & 3) || a->dil < 0 || a->dil > 2) return -1;
     hipStream_t st = (hipStream_t)s;
-    static int wide = -1, deep = -1;
-    if (wide < 0) wide = getenv("RADE_ENCF_NT6") ? 1 : 0;               // developer switches (A/B builds)
-    if (deep < 0) deep = getenv("RADE_ENCF_ST") ? atoi(getenv("RADE_ENCF_ST")) : 3;
+    static int xs = -1;
+    if (xs < 0) xs = getenv("RADE_ENCF_XS") ? atoi(getenv("RADE_ENCF_XS")) : 3;               // developer switch (A/B builds): activation k-blocks in flight
+    const dim3 g((a->B * tpq + ENCF_WPB - 1) / ENCF_WPB, ntt / 3), blk(64 * ENCF_WPB);
     if (a->Wscale) {
-        if (wide && ntt % 6 == 0) { hipLaunchKernelGGL((k_encf_gemm<6, 1, true, 2>), dim3(a->B * tpq, ntt / 6), dim3(64), 0, st, *a); return (int)hipGetLastError(); }
-        const dim3 g(a->B * tpq, ntt / 3);
-        if (deep == 2) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 2>), g, dim3(64), 0, st, *a);
-        else if (deep == 4) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 4>), g, dim3(64), 0, st, *a);
-        else hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 3>), g, dim3(64), 0, st, *a);
+        if (xs == 2) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 2, 2>), g, blk, 0, st, *a);
+        else if (xs == 4) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 4, 2>), g, blk, 0, st, *a);
+        else hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 3, 3>), g, blk, 0, st, *a);
     } else {
-        hipLaunchKernelGGL((k_encf_gemm<3, 1, false, 2>), dim3(a->B * tpq, ntt / 3), dim3(64), 0, st, *a);
+        hipLaunchKernelGGL((k_encf_gemm<3, 1, false, 2, 2>), g, blk, 0, st, *a);
     }
     return (int)hipGetLastError();
 }
