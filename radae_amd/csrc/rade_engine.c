@@ -86,7 +86,8 @@ struct rade_batch {
     unsigned short *dec_whq[5]; float *dec_whs[5];      /* decoder W_hh as matrix-core fragments (int8-exact) + row scales; NULL when the blob's recurrent weights are not int8 x scale */
     /* transmit side */
     float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
-    unsigned short *enc_xf; int enc_nq, enc_unfused;   /* the concat buffer as matrix-core operand fragments (rade_enc.hip: [B][enc_nq][RD_EF_TILE] binary16), engines with enough rows for the batched GEMMs only */
+    unsigned short *enc_xf; int enc_nq, enc_unfused;
+    int enc_hist_frag;                   /* the history tile of enc_xf holds what enc_x's two float32 history rows hold (set by a fragment pass, cleared by a reset or a float32-row pass) */   /* the concat buffer as matrix-core operand fragments (rade_enc.hip: [B][enc_nq][RD_EF_TILE] binary16), engines with enough rows for the batched GEMMs only */
     /* optional Tx band-pass filter + clip (RADE_BATCH_TX_BPF; radae_txe.py:74-83): filter state per stream, its initial value, the modulator's raw output, block phases */
     rd_bpf_state *tx_bpf, *tx_bpf_init; void *tx_raw; float *tx_chain; float *eoo_filt;   /* eoo_filt [B][Neoo] c64: the end-of-over frame as transmitted (filtered + clipped) for the channel's with_eoo */
     void *chan_scratch; void *chan_mp;        /* chan_mp [B][max_tx_mf * 960] c64: multipath output of the fused modulator (rade_batch_tx_channel), allocated on first use */
@@ -202,6 +203,7 @@ static void reset_on(rade_batch *h, int tx, int rx, void *stream)
         if (h->trace) { hipMemsetAsync(h->trace, 0, sizeof(rd_rx_trace) * (size_t)h->B * h->trace_cap, st); hipMemsetAsync(h->trace_z, 0, sizeof(float) * (size_t)h->B * h->trace_cap * RD_ZMF, st); }
     }
     if (tx) {
+        h->enc_hist_frag = 0;
         if (h->tx_bpf) hipMemcpyAsync(h->tx_bpf, h->tx_bpf_init, sizeof(rd_bpf_state) * h->B, hipMemcpyDeviceToDevice, st);
         r.enc_h = h->enc_h[0];
         /* the two history rows of each stream (conv taps before the first frame); rows 2.. are written layer by layer before they are read */
@@ -534,7 +536,10 @@ static int encf_gemm(rade_batch *h, const dev_lin *w, int K1, int K0, int dil, f
 static int encode_core_frag(rade_batch *h, int T, float *z, void *stream)
 {
     const int B = h->B;
-    int e = rd_launch_encf_hist(h->enc_xf, h->enc_nq, h->enc_x, (long)(2 + h->Tcap) * RD_ENC_W, B, T, 0, stream);
+    /* history rows: float32 -> planes only when the float32 rows are the newer ones (after a reset or a short call).  After a fragment pass the tile already holds the
+     * planes themselves: rebuilding them from 2^-8 (hi + lo) would re-split a pair whose low plane is exactly half an ulp of the high one differently (round to even) --
+     * the same sum, other partial products, last-bit differences against the float32-row kernels in about one stream of 400 per call */
+    int e = h->enc_hist_frag ? 0 : rd_launch_encf_hist(h->enc_xf, h->enc_nq, h->enc_x, (long)(2 + h->Tcap) * RD_ENC_W, B, T, 0, stream);
     {
         rd_encf_args g;
         memset(&g, 0, sizeof g);
@@ -568,6 +573,7 @@ static int encode_core_frag(rade_batch *h, int T, float *z, void *stream)
         PROF_END(h, stream, RADE_PROF_GEMM, 2.0 * (double)B * T * ((double)2 * cin * 96 + (double)(cin + 96) * nx->N));
     }
     e |= rd_launch_encf_hist(h->enc_xf, h->enc_nq, h->enc_x, (long)(2 + h->Tcap) * RD_ENC_W, B, T, 1, stream);
+    h->enc_hist_frag = !e;
     return e;
 }
 
@@ -575,6 +581,7 @@ static int encode_core(rade_batch *h, int T, float *z, void *stream)
 {
     const int B = h->B, W = RD_ENC_W;
     if (h->enc_xf && (long)B * T > 16384 && h->enc_chunks != 2) return encode_core_frag(h, T, z, stream);
+    h->enc_hist_frag = 0;
     const long xsb = (long)(2 + h->Tcap) * W;
     float *x0 = h->enc_x + 2 * W;              /* time row 0 of each stream; rows -2,-1 hold the conv history */
     hipStream_t S[2] = { (hipStream_t)stream, h->enc_side };

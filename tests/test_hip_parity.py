@@ -110,6 +110,27 @@ def test_encoder_fragment_layout_equals_row_layout(Engine, torch_dev, monkeypatc
             assert (iq_f - iq_r).abs().max().item() < 2e-4
 
 
+def test_encoder_fragment_layout_short_calls_many_streams(Engine, torch_dev, monkeypatch):
+    """The same equality where a call is ONE modem frame (3 encoder steps: one partly filled time tile, both conv taps' earlier rows in the
+    history tile) of enough streams for the batched kernels: five consecutive calls, bit-identical to the float32-row kernels."""
+    import torch
+    from radae_amd.channel_tools import synth_features
+    B = 5632                                                  # x 3 steps = 16896 rows
+    base = np.stack([synth_features(40 + b, 12 * 5) for b in range(64)])
+    feats = torch.tensor(np.tile(base, (B // 64, 1, 1)) * (1.0 + 0.001 * (np.arange(B) // 64))[:, None, None].astype(np.float32), device=torch_dev)
+    def run():
+        eng = Engine(B, max_tx_mf=1)
+        out = [eng.tx(feats[:, 12 * k:12 * k + 12].contiguous(), want_z=True) for k in range(5)]
+        eng.close()
+        return out
+    frag = run()
+    monkeypatch.setenv("RADE_ENC_ROWS", "1")
+    rows = run()
+    for (iq_f, z_f), (iq_r, z_r) in zip(frag, rows):
+        assert torch.equal(z_f, z_r) and torch.equal(iq_f, iq_r)
+    assert not torch.equal(frag[4][1][0], frag[4][1][64])     # (the streams are not copies of each other)
+
+
 def test_eoo_frames(Engine, golden):
     c = golden("consts")
     eng = Engine(3, max_tx_mf=1)

@@ -2,6 +2,8 @@
 # Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats of the bench command + separate PMC passes (never combined with
 # trace domains other than --kernel-trace).  Outputs land in gpurun_out/prof_$TAG/ and are summarised into profiles/ by
 # tools/make_profile_summary.py (run it afterwards in the repo).  Usage: bash tools/collect_profiles.sh [tag]
+# a rocprofv3 run that aborts can hang until the box's limit (round 5: 30 GPU-minutes lost on an unknown counter name): every run is bounded
+rocprofv3() { timeout -k 10 ${RP_TIMEOUT:-420} "$(which rocprofv3)" "$@"; }
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,5 +1,7 @@
 #!/bin/bash
 # developer aid, runs on the GPU box: per-dispatch durations of one step's kernels in launch order (one batch in flight) for library $1
+# a rocprofv3 run that aborts can hang until the box's limit (round 5: 30 GPU-minutes lost on an unknown counter name): every run is bounded
+rocprofv3() { timeout -k 10 ${RP_TIMEOUT:-420} "$(which rocprofv3)" "$@"; }
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/gtrace; rm -rf $O; mkdir -p $O
 RADE_LIBRADEHIP=$R/$1 rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python $R/bench.py --pipeline 1 --steps 4 --warmup 1 --no-cpu-baseline --no-parity --no-roofline > /dev/null 2> $O/err.txt

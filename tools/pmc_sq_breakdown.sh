@@ -1,5 +1,7 @@
 #!/bin/bash
 # Where do k_rx_sync's wave-cycles go?  Two PMC passes over one bench step (SQ counters are in quad-cycles, see MI355X_MICROARCH.md).
+# a rocprofv3 run that aborts can hang until the box's limit (round 5: 30 GPU-minutes lost on an unknown counter name): every run is bounded
+rocprofv3() { timeout -k 10 ${RP_TIMEOUT:-420} "$(which rocprofv3)" "$@"; }
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/sq; rm -rf $O; mkdir -p $O

@@ -2,6 +2,8 @@
 # developer aid, runs on the GPU box: instruction counters of k_rx_sync2 alone (tools/rx_only.py) for each census mask of a -DRX2_CENSUS build
 # (tools/ab_build.sh census -DRX2_CENSUS).  Mask bits: 1 no decoder stage, 2 no GRU recurrence, 8 operand planes twice,
 # 16 refine twice, 32 check_pilots rows twice, 64 correlations twice, 128 corrected window twice, 256 demodulator DFT twice, 512 detect_pilots (matrix-core pilot search) twice.
+# a rocprofv3 run that aborts can hang until the box's limit (round 5: 30 GPU-minutes lost on an unknown counter name): every run is bounded
+rocprofv3() { timeout -k 10 ${RP_TIMEOUT:-420} "$(which rocprofv3)" "$@"; }
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/census; rm -rf $O; mkdir -p $O
 export RADE_LIBRADEHIP=$R/abso/census.so

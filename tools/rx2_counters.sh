@@ -1,6 +1,8 @@
 #!/bin/bash
 # developer aid, runs on the GPU box: stall / instruction-cache / LDS counters of the receiver kernel alone (tools/rx_only.py) at one and two
 # workgroups per CU (B = 256 / 512).  usage: rx2_counters.sh [variant]
+# a rocprofv3 run that aborts can hang until the box's limit (round 5: 30 GPU-minutes lost on an unknown counter name): every run is bounded
+rocprofv3() { timeout -k 10 ${RP_TIMEOUT:-420} "$(which rocprofv3)" "$@"; }
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/rxcnt; rm -rf $O; mkdir -p $O; V=${1:-2}
 pass() { n=$1; B=$2; shift; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/${n}_$B -o pmc -- python $R/tools/rx_only.py 2 $V $B > $O/${n}_$B.log 2>&1; }

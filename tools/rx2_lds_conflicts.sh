@@ -2,6 +2,8 @@
 # developer aid, runs on the GPU box: where the LDS bank conflicts of k_rx_sync2 sit -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of the receiver alone (tools/rx_only.py)
 # for census masks of a -DRX2_CENSUS build (tools/ab_build.sh census -DRX2_CENSUS): a phase run TWICE (mask 8 planes, 16 refine, 32 check_pilots rows + window, 256 DFT,
 # 512 pilot search) adds its own conflict and active cycles to the totals; mask 1 runs no decoder stage.
+# a rocprofv3 run that aborts can hang until the box's limit (round 5: 30 GPU-minutes lost on an unknown counter name): every run is bounded
+rocprofv3() { timeout -k 10 ${RP_TIMEOUT:-420} "$(which rocprofv3)" "$@"; }
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/ldsconf; rm -rf $O; mkdir -p $O
 export RADE_LIBRADEHIP=$R/abso/census.so
