@@ -46,6 +46,10 @@ __device__ __forceinline__ void encf_emit(const rd_encf_args &a, int b, int t, i
 // per launch), but activations further ahead than weights (XS 4 / 6 / 8 over WS 2) are SLOWER alone (0.536 / 0.566 / 0.575 against 0.526 ms per pass) and in the
 // pipeline (-2.2 % +- 0.8, -1.3 % +- 0.4): loads return in order, so every wait for a young weight fragment is a wait for all older activation loads as well,
 // and the deeper ring only costs registers.  2 / 4 adjacent row tiles per workgroup (ENCF_WPB: weights of all but the first from L1): 0.526 / 0.519 against 0.531.
+// Knock-out builds (timing only; GEMM class of a pass, 0.536 ms whole): without the activation loads 0.366, without the weight loads 0.541, without the matrix
+// instructions 0.364, without the stores 0.436, with none of the four 0.212 (launches, dense_1, epilogue arithmetic) -- the parts ADD UP: a wavefront's load waits
+// and its matrix instructions do not overlap with its SIMD neighbour's, whatever the prefetch depth, a staggered start of the wavefronts (s_sleep in four phases:
+// 0.533 .. 0.551) or the weights' path (shared through LDS: tools/experiments/encf_gemm_lds_weights.inc, 0.538).
 #ifndef ENCF_WPB
 #define ENCF_WPB 1          /* wavefronts per workgroup = adjacent row tiles against the same column tiles (developer switch; nothing shared in the source) */
 #endif
@@ -99,14 +103,21 @@ __global__ __launch_bounds__(64 * ENCF_WPB) void k_encf_gemm(rd_encf_args a)
         }
     };
     auto products = [&](int sx, int sw) {
+        // plane by plane over the tiles: an accumulator's next instruction is NT x RT instructions away (back to back per accumulator measured the same: -0.2 %)
 #pragma unroll
         for (int q = 0; q < RT; q++)
 #pragma unroll
-            for (int i = 0; i < NT; i++) {
-                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][i], xl[sx][q], acc[q][i], 0, 0, 0);
-                if (!SINGLE) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[sw][i], xh[sx][q], acc[q][i], 0, 0, 0);
-                acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][i], xh[sx][q], acc[q][i], 0, 0, 0);
-            }
+            for (int i = 0; i < NT; i++) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][i], xl[sx][q], acc[q][i], 0, 0, 0);
+        if (!SINGLE) {
+#pragma unroll
+            for (int q = 0; q < RT; q++)
+#pragma unroll
+                for (int i = 0; i < NT; i++) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[sw][i], xh[sx][q], acc[q][i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < RT; q++)
+#pragma unroll
+            for (int i = 0; i < NT; i++) acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[sw][i], xh[sx][q], acc[q][i], 0, 0, 0);
     };
 #pragma unroll
     for (int s = 0; s < XS; s++) fetch_x(s, s);
