@@ -330,8 +330,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
      * pipelined bench against the separate launches (profiles/r05_ab_enc_fragments.txt) */
     h->enc_unfused = getenv("RADE_ENCF_FUSED") == NULL;
     if (B * T > 16384 && !getenv("RADE_ENC_ROWS")) {       /* $RADE_ENC_ROWS: the float32-row path (k_gemm16p) for every size: A/B and the equality test */
-        h->enc_xf = dev_zeros(sizeof(unsigned short) * B * h->enc_nq * RD_EF_TILE);
-        if (!h->enc_xf) err |= 1;
+        h->enc_xf = dev_zeros(sizeof(unsigned short) * B * h->enc_nq * RD_EF_TILE);      /* (NULL = no memory for it: the float32-row kernels serve every call) */
     }
     h->enc_z = dev_zeros(sizeof(float) * B * T * RD_LATENT);
     h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
