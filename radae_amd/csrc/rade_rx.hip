@@ -85,10 +85,12 @@ __device__ __forceinline__ int rx2_tid(int wv) { int l = (int)__builtin_amdgcn_m
 __device__ long long g_phase_cycles2[32];
 #define PH2_T0() long long ph2_t_ = clock64()
 #define PH2(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { long long n_ = clock64(); atomicAdd((unsigned long long *)&g_phase_cycles2[i], (unsigned long long)(n_ - ph2_t_)); ph2_t_ = n_; } } while (0)
+#define PH2_RESTART() do { ph2_t_ = clock64(); } while (0)
 extern "C" void rd_debug_phase_cycles2(long long *out) { hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles2), sizeof(long long) * 32); long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles2), z, sizeof z); }
 #else
 #define PH2_T0() do { } while (0)
 #define PH2(i) do { } while (0)
+#define PH2_RESTART() do { } while (0)
 #endif
 #define DQ2_ROWS 12
 #ifndef RX2_DQ_D3
@@ -1029,9 +1031,11 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
     rd_rx_stream *st = a.st + b;
     const int tid = rx_tid();
     const int Tb = S->n_rows;
+    PH2_T0();
     for (int i = tid; i < RD_RXBUF; i += NT2) { st->rx_buf[i][0] = sh->rxb[i].x; st->rx_buf[i][1] = sh->rxb[i].y; }
     for (int i = tid; i < RD_NMF; i += NT2) { st->rowsum1[i] = sh->rowsum1[i]; st->rowsum2[i] = sh->rowsum2[i]; }
     __syncthreads();
+    PH2(19);
     for (int i = tid; i < Tb; i += NT2) ds->rst[i] = rnd->row_reset[i];
     if (tid == 0) S->lds_sync = 0;
     __syncthreads();
@@ -1073,8 +1077,10 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
         S->out_base += Tb / 3; S->n_rows = 0; S->uw_from_row = 0; S->pending_valid = 0; S->batch_call0 = S->n_calls; S->need_decode = 0;
     }
     __syncthreads();
+    PH2_RESTART();
     rx2_load_rxbuf(sh, st, tid);
     __syncthreads();
+    PH2(19);
 }
 
 // check_pilots' row refreshes of one modem frame, NRT tiles of 16 row draws per wavefront, by the two-stage correlator (rx2_detect_q's algebra): the three tiles of 16 row draws against the

@@ -18,7 +18,7 @@ eng.profile(True)
 fo, st, _ = eng.rx(rx); torch.cuda.synchronize()
 eng.profile(False); pr = eng.profile_get()['rx_sync']
 lib.rd_debug_phase_cycles2(buf)
-names = ["load", "loop top", "decode+post (total)", "input: filtered samples requested + pilot replicas", "(unused)", "rx_buf shift + append", "detect: pre", "detect: correlator", " check: two-stage correlator (wave 0)", "planes+refine", "check: barrier wait", " check: window share (wave 0)", "state machine + dft", "search: reduce / sync: eq", "call end", " search: stage A(0)", " search: k loop (per group)", " search: epilogue", " search: end barrier", "", " dec: hist+dense1+gin0", " dec: scan", " dec: glu", " dec: conv+next", " dec: fixup", " dft: prefetch + products (wave 0)", " dft: barrier wait", " refine: window to f64", " refine: moments (f64 mfma)", " refine: sum partials", " refine: polynomials", " refine: argmax"]
+names = ["load", "loop top", "decode+post (total)", "input: filtered samples requested + pilot replicas", "(unused)", "rx_buf shift + append", "detect: pre", "detect: correlator", " check: two-stage correlator (wave 0)", "planes+refine", "check: barrier wait", " check: window share (wave 0)", "state machine + dft", "search: reduce / sync: eq", "call end", " search: stage A(0)", " search: k loop (per group)", " search: epilogue", " search: end barrier", " dec: rx_buf + row sums out to HBM and back (both ways)", " dec: hist+dense1+gin0", " dec: scan", " dec: glu", " dec: conv+next", " dec: fixup", " dft: prefetch + products (wave 0)", " dft: barrier wait", " refine: window to f64", " refine: moments (f64 mfma)", " refine: sum partials", " refine: polynomials", " refine: argmax"]
 tot = sum(buf[:15])
 print("stream0 calls", st[0].n_calls, "valid", st[0].n_valid, "rx_sync kernel ms", pr["ms"], "launches", pr["launches"])
 for i, n in enumerate(names): print(f"{n:18s} {buf[i]:12d} cyc  {100*buf[i]/tot:5.1f}%  {buf[i]/100e6*1e3:8.3f} ms (100MHz clk?)")
