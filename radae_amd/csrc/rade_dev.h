@@ -150,6 +150,8 @@ typedef struct {
     const unsigned short *Wp16; const float *Wscale; const float *bias; int N, act;   /* as rd_gemm_args; act 0 none, 1 tanh + clamp */
     float *y; long y_sb, y_st;
     unsigned short *yf; int ycol;
+    int seq_taps, no_pair;                          /* developer switches: conv taps one after the other (the float32-row kernels' summation order); no XCD pairing of column groups */
+    int pair;                                       /* set by rd_launch_encf_gemm: the two column groups of a 192-column product as blocks i, i + 8 of a 1-D grid (same XCD) */
     const float *xin; int Kin; const float *Wp;     /* rd_launch_encf_dense1 only: float32 input rows [B][T][Kin], rd_pack_weights copy of dense_1 */
 } rd_encf_args;
 int rd_launch_encf_gemm(const rd_encf_args *a, rd_stream_t s);

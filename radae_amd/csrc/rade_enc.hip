@@ -53,18 +53,25 @@ __device__ __forceinline__ void encf_emit(const rd_encf_args &a, int b, int t, i
 #ifndef ENCF_WPB
 #define ENCF_WPB 1          /* wavefronts per workgroup = adjacent row tiles against the same column tiles (developer switch; nothing shared in the source) */
 #endif
-template <int NT, int RT, bool SINGLE, int XS, int WS>
+// TI: the two conv taps alternate per k-block (tap 0 of k-block j, tap 1 of k-block j, ...) instead of all of tap 0 and then all of tap 1: tap 1's fragments
+// are tap 0's rows two (or one) further on -- the same cache lines, read again while they are still in L1 / L2 instead of 16..98 KB of streaming later (by then
+// from the Infinity Cache or HBM again: the launch is bound by that stream).  The float32 sums are formed in another order: last-bit differences against the
+// float32-row kernels, inside every parity bar; $RADE_ENCF_SEQ_TAPS keeps the sequential order (the bit-equality tests).
+// a.pair: a product with two column groups (a GRU input projection, 192 columns) as ONE 1-D grid in which the two wavefronts of a row tile are blocks i and i + 8
+// -- the same XCD (blocks are observed to go to XCD i % 8), dispatched back to back -- so the second one's activation reads hit that XCD's L2.
+template <int NT, int RT, bool SINGLE, int XS, int WS, bool TI>
 __global__ __launch_bounds__(64 * ENCF_WPB) void k_encf_gemm(rd_encf_args a)
 {
     static_assert(XS % WS == 0, "activation slots are a multiple of the weight slots");
     const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
     const int tpq = (a.T + 31) >> 5;                     // time tiles with rows of this call
     const int tq = (tpq + RT - 1) / RT;
-    const int wid = blockIdx.x * ENCF_WPB + (threadIdx.x >> 6);
+    int wid = blockIdx.x * ENCF_WPB + (threadIdx.x >> 6), cg = blockIdx.y;
+    if (a.pair) { const int i = blockIdx.x; wid = ((i >> 4) << 3) | (i & 7); cg = (i >> 3) & 1; }
     if (wid >= a.B * tq) return;
     const int b = wid / tq, qt0 = (wid - b * tq) * RT;
     const int ntt = (a.N + 31) >> 5;
-    const int nt0 = blockIdx.y * NT;
+    const int nt0 = cg * NT;
     const _Float16 *sb = (const _Float16 *)a.xf + (size_t)b * a.NQ * EF_TILE;
     const _Float16 *p1[RT], *p0[RT];
 #pragma unroll
@@ -90,12 +97,13 @@ __global__ __launch_bounds__(64 * ENCF_WPB) void k_encf_gemm(rd_encf_args a)
         const int kb = min(kb_, nkb - 1);
 #pragma unroll
         for (int q = 0; q < RT; q++) {
-            const _Float16 *p = kb < nkb0 ? p0[q] + (size_t)kb * 1024 : p1[q] + (size_t)(kb - nkb0) * 1024;
+            const _Float16 *p = TI ? ((kb & 1) ? p1[q] : p0[q]) + (size_t)(kb >> 1) * 1024 : (kb < nkb0 ? p0[q] + (size_t)kb * 1024 : p1[q] + (size_t)(kb - nkb0) * 1024);
             xh[st][q] = *(const f16x8 *)p; xl[st][q] = *(const f16x8 *)(p + 512);
         }
     };
     auto fetch_w = [&](int st, int kb_) {
-        const int kb = min(kb_, nkb - 1);
+        const int kq = min(kb_, nkb - 1);
+        const int kb = TI ? ((kq & 1) ? nkb0 : 0) + (kq >> 1) : kq;       // the weight's K axis stays [tap 0 | tap 1]
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             wh[st][i] = *(const f16x8 *)(wbase + kb * wstep + (size_t)i * planes * 64 * 8);
@@ -454,14 +462,20 @@ extern "C" int rd_launch_encf_gemm(const rd_encf_args *a, rd_stream_t s)
     if ((a->K0 & 15) || (a->K1 & 15) || ntt % 3 || (a->N & 3) || a->dil < 0 || a->dil > 2) return -1;
     hipStream_t st = (hipStream_t)s;
     static int xs = -1;
-    if (xs < 0) xs = getenv("RADE_ENCF_XS") ? atoi(getenv("RADE_ENCF_XS")) : 3;               // developer switch (A/B builds): activation k-blocks in flight
-    const dim3 g((a->B * tpq + ENCF_WPB - 1) / ENCF_WPB, ntt / 3), blk(64 * ENCF_WPB);
+    if (xs < 0) xs = getenv("RADE_ENCF_XS") ? atoi(getenv("RADE_ENCF_XS")) : 3;               // developer switch (A/B builds)
+    const int seq = a->seq_taps, nopair = a->no_pair;                                          // per-engine switches (rade_engine.c: $RADE_ENCF_SEQ_TAPS, $RADE_ENCF_NO_PAIR)
+    rd_encf_args b = *a;
+    const int ntile = a->B * tpq;
+    b.pair = (ntt == 6 && !nopair && ENCF_WPB == 1) ? 1 : 0;
+    const dim3 g = b.pair ? dim3(((ntile + 7) / 8) * 16, 1) : dim3((ntile + ENCF_WPB - 1) / ENCF_WPB, ntt / 3), blk(64 * ENCF_WPB);
+    const bool ti = a->K0 > 0 && a->K0 == a->K1 && !seq;
     if (a->Wscale) {
-        if (xs == 2) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 2, 2>), g, blk, 0, st, *a);
-        else if (xs == 4) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 4, 2>), g, blk, 0, st, *a);
-        else hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 3, 3>), g, blk, 0, st, *a);
+        if (ti) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 3, 3, true>), g, blk, 0, st, b);
+        else if (xs == 2) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 2, 2, false>), g, blk, 0, st, b);
+        else if (xs == 4) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 4, 2, false>), g, blk, 0, st, b);
+        else hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 3, 3, false>), g, blk, 0, st, b);
     } else {
-        hipLaunchKernelGGL((k_encf_gemm<3, 1, false, 2, 2>), g, blk, 0, st, *a);
+        hipLaunchKernelGGL((k_encf_gemm<3, 1, false, 2, 2, false>), g, blk, 0, st, b);
     }
     return (int)hipGetLastError();
 }

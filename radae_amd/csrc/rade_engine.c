@@ -86,7 +86,7 @@ struct rade_batch {
     unsigned short *dec_whq[5]; float *dec_whs[5];      /* decoder W_hh as matrix-core fragments (int8-exact) + row scales; NULL when the blob's recurrent weights are not int8 x scale */
     /* transmit side */
     float *enc_xin, *enc_x, *enc_gi, *enc_h[5], *enc_z, *eoo, *eoo_bits;
-    unsigned short *enc_xf; int enc_nq, enc_unfused;
+    unsigned short *enc_xf; int enc_nq, enc_unfused, enc_seq_taps, enc_no_pair;
     int enc_hist_frag;                   /* the history tile of enc_xf holds what enc_x's two float32 history rows hold (set by a fragment pass, cleared by a reset or a float32-row pass) */   /* the concat buffer as matrix-core operand fragments (rade_enc.hip: [B][enc_nq][RD_EF_TILE] binary16), engines with enough rows for the batched GEMMs only */
     /* optional Tx band-pass filter + clip (RADE_BATCH_TX_BPF; radae_txe.py:74-83): filter state per stream, its initial value, the modulator's raw output, block phases */
     rd_bpf_state *tx_bpf, *tx_bpf_init; void *tx_raw; float *tx_chain; float *eoo_filt;   /* eoo_filt [B][Neoo] c64: the end-of-over frame as transmitted (filtered + clipped) for the channel's with_eoo */
@@ -329,6 +329,8 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
      * alone, but 4-wavefront workgroups with 12 KB of LDS that find fewer places beside the receivers: -1.1 % +- 1.2 (124 registers) / -2.8 % +- 1.2 (152) frames/s in the
      * pipelined bench against the separate launches (profiles/r05_ab_enc_fragments.txt) */
     h->enc_unfused = getenv("RADE_ENCF_FUSED") == NULL;
+    h->enc_seq_taps = getenv("RADE_ENCF_SEQ_TAPS") != NULL;    /* developer switches, read per engine (rade_enc.hip: k_encf_gemm) */
+    h->enc_no_pair = getenv("RADE_ENCF_NO_PAIR") != NULL;
     if (B * T > 16384 && !getenv("RADE_ENC_ROWS")) {       /* $RADE_ENC_ROWS: the float32-row path (k_gemm16p) for every size: A/B and the equality test */
         h->enc_xf = dev_zeros(sizeof(unsigned short) * B * h->enc_nq * RD_EF_TILE);      /* (NULL = no memory for it: the float32-row kernels serve every call) */
     }
@@ -526,6 +528,7 @@ static int encf_gemm(rade_batch *h, const dev_lin *w, int K1, int K0, int dil, f
     g.xf = h->enc_xf; g.NQ = h->enc_nq; g.B = h->B; g.T = T; g.K0 = K0; g.K1 = K1; g.dil = dil;
     g.Wp16 = w->wp16; g.Wscale = w->wscale16; g.bias = w->bias; g.N = w->N; g.act = act;
     g.y = y; g.y_sb = y_sb; g.y_st = y_st; if (!y) { g.yf = h->enc_xf; g.ycol = ycol; }
+    g.seq_taps = h->enc_seq_taps; g.no_pair = h->enc_no_pair;
     if (K0 + K1 != w->K || !w->wp16) { fprintf(stderr, "rade: internal GEMM shape error (%d+%d != %d)\n", K0, K1, w->K); return -1; }
     PROF_BEGIN(h, stream);
     const int rc = rd_launch_encf_gemm(&g, stream);

@@ -86,10 +86,11 @@ def test_encoder_large_batch_split_f16_gemm(Engine, torch_dev, oracle, oracle_mo
 def test_encoder_fragment_layout_equals_row_layout(Engine, torch_dev, monkeypatch):
     """Calls with more than 16 k GEMM rows keep the encoder's concat buffer as matrix-core operand fragments (rade_enc.hip: two binary16
     planes per activation, written once by the producing layer); $RADE_ENC_ROWS keeps the float32-row kernels (k_gemm16p) for every size.
-    Same products in the same order: latents and transmit samples bit-identical over consecutive long calls (conv history through the
-    history tile).  A short call (float32 rows, k_gemm_splitk) between two long ones takes the history from the 22-bit planes instead of
-    the float32 rows, and the fused launches ($RADE_ENCF_FUSED, not the default) add the two conv taps alternately: equal to float32
-    roundings, which the recurrences carry along (759 steps here)."""
+    With the conv taps summed one after the other ($RADE_ENCF_SEQ_TAPS: the float32-row kernels' order) the products and their order are the
+    same: latents and transmit samples bit-identical over consecutive long calls (conv history through the history tile).  The shipped
+    order alternates the taps per k-block (tap 1 re-reads tap 0's cache lines while they are hot), the fused launches ($RADE_ENCF_FUSED)
+    do too, and a short call (float32 rows, k_gemm_splitk) between two long ones takes the history from the 22-bit planes instead of the
+    float32 rows: equal to float32 roundings, which the recurrences carry along (759 steps here)."""
     import torch
     from radae_amd.channel_tools import synth_features
     B, n_mf = 72, 84                                          # 72 x 252 = 18144 rows
@@ -100,16 +101,21 @@ def test_encoder_fragment_layout_equals_row_layout(Engine, torch_dev, monkeypatc
         out = [eng.tx(feats[:, 12 * a:12 * b].contiguous(), want_z=True) for a, b in cuts]
         eng.close()
         return out
-    frag = run()
+    shipped = run()
     monkeypatch.setenv("RADE_ENCF_FUSED", "1")
     fused = run()
     monkeypatch.delenv("RADE_ENCF_FUSED")
+    monkeypatch.setenv("RADE_ENCF_SEQ_TAPS", "1")
+    seq = run()
+    monkeypatch.setenv("RADE_ENCF_NO_PAIR", "1")
+    seq_nopair = run()
     monkeypatch.setenv("RADE_ENC_ROWS", "1")
     rows = run()
     for k in (0, 1):
-        assert torch.equal(frag[k][1], rows[k][1]) and torch.equal(frag[k][0], rows[k][0])
-    assert not torch.equal(fused[0][1], rows[0][1])           # (the switch did select the other kernels)
-    for other in (fused, frag):
+        assert torch.equal(seq[k][1], rows[k][1]) and torch.equal(seq[k][0], rows[k][0])
+        assert torch.equal(seq_nopair[k][1], rows[k][1])
+    assert not torch.equal(fused[0][1], rows[0][1]) and not torch.equal(shipped[0][1], rows[0][1])     # (the switches did select other kernels)
+    for other in (shipped, fused, seq):
         for (iq_f, z_f), (iq_r, z_r) in zip(other, rows):
             assert (z_f - z_r).abs().max().item() < 2e-5 * z_r.abs().max().item()
             assert (iq_f - iq_r).abs().max().item() < 2e-4
@@ -128,6 +134,7 @@ def test_encoder_fragment_layout_short_calls_many_streams(Engine, torch_dev, mon
         out = [eng.tx(feats[:, 12 * k:12 * k + 12].contiguous(), want_z=True) for k in range(5)]
         eng.close()
         return out
+    monkeypatch.setenv("RADE_ENCF_SEQ_TAPS", "1")            # (the float32-row kernels' summation order: see the test above)
     frag = run()
     monkeypatch.setenv("RADE_ENC_ROWS", "1")
     rows = run()
