@@ -12,8 +12,8 @@
 // The products are computed TRANSPOSED: the packed weights (rd_pack_weights_q16 / _f16x2: lane = output column, 8 k per lane -- the same bytes k_gemm16p
 // streams as B operands) are the A operand, the activation fragments the B operand, so a lane ends up with 4 x 4 consecutive output channels of ONE row:
 // 16-byte stores for float32 outputs (gi, z), 8-byte stores per plane into the fragment layout for the concat buffer.  Same products, same order of the
-// partial products per k-block (lo x W, [hi x Wlo,] hi x W), same epilogue arithmetic as k_gemm16p: the results are bit-identical to it
-// (tests/test_hip_parity.py::test_encoder_fragment_layout_equals_row_layout).
+// partial products per k-block (lo x W, [hi x Wlo,] hi x W), same epilogue arithmetic as k_gemm16p: with the conv taps summed in its order ($RADE_ENCF_SEQ_TAPS)
+// the results are bit-identical to it (tests/test_hip_parity.py::test_encoder_fragment_layout_*); the shipped order alternates the taps (see k_encf_gemm).
 #include "rade_devutil.h"
 
 #define EF_TILE RD_EF_TILE
@@ -42,14 +42,14 @@ __device__ __forceinline__ void encf_emit(const rd_encf_args &a, int b, int t, i
 
 // One wavefront = RT time tiles of 32 rows of one stream x NT tiles of 32 output columns.  Operands in flight: XS k-blocks of activations and WS k-blocks of
 // weights, XS a multiple of WS; a slot is refilled right behind the matrix instructions that read it (no register copies).  Shipped: XS = WS = 3 (124 registers).
-// Measured (profiles/r05_ab_enc_fragments.txt): the kernel waits on memory (61 % of its wave-cycles on s_waitcnt, 17 % matrix-pipe busy, two wavefronts per SIMD exist
-// per launch), but activations further ahead than weights (XS 4 / 6 / 8 over WS 2) are SLOWER alone (0.536 / 0.566 / 0.575 against 0.526 ms per pass) and in the
-// pipeline (-2.2 % +- 0.8, -1.3 % +- 0.4): loads return in order, so every wait for a young weight fragment is a wait for all older activation loads as well,
-// and the deeper ring only costs registers.  2 / 4 adjacent row tiles per workgroup (ENCF_WPB: weights of all but the first from L1): 0.526 / 0.519 against 0.531.
-// Knock-out builds (timing only; GEMM class of a pass, 0.536 ms whole): without the activation loads 0.366, without the weight loads 0.541, without the matrix
-// instructions 0.364, without the stores 0.436, with none of the four 0.212 (launches, dense_1, epilogue arithmetic) -- the parts ADD UP: a wavefront's load waits
-// and its matrix instructions do not overlap with its SIMD neighbour's, whatever the prefetch depth, a staggered start of the wavefronts (s_sleep in four phases:
-// 0.533 .. 0.551) or the weights' path (shared through LDS: tools/experiments/encf_gemm_lds_weights.inc, 0.538).
+// What bounds it, measured (profiles/r05_ab_enc_fragments.txt; tools/ubench/mfma_load_overlap.hip = this loop without the arithmetic around it): a k-block costs a
+// wavefront 2 KB of activations + 3 KB of weights; with everything L2-resident the loop runs at the L2 -> L1 rate (32.7 TB/s over the chip: 0.36 us per k-block at two
+// wavefronts per SIMD, matrix instructions hidden underneath), with the activations from the Infinity Cache / HBM at 6-7 TB/s of that stream (0.6 us).  So the launches
+// read nothing twice from beyond L2 that need not be (TI and a.pair below: 0.526 -> 0.486 ms per pass), and what remains is the 5.5 GB a pass moves through the L1s
+// (3.5 GB of it weights: a 32-row tile re-streams its layer's weights) + ~10 us per launch.  Measured and not kept: activations prefetched further ahead than weights
+// (XS 4 / 6 / 8 over WS 2: 0.536 / 0.566 / 0.575 against 0.526 -- loads return in order, so a wait for a young weight fragment waits for every older activation load),
+// 2 / 4 adjacent row tiles per workgroup (ENCF_WPB: L1 hits cost the same L1 cycles, -2 %), weights through LDS (tools/experiments/encf_gemm_lds_weights.inc: +1 % alone with
+// the old tap order, -3 % in the pipeline: four-wavefront workgroups), a staggered start of the wavefronts, back-to-back against plane-by-plane matrix instructions (-0.2 %).
 #ifndef ENCF_WPB
 #define ENCF_WPB 1          /* wavefronts per workgroup = adjacent row tiles against the same column tiles (developer switch; nothing shared in the source) */
 #endif
