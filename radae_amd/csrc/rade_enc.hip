@@ -469,6 +469,14 @@ extern "C" int rd_launch_encf_gemm(const rd_encf_args *a, rd_stream_t s)
     b.pair = (ntt == 6 && !nopair && ENCF_WPB == 1) ? 1 : 0;
     const dim3 g = b.pair ? dim3(((ntile + 7) / 8) * 16, 1) : dim3((ntile + ENCF_WPB - 1) / ENCF_WPB, ntt / 3), blk(64 * ENCF_WPB);
     const bool ti = a->K0 > 0 && a->K0 == a->K1 && !seq;
+    static int rt2 = -1; if (rt2 < 0) rt2 = getenv("RADE_ENCF_RT2") ? 1 : 0;                  // developer switch: two row tiles per wavefront (half the weight bytes per product)
+    if (a->Wscale && rt2 && ENCF_WPB == 1) {
+        const int nt2 = a->B * ((tpq + 1) / 2);
+        const dim3 g2 = b.pair ? dim3(((nt2 + 7) / 8) * 16, 1) : dim3(nt2, ntt / 3);
+        if (ti) hipLaunchKernelGGL((k_encf_gemm<3, 2, true, 3, 3, true>), g2, blk, 0, st, b);
+        else hipLaunchKernelGGL((k_encf_gemm<3, 2, true, 3, 3, false>), g2, blk, 0, st, b);
+        return (int)hipGetLastError();
+    }
     if (a->Wscale) {
         if (ti) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 3, 3, true>), g, blk, 0, st, b);
         else if (xs == 2) hipLaunchKernelGGL((k_encf_gemm<3, 1, true, 2, 2, false>), g, blk, 0, st, b);
