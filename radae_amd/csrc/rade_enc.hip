@@ -20,7 +20,7 @@
 
 // bias / scale / activation of 4 consecutive output channels of one row, and the store: float32 row-major, or the two binary16 planes at their fragment position
 template <bool LIBM_TANH>
-__device__ __forceinline__ void encf_emit(const rd_encf_args &a, int b, int t, int ch0, f32x4 v, f32x4 sc, f32x4 bs, int half, int r)
+__device__ __forceinline__ void encf_emit(const rd_encf_args &a, int b, int t, int ch0, f32x4 v, f32x4 sc, f32x4 bs)
 {
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * ENCF_WPB) void k_encf_gemm(rd_encf_args a)
                 f32x4 sc = { 0x1p-18f, 0x1p-18f, 0x1p-18f, 0x1p-18f };        // two planes of 2^10 w x rows of 2^8 x
                 if (SINGLE) { sc = *(const f32x4 *)(a.Wscale + ch0); sc *= 0x1p-8f; }     // integers x column scale, rows carry 2^8
                 const f32x4 v = { acc[q][i][4 * g], acc[q][i][4 * g + 1], acc[q][i][4 * g + 2], acc[q][i][4 * g + 3] };
-                encf_emit<false>(a, b, t, ch0, v, sc, bs, half, r);
+                encf_emit<false>(a, b, t, ch0, v, sc, bs);
             }
     }
 }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64) void k_encf_dense1(rd_encf_args a)
             const int ch0 = 32 * i + 8 * g + 4 * half;
             const f32x4 bs = *(const f32x4 *)(a.bias + ch0);
             const f32x4 v = { acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3] };
-            encf_emit<true>(a, b, t, ch0, v, (f32x4){ 1.0f, 1.0f, 1.0f, 1.0f }, bs, half, r);
+            encf_emit<true>(a, b, t, ch0, v, (f32x4){ 1.0f, 1.0f, 1.0f, 1.0f }, bs);
         }
 }
 
@@ -411,8 +411,10 @@ __global__ __launch_bounds__(256) void k_encf_hist(unsigned short *xf_, int NQ, 
     const int b = blockIdx.x, tid = threadIdx.x;
     _Float16 *sb = (_Float16 *)xf_ + (size_t)b * NQ * EF_TILE;
     float *xr = x32 + (size_t)b * x32_sb;
-    const int k = tid / 108, c8 = tid - k * 108;         // history row k = 0, 1 (step -2, -1), columns 8 c8 .. 8 c8 + 7
-    const bool on = tid < 216;
+    static_assert(RD_ENC_W % 16 == 0 && 2 * (RD_ENC_W / 8) <= 256, "two history rows in 8-column pieces, one piece per thread");
+    constexpr int PW = RD_ENC_W / 8;                     // 108 pieces per row
+    const int k = tid / PW, c8 = tid - k * PW;           // history row k = 0, 1 (step -2, -1), columns 8 c8 .. 8 c8 + 7
+    const bool on = tid < 2 * PW;
     const int col = 8 * c8;
     const size_t fo = (size_t)(col >> 4) * 1024 + ((col >> 3) & 1) * 256;
     f16x8 hi = {}, lo = {};
