@@ -143,6 +143,29 @@ def test_encoder_fragment_layout_short_calls_many_streams(Engine, torch_dev, mon
     assert not torch.equal(frag[4][1][0], frag[4][1][64])     # (the streams are not copies of each other)
 
 
+def test_encoder_fragment_layout_ragged_call_lengths(Engine, torch_dev, monkeypatch):
+    """Calls of 150, 252 and 138 steps on an engine sized for 252 (partly filled last tiles, tiles left untouched, the history taken from
+    a different tile each time): bit-identical to the float32-row kernels with the conv taps in their order."""
+    import torch
+    from radae_amd.channel_tools import synth_features
+    B, cap = 120, 84
+    lens = (50, 84, 46)                                       # x 3 steps x 120 streams = 18000 / 30240 / 16560 rows: all batched
+    feats = torch.tensor(np.stack([synth_features(300 + b, 12 * sum(lens)) for b in range(B)]), device=torch_dev)
+    def run():
+        eng = Engine(B, max_tx_mf=cap)
+        out, a = [], 0
+        for n in lens:
+            out.append(eng.tx(feats[:, 12 * a:12 * (a + n)].contiguous(), want_z=True)); a += n
+        eng.close()
+        return out
+    monkeypatch.setenv("RADE_ENCF_SEQ_TAPS", "1")
+    frag = run()
+    monkeypatch.setenv("RADE_ENC_ROWS", "1")
+    rows = run()
+    for (iq_f, z_f), (iq_r, z_r) in zip(frag, rows):
+        assert torch.equal(z_f, z_r) and torch.equal(iq_f, iq_r)
+
+
 def test_eoo_frames(Engine, golden):
     c = golden("consts")
     eng = Engine(3, max_tx_mf=1)
