@@ -139,26 +139,8 @@ def gen_consts():
     print("consts ok")
 
 
-def gen_weights_check():
-    d = {}
-    def add(name, a):
-        a = np.asarray(a, dtype=np.float64).ravel()
-        d[name] = np.array([a.size, a.sum(), np.abs(a).sum()] + list(a[:8]) + list(a[-4:]))
-    m = M19
-    add("enc_dense1_w", m.enc_dense1.w); add("enc_dense1_b", m.enc_dense1.b)
-    add("enc_zdense_w", m.enc_zdense.w); add("enc_zdense_b", m.enc_zdense.b)
-    add("dec_dense1_w", m.dec_dense1.w); add("dec_dense1_b", m.dec_dense1.b)
-    add("dec_output_w", m.dec_output.w); add("dec_output_b", m.dec_output.b)
-    for i in range(5):
-        for side, grus, convs in (("enc", m.enc_gru, m.enc_conv), ("dec", m.dec_gru, m.dec_conv)):
-            g = grus[i]; c = convs[i]
-            add(f"{side}_gru{i+1}_w_ih", g.w_ih); add(f"{side}_gru{i+1}_w_hh", g.w_hh)
-            add(f"{side}_gru{i+1}_b_ih", g.b_ih); add(f"{side}_gru{i+1}_b_hh", g.b_hh)
-            # conv flattened as [out][k][in] (tap-major) which is the C layout
-            add(f"{side}_conv{i+1}_w", c.w.transpose(0, 2, 1)); add(f"{side}_conv{i+1}_b", c.b)
-        add(f"dec_glu{i+1}_w", m.dec_glu[i].w)
-    np.savez(os.path.join(OUT, "weights_check.npz"), **d)
-    print("weights_check ok")
+# weights_check.npz is written by oracle/gen_golden_dnnw.py since round 6: from a checkpoint run through the reference's own exporter, not from
+# radae_amd/dnnw.py's reading of model19_check3.bin (which pinned the readers against each other only).
 
 
 def gen_enc_tx():
@@ -469,7 +451,6 @@ if __name__ == "__main__":
     if "wire" in which: gen_wire()
     if "knobs" in which: gen_knobs()
     if "consts" in which: gen_consts()
-    if "weights" in which: gen_weights_check()
     if "enc" in which: gen_enc_tx()
     if "chanrx" in which: gen_chan_rx()
     if "dec" in which: gen_dec_loss()

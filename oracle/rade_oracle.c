@@ -88,14 +88,14 @@ static void load_dense_int8(const orc_model *m, const char *name, lin_t *l)
     }
 }
 
-static void load_sparse_int8(const orc_model *m, const char *name, lin_t *l)
+/* n_in from the architecture: it is not in the blob (common.py:274 compiles it in) and cannot be inferred when no group keeps the last input block */
+static void load_sparse_int8(const orc_model *m, const char *name, lin_t *l, int n_in)
 {
     const rec_t *rb = find_rec(m, name, "_bias"), *rs = find_rec(m, name, "_scale"), *rq = find_rec(m, name, "_weights_int8"),
                 *ri = find_rec(m, name, "_weights_idx");
     l->n_out = rb->size / 4;
     const int *idx = (const int *)ri->data; const float *sc = (const float *)rs->data; const signed char *q = (const signed char *)rq->data;
-    int n_in = 0, p = 0;
-    for (int g = 0; g < l->n_out / 8; g++) { int cnt = idx[p++]; for (int k = 0; k < cnt; k++) { if (idx[p] + 4 > n_in) n_in = idx[p] + 4; p++; } }
+    int p = 0;
     l->n_in = n_in;
     l->b = malloc(sizeof(float) * l->n_out); memcpy(l->b, rb->data, sizeof(float) * l->n_out);
     l->w = calloc((size_t)l->n_in * l->n_out, sizeof(float));
@@ -121,10 +121,10 @@ static void unswap_rows(float *a, int hid, int cols)
     free(tmp);
 }
 
-static void load_gru(const orc_model *m, const char *name, gru_t *g)
+static void load_gru(const orc_model *m, const char *name, gru_t *g, int n_in)
 {
     char nm[64]; lin_t a, b;
-    snprintf(nm, sizeof nm, "%s_input", name); load_sparse_int8(m, nm, &a);
+    snprintf(nm, sizeof nm, "%s_input", name); load_sparse_int8(m, nm, &a, n_in);
     snprintf(nm, sizeof nm, "%s_recurrent", name); load_dense_int8(m, nm, &b);
     g->n_in = a.n_in; g->hid = b.n_in;
     g->w_ih = a.w; g->b_ih = a.b; g->w_hh = b.w; g->b_hh = b.b;
@@ -157,8 +157,8 @@ orc_model *orc_model_load(const char *path)
     load_dense_float(m, "dec_dense1", &m->dec_dense1); load_dense_float(m, "dec_output", &m->dec_output);
     for (int i = 0; i < 5; i++) {
         char nm[32];
-        snprintf(nm, sizeof nm, "enc_gru%d", i + 1); load_gru(m, nm, &m->enc_gru[i]);
-        snprintf(nm, sizeof nm, "dec_gru%d", i + 1); load_gru(m, nm, &m->dec_gru[i]);
+        snprintf(nm, sizeof nm, "enc_gru%d", i + 1); load_gru(m, nm, &m->enc_gru[i], 64 + 160 * i);      /* radae_base.py:239-249 */
+        snprintf(nm, sizeof nm, "dec_gru%d", i + 1); load_gru(m, nm, &m->dec_gru[i], 96 + 128 * i);      /* radae_base.py:377-391 */
         snprintf(nm, sizeof nm, "enc_conv%d", i + 1); load_dense_int8(m, nm, &m->enc_conv[i]);
         snprintf(nm, sizeof nm, "dec_conv%d", i + 1); load_dense_int8(m, nm, &m->dec_conv[i]);
         snprintf(nm, sizeof nm, "dec_glu%d", i + 1); load_dense_int8(m, nm, &m->dec_glu[i]);

@@ -168,7 +168,9 @@ static int dequant_dense_int8(const dnnw_rec *R, int n, const char *name, rd_lin
     return 0;
 }
 
-static int dequant_blocksparse_int8(const dnnw_rec *R, int n, const char *name, rd_linear *l)
+/* n_in comes from the architecture: the blob does not hold it (the reference compiles nb_inputs into linear_init(), wexchange/c_export/common.py:274), and
+ * a trailing 4-input block that no output group keeps leaves no trace in the index list (tests/golden/dnnw_export_A.bin has such layers) */
+static int dequant_blocksparse_int8(const dnnw_rec *R, int n, const char *name, rd_linear *l, int n_in)
 {
     const dnnw_rec *b = rec_find(R, n, name, "_bias"), *s = rec_find(R, n, name, "_scale"), *q = rec_find(R, n, name, "_weights_int8"),
                    *ix = rec_find(R, n, name, "_weights_idx");
@@ -176,20 +178,20 @@ static int dequant_blocksparse_int8(const dnnw_rec *R, int n, const char *name, 
     l->n_out = b->size / 4;
     const int *idx = (const int *)ix->data; const int nidx = ix->size / 4;
     const float *sc = (const float *)s->data; const signed char *qq = (const signed char *)q->data;
-    /* first walk: validate every count and column index, find n_in and the number of 8x4 blocks */
-    int n_in = 0, p = 0; long nblk = 0;
+    /* first walk: validate every count and column index against n_in, count the 8x4 blocks */
+    int p = 0; long nblk = 0;
+    if (n_in <= 0 || n_in % 4) return -1;
     for (int g = 0; g < l->n_out / 8; g++) {
         if (p >= nidx) return -1;
         const int cnt = idx[p++];
         if (cnt < 0 || cnt > nidx - p) return -1;
         for (int k = 0; k < cnt; k++, p++) {
             const int j = idx[p];
-            if (j < 0 || j > 65536 - 4) return -1;
-            if (j + 4 > n_in) n_in = j + 4;
+            if (j < 0 || j % 4 || j + 4 > n_in) return -1;
         }
         nblk += cnt;
     }
-    if (nblk * 32 != (long)q->size) return -1;
+    if (nblk * 32 != (long)q->size || p != nidx) return -1;
     l->n_in = n_in;
     if (lin_alloc(l)) return -1;
     memcpy(l->b, b->data, sizeof(float) * l->n_out);
@@ -214,10 +216,10 @@ static void swap_first_two_thirds(float *a, int third)
     for (int i = 0; i < third; i++) { const float t = a[i]; a[i] = a[third + i]; a[third + i] = t; }
 }
 
-static int load_gru(const dnnw_rec *R, int n, const char *name, rd_gru *g)
+static int load_gru(const dnnw_rec *R, int n, const char *name, rd_gru *g, int n_in)
 {
     char nm[64]; rd_linear in, rec;
-    snprintf(nm, sizeof nm, "%s_input", name); if (dequant_blocksparse_int8(R, n, nm, &in)) return -1;
+    snprintf(nm, sizeof nm, "%s_input", name); if (dequant_blocksparse_int8(R, n, nm, &in, n_in)) return -1;
     snprintf(nm, sizeof nm, "%s_recurrent", name); if (dequant_dense_int8(R, n, nm, &rec)) { free(in.w); free(in.b); free(in.row_scale); return -1; }
     if (rec.n_out != 3 * rec.n_in || in.n_out != rec.n_out) { free(in.w); free(in.b); free(in.row_scale); free(rec.w); free(rec.b); free(rec.row_scale); return -1; }
     g->hid = rec.n_in; g->n_in = in.n_in; g->w_ih = in.w; g->b_ih = in.b; g->w_hh = rec.w; g->b_hh = rec.b; g->s_ih = in.row_scale; g->s_hh = rec.row_scale;
@@ -243,6 +245,8 @@ int rd_model_parse(const void *blob, size_t len, rd_model *m)
         recs[n].name = names[n]; recs[n].type = type; recs[n].size = size; recs[n].data = p + off + 64;
         n++; off += 64 + block;
     }
+    /* the architecture this engine is built for (radae_base.py:239-251, :377-393): GRU input widths = the running concat */
+    static const int enc_in[5] = { 64, 224, 384, 544, 704 }, dec_in[5] = { 96, 224, 352, 480, 608 };
     int err = 0;
     err |= dequant_dense_float(recs, n, "enc_dense1", &m->enc_dense1);
     err |= dequant_dense_float(recs, n, "enc_zdense", &m->enc_zdense);
@@ -250,15 +254,14 @@ int rd_model_parse(const void *blob, size_t len, rd_model *m)
     err |= dequant_dense_float(recs, n, "dec_output", &m->dec_output);
     for (int i = 0; i < 5 && !err; i++) {
         char nm[32];
-        snprintf(nm, sizeof nm, "enc_gru%d", i + 1); err |= load_gru(recs, n, nm, &m->enc_gru[i]);
-        snprintf(nm, sizeof nm, "dec_gru%d", i + 1); err |= load_gru(recs, n, nm, &m->dec_gru[i]);
+        snprintf(nm, sizeof nm, "enc_gru%d", i + 1); err |= load_gru(recs, n, nm, &m->enc_gru[i], enc_in[i]);
+        snprintf(nm, sizeof nm, "dec_gru%d", i + 1); err |= load_gru(recs, n, nm, &m->dec_gru[i], dec_in[i]);
         snprintf(nm, sizeof nm, "enc_conv%d", i + 1); err |= dequant_dense_int8(recs, n, nm, &m->enc_conv[i]);
         snprintf(nm, sizeof nm, "dec_conv%d", i + 1); err |= dequant_dense_int8(recs, n, nm, &m->dec_conv[i]);
         snprintf(nm, sizeof nm, "dec_glu%d", i + 1); err |= dequant_dense_int8(recs, n, nm, &m->dec_glu[i]);
     }
     if (err) { fprintf(stderr, "rade: weight blob is missing layers\n"); rd_model_free(m); return -1; }
-    /* sanity: the architecture this engine is built for (radae_base.py:239-251, :377-393) */
-    static const int enc_in[5] = { 64, 224, 384, 544, 704 }, dec_in[5] = { 96, 224, 352, 480, 608 };
+    /* sanity: every other layer shape of that architecture */
     for (int i = 0; i < 5; i++)
         if (m->enc_gru[i].n_in != enc_in[i] || m->enc_gru[i].hid != 64 || m->dec_gru[i].n_in != dec_in[i] || m->dec_gru[i].hid != 96 ||
             m->enc_conv[i].n_in != 2 * (enc_in[i] + 64) || m->enc_conv[i].n_out != 96 || m->dec_conv[i].n_in != 2 * (dec_in[i] + 96) || m->dec_conv[i].n_out != 32) {

@@ -70,21 +70,15 @@ def _dense_int8(rec, name):
     return np.ascontiguousarray(w, dtype=np.float32), rec[name + "_bias"].astype(np.float32)
 
 
-def _sparse_int8(rec, name):
-    """GRU-input "sparse" form: per 8-output group an idx list [count, pos...]; each kept
-    block is 4 inputs x 8 outputs stored output-major (8x4)."""
+def _sparse_int8(rec, name, n_in):
+    """GRU-input "sparse" form (common.py:140-176): per 8-output group an idx list [count, pos...]; each kept
+    block is 4 inputs x 8 outputs stored output-major (8x4); blocks that are not listed are zero.  n_in is NOT in the
+    blob (the reference compiles it in: `linear_init(..., nb_inputs, nb_outputs)`, common.py:274) -- a trailing input
+    block that no group keeps leaves no trace in the index list -- so it comes from the architecture."""
     scale = rec[name + "_scale"].astype(np.float32) * np.float32(127.0)
     n_out = scale.shape[0]
     idx = rec[name + "_weights_idx"]
     q = rec[name + "_weights_int8"]
-    # n_in is not stored; it is the largest referenced input position + 4
-    n_in = 0
-    p = 0
-    for _ in range(n_out // 8):
-        cnt = int(idx[p]); p += 1
-        if cnt:
-            n_in = max(n_in, int(idx[p:p + cnt].max()) + 4)
-        p += cnt
     wq = np.zeros((n_in, n_out), dtype=np.float32)
     p = 0
     blk = 0
@@ -92,9 +86,13 @@ def _sparse_int8(rec, name):
         cnt = int(idx[p]); p += 1
         for _ in range(cnt):
             j = int(idx[p]); p += 1
+            if j < 0 or j + 4 > n_in or j % 4:
+                raise ValueError(f"{name}: block position {j} outside the {n_in} inputs of this layer")
             b = q[blk * 32:(blk + 1) * 32].reshape(8, 4).T  # (4 in, 8 out)
             wq[j:j + 4, g * 8:(g + 1) * 8] = b
             blk += 1
+    if p != idx.size or blk * 32 != q.size:
+        raise ValueError(f"{name}: index list and block data disagree")
     w = (wq * scale[None, :]).T
     return np.ascontiguousarray(w, dtype=np.float32), rec[name + "_bias"].astype(np.float32)
 
@@ -129,8 +127,8 @@ class Dense:
     b: np.ndarray
 
 
-def _gru(rec, name):
-    w_ih, b_ih = _sparse_int8(rec, name + "_input")
+def _gru(rec, name, n_in):
+    w_ih, b_ih = _sparse_int8(rec, name + "_input", n_in)
     w_hh, b_hh = _dense_int8(rec, name + "_recurrent")
     return GRU(_unswap_gates(w_ih), _unswap_gates(w_hh), _unswap_gates(b_ih), _unswap_gates(b_hh))
 
@@ -156,17 +154,20 @@ class Model:
 
 
 ENC_DILATION = (1, 2, 2, 2, 2)  # radae_base.py:241-249
+# GRU input widths = the running DenseNet concat (radae_base.py:239-249, :377-391; rade_enc_data.h / rade_dec_data.h)
+ENC_GRU_IN = tuple(64 + k * (64 + 96) for k in range(5))
+DEC_GRU_IN = tuple(96 + k * (96 + 32) for k in range(5))
 
 
 def load_model(path: str) -> Model:
     rec = read_records(path)
     return Model(
         enc_dense1=Dense(*_dense_float(rec, "enc_dense1")),
-        enc_gru=[_gru(rec, f"enc_gru{i}") for i in range(1, 6)],
+        enc_gru=[_gru(rec, f"enc_gru{i}", ENC_GRU_IN[i - 1]) for i in range(1, 6)],
         enc_conv=[_conv(rec, f"enc_conv{i}", ENC_DILATION[i - 1]) for i in range(1, 6)],
         enc_zdense=Dense(*_dense_float(rec, "enc_zdense")),
         dec_dense1=Dense(*_dense_float(rec, "dec_dense1")),
-        dec_gru=[_gru(rec, f"dec_gru{i}") for i in range(1, 6)],
+        dec_gru=[_gru(rec, f"dec_gru{i}", DEC_GRU_IN[i - 1]) for i in range(1, 6)],
         dec_glu=[Dense(*_dense_int8(rec, f"dec_glu{i}")) for i in range(1, 6)],
         dec_conv=[_conv(rec, f"dec_conv{i}", 1) for i in range(1, 6)],
         dec_output=Dense(*_dense_float(rec, "dec_output")),
@@ -194,7 +195,7 @@ def _record(name: str, arr: np.ndarray) -> bytes:
 
 
 def _scaling(w_io: np.ndarray) -> np.ndarray:
-    """common.py:180-194 on a (n_in, n_out) matrix."""
+    """common.py:180-194 on a float32 (n_in, n_out) matrix, in float32 like the exporter."""
     n_in = w_io.shape[0]
     m_abs = np.max(np.abs(w_io), axis=0)
     m_sum = np.max(np.abs(w_io[:n_in:2] + w_io[1:n_in:2]), axis=0)
@@ -202,8 +203,12 @@ def _scaling(w_io: np.ndarray) -> np.ndarray:
 
 
 def _quant(w_io, scale):
-    q = np.round(w_io / scale).astype("int")
-    return np.clip(q, -128, 127)
+    """common.py:132-137 (float32 division, round half to even, the exporter's bounds check)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = np.round(w_io / scale).astype("int")
+    if q.max() > 127 or q.min() <= -128:
+        raise ValueError("value out of bounds in quantize_weight (an all-zero output column, or a scale rule violated)")
+    return q
 
 
 def _emit_dense_float(out, name, w_oi, b):
@@ -211,15 +216,17 @@ def _emit_dense_float(out, name, w_oi, b):
     out.append(_record(name + "_bias", b.astype(np.float32)))
 
 
-def _emit_int8(out, name, w_oi, b, sparse):
-    w_io = w_oi.T.astype(np.float64)
+def _emit_int8(out, name, w_io, b, sparse):
+    """One quantised linear layer as `print_linear_layer` (common.py:200-277) + the compiler + write_rade_weights.c make it.
+    w_io: float32 (n_in, n_out) IN THE MEMORY ORDER THE EXPORTER HOLDS IT (a transposed view for dense / GRU matrices, a C-ordered copy for
+    convolutions): `np.sum(q * scale, axis=0)` runs in float64 and its summation order follows the memory order, and byte identity of
+    `subias` with the reference-exported blob (tests/golden/dnnw_export.npz) depends on it.  b: float32 or None."""
+    assert w_io.dtype == np.float32
     n_in, n_out = w_io.shape
     assert n_in % 4 == 0 and n_out % 8 == 0
-    scale = _scaling(w_io)
-    scale = np.where(scale == 0, 1e-12, scale)
+    scale = _scaling(w_io)                                            # float32
     q = _quant(w_io, scale)
-    bias = np.zeros(n_out) if b is None else b.astype(np.float64)
-    if sparse:   # common.py:140-176, every non-zero 4x8 block kept, block stored output-major (8x4)
+    if sparse:   # common.py:140-176: every 4x8 block with a non-zero FLOAT weight kept, block stored output-major (8x4)
         idx, blocks = [], []
         for i in range(n_out // 8):
             pos = len(idx); idx.append(-1); cnt = 0
@@ -234,9 +241,11 @@ def _emit_int8(out, name, w_oi, b, sparse):
     else:        # common.py:59-69
         qq = q.reshape(n_in // 4, 4, n_out // 8, 8).transpose(2, 0, 3, 1)
         out.append(_record(name + "_weights_int8", np.ascontiguousarray(qq).astype(np.int8).ravel()))
-    out.append(_record(name + "_subias", (bias - np.sum(q * scale, axis=0)).astype(np.float32)))
+    # common.py:263-268: int64 q x float32 scale -> float64 products, float64 sums; the C compiler then rounds the printed doubles to float
+    subias = (np.zeros(n_out) if b is None else b.astype(np.float32)) - np.sum(q * scale, axis=0)
+    out.append(_record(name + "_subias", subias.astype(np.float64).astype(np.float32)))
     out.append(_record(name + "_scale", (scale / 127).astype(np.float32)))
-    out.append(_record(name + "_bias", bias.astype(np.float32)))
+    out.append(_record(name + "_bias", (np.zeros(n_out) if b is None else b).astype(np.float32)))
 
 
 def _swap_gates(a):
@@ -245,24 +254,34 @@ def _swap_gates(a):
     return out
 
 
+def _emit_gru(out, name, g):
+    """print_gru_layer (common.py:346-382): gates r,z,n -> z,r,n in place on the torch-oriented arrays, then the transposed VIEW."""
+    _emit_int8(out, name + "_input", np.ascontiguousarray(_swap_gates(g.w_ih), dtype=np.float32).T, _swap_gates(g.b_ih), sparse=True)
+    _emit_int8(out, name + "_recurrent", np.ascontiguousarray(_swap_gates(g.w_hh), dtype=np.float32).T, _swap_gates(g.b_hh), sparse=False)
+
+
+def _emit_conv(out, name, c):
+    """print_conv1d_layer (common.py:297-311): (out, in, k) -> (k, in, out) -> a C-ordered (k * in, out) copy."""
+    w = np.transpose(np.asarray(c.w, dtype=np.float32), (2, 1, 0))
+    _emit_int8(out, name, np.reshape(w, (-1, w.shape[-1])), c.b, sparse=False)
+
+
 def write_blob(model: Model, path: str) -> None:
     """Quantise (int8 + per-output scale, like the reference's exporter) and write a DNNw blob."""
     out = []
     _emit_dense_float(out, "enc_dense1", model.enc_dense1.w, model.enc_dense1.b)
     _emit_dense_float(out, "enc_zdense", model.enc_zdense.w, model.enc_zdense.b)
     for i, g in enumerate(model.enc_gru, 1):
-        _emit_int8(out, f"enc_gru{i}_input", _swap_gates(g.w_ih), _swap_gates(g.b_ih), sparse=True)
-        _emit_int8(out, f"enc_gru{i}_recurrent", _swap_gates(g.w_hh), _swap_gates(g.b_hh), sparse=False)
+        _emit_gru(out, f"enc_gru{i}", g)
     for i, c in enumerate(model.enc_conv, 1):
-        _emit_int8(out, f"enc_conv{i}", c.w.transpose(0, 2, 1).reshape(c.w.shape[0], -1), c.b, sparse=False)
+        _emit_conv(out, f"enc_conv{i}", c)
     _emit_dense_float(out, "dec_dense1", model.dec_dense1.w, model.dec_dense1.b)
     for i, g in enumerate(model.dec_glu, 1):
-        _emit_int8(out, f"dec_glu{i}", g.w, None, sparse=False)
+        _emit_int8(out, f"dec_glu{i}", np.ascontiguousarray(g.w, dtype=np.float32).T, None, sparse=False)
     _emit_dense_float(out, "dec_output", model.dec_output.w, model.dec_output.b)
     for i, g in enumerate(model.dec_gru, 1):
-        _emit_int8(out, f"dec_gru{i}_input", _swap_gates(g.w_ih), _swap_gates(g.b_ih), sparse=True)
-        _emit_int8(out, f"dec_gru{i}_recurrent", _swap_gates(g.w_hh), _swap_gates(g.b_hh), sparse=False)
+        _emit_gru(out, f"dec_gru{i}", g)
     for i, c in enumerate(model.dec_conv, 1):
-        _emit_int8(out, f"dec_conv{i}", c.w.transpose(0, 2, 1).reshape(c.w.shape[0], -1), c.b, sparse=False)
+        _emit_conv(out, f"dec_conv{i}", c)
     with open(path, "wb") as f:
         f.write(b"".join(out))
