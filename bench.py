@@ -37,6 +37,8 @@ import torch
 
 NMF = 960
 F32_PEAK_TFLOPS = 157.3          # MI355X f32 matrix == f32 vector peak (MI355X_MICROARCH.md)
+F16_PEAK_TFLOPS = 2500.0         # dense binary16 MFMA peak (MI355X_MICROARCH.md; the sparsity-inclusive headline figure is not used)
+DTYPE = "f32 I/O, 2xf16 (22-bit) MFMA operands, f32 accumulate (refine: f64 MFMA)"
 HBM_PEAK_GBS = 8000.0
 # ---- executed-work model of k_rx_sync (SURVEY.md 8d figures) --------------------------------------------
 PREWARM_SECONDS = 1.5                            # see main(): untimed, before the W warm-up steps (the clocks of an idle GPU take about a second of load to settle)
@@ -55,7 +57,7 @@ REF_SEARCH_CALL_FLOP = 960 * 40 * 160 * 2 * 8.0  # the reference's formulation o
 ALGO_BYTES_PER_FRAME = 4128                      # whole path, BASELINE.md section 4
 RX_ALGO_BYTES_PER_FRAME = 640 + 144              # the receiver kernel's share: IQ in + features out
 RX_KERNEL_NAME = "k_rx_sync2"                     # the receiver kernel (rade_rx.hip): the PMC summary is looked up under this name
-PROFILE_TAG = "r05"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
+PROFILE_TAG = "r06"                              # profiles/<tag>_pmc_summary.json etc. (tools/collect_profiles.sh)
 
 
 def executed_flop(search_calls, sync_calls, decoded_mf):
@@ -267,7 +269,7 @@ def main():
     out = {
         "metric": "vocoder-feature frames/sec (enc+chan+dec), model19", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "model19_check3 streaming radae_txe -> OFDM + MPP multipath/AWGN 3 dB/-11 Hz -> radae_rxe (configs[2])",
                    "streams_per_gpu": B, "frames_per_stream": T, "global_streams": B * world, "batches_in_flight": depth, "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only",
                    "arithmetic": "f32 DSP, f64 refine, matrix products on split-binary16 (2 x 11 bit) MFMA with f32 accumulation"},
@@ -367,15 +369,19 @@ def roofline_leg(eng, step, steps, B, T, value, world):
     else:
         achieved = p["flops"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
         r.update({"achieved": achieved, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F32_PEAK_TFLOPS})
-    # counters of the same command, collected in separate rocprofv3 --pmc passes (tools/collect_profiles.sh -> profiles/)
-    # "bound" names the roofline the (achieved, peak) pair is priced against -- compute, at the f32 matrix-core peak; the byte side is
-    # hbm_frac_kernel / hbm_frac_whole_job.  Neither binds this kernel: "limiter" says what does (SQ wave-cycle shares of the same
-    # command, separate --pmc pass): waves parked on s_waitcnt / s_barrier on a per-stream serial chain, then VALU issue.
+    # counters of the same command, collected in separate rocprofv3 --pmc passes (tools/collect_profiles.sh -> profiles/).
+    # (achieved, peak, frac) keep the contract's pricing -- executed work in its cheapest formulation against the f32 matrix peak ("priced_against") -- and
+    # describe ONE launch with the chip to itself, the duration `rocprofv3 --kernel-trace --stats` reproduces (profiles/<tag>_bench_kernel_stats.csv).
+    # "bound" says what limits the kernel: "mfma" / "hbm" when a pipe is, "latency" when neither is (matrix pipe < 25 % busy by SQ_BUSY counters AND
+    # algorithmic bytes < 10 % of HBM): a per-stream serial chain parked on s_waitcnt / s_barrier, then VALU issue ("limiter", SQ wave-cycle shares).
+    # f16_pipe prices the matrix instructions the kernel actually ISSUES (SQ_INSTS_VALU_MFMA_MOPS_F16 x 512 flop, split-binary16 products) against the
+    # dense binary16 peak: the distance to the pipe the products run on.
+    r["priced_against"] = "mfma (f32 matrix peak; SURVEY 8(d))"
     r["bound"] = "mfma"
     r["limiter"] = "latency (s_waitcnt/s_barrier) + valu-issue"
     r["traffic"] = None
     try:
-        tag = next(t for t in (PROFILE_TAG, "r04", "r03") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
+        tag = next(t for t in (PROFILE_TAG, "r05", "r04", "r03") if os.path.exists(os.path.join(REPO, "profiles", f"{t}_pmc_summary.json")))
         pm = json.load(open(os.path.join(REPO, "profiles", f"{tag}_pmc_summary.json")))
         k = pm["kernels"][{"rx_sync": RX_KERNEL_NAME}.get(dom, dom)]
         raw = k["fetch_bytes_per_dispatch"] + k["write_bytes_per_dispatch"]
@@ -391,6 +397,14 @@ def roofline_leg(eng, step, steps, B, T, value, world):
         if "l2_hit_rate" in k:
             r["l2_hit_rate_pmc"] = k["l2_hit_rate"]
         r["mfma_busy_pct_pmc"] = k["mfma_busy_pct"]
+        if dom == "rx_sync" and "mfma_mops_f16_per_dispatch" in k:
+            f16 = 512.0 * k["mfma_mops_f16_per_dispatch"]
+            ach16 = f16 / (r["avg_launch_ms"] * 1e-3) / 1e12
+            r["f16_pipe"] = {"executed_f16_flop_per_launch": f16, "achieved": ach16, "peak": F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach16 / F16_PEAK_TFLOPS,
+                             "f64_flop_per_launch": 512.0 * k.get("mfma_mops_f64_per_dispatch", 0.0), "f32_flop_per_launch": 512.0 * k.get("mfma_mops_f32_per_dispatch", 0.0),
+                             "note": "issued matrix work of one launch (PMC pass of the profiled command: SQ_INSTS_VALU_MFMA_MOPS_F16 x 512) over this run's launch duration, against the dense binary16 peak"}
+        if k["mfma_busy_pct"] < 25.0 and r.get("hbm_frac_kernel", 1.0) < 0.1:
+            r["bound"] = "latency"
         r["counters_from"] = f"profiles/{tag}_pmc_summary.json (commit {pm.get('commit', '?')})"
         sq = pm.get("sq_breakdown", {}).get(RX_KERNEL_NAME)
         if sq:
@@ -429,14 +443,10 @@ def pipelined_roofline(r, engs, run_steps, n, dev):
     total = sum(b - a for a, b in iv)
     fl = r["executed_flop_per_launch"] * len(iv)
     ach = fl / (union * 1e-3) / 1e12
-    r["alone"] = {"avg_launch_ms": r["avg_launch_ms"], "achieved": r["achieved"], "frac": r["frac"], "note": "one launch with the chip to itself (the leg above)"}
+    r["alone"] = {"avg_launch_ms": r["avg_launch_ms"], "achieved": r["achieved"], "frac": r["frac"], "note": "one launch with the chip to itself: the headline (achieved, frac, avg_launch_ms) of this block"}
     r["pipelined"] = {"launches": len(iv), "avg_launch_ms_overlapped": total / max(len(iv), 1), "busy_union_ms_per_launch": union / max(len(iv), 1),
                       "mean_concurrency": total / union if union else 0.0, "achieved": ach, "frac": ach / F32_PEAK_TFLOPS,
-                      "note": "receiver launches of all engines in flight on one time axis (HIP events, rade_batch_profile_intervals); achieved = launches x executed FLOP per launch / time with at least one receiver launch running"}
-    # the line's (achieved, frac) describe the timed configuration; the single-launch figures stay beside them
-    r["achieved"], r["frac"] = ach, ach / F32_PEAK_TFLOPS
-    r["avg_launch_ms"] = union / max(len(iv), 1)
-    r["avg_launch_ms_note"] = "busy time of the receiver kernel per launch in the timed (pipelined) configuration; alone.avg_launch_ms = one launch by itself; pipelined.avg_launch_ms_overlapped = event duration of a launch sharing the chip"
+                      "note": "receiver launches of all engines in flight on one time axis (HIP events, rade_batch_profile_intervals); achieved = launches x executed FLOP per launch / time with at least one receiver launch running (the timed configuration; a sub-field since round 6: the headline is `alone`, which rocprofv3's per-kernel average reproduces)"}
 
 
 def two_per_cu_leg(r, B, T, n_mf, local, blob, feats, G, sigma, n_pre, n_post, steps=6):
@@ -636,7 +646,7 @@ def config2(T):
     c2 = time.perf_counter()
     out = {"metric": "vocoder-feature frames/sec (core enc + dec, single stream), model19_check3", "value": T / (t2 - t0), "unit": "frames/s", "n_gpus": 1,
            "steps": n_steps, "warmup": min(32, n_steps), "ms_per_step": 1e3 * (t2 - t0) / n_steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32", "data": "synthetic",
+           "dtype": DTYPE, "data": "synthetic",
            "config": {"workload": "model19_check3 rade_core_encoder + rade_core_decoder, single stream, one 40 ms step per call (configs[1])", "frames": T},
            "latency_ms": {"encoder_call": 1e3 * float(te.mean()), "decoder_call": 1e3 * float(td.mean()), "encoder_call_median": 1e3 * float(np.median(te)), "decoder_call_median": 1e3 * float(np.median(td)),
                           "encoder_call_max": 1e3 * float(te.max()), "decoder_call_max": 1e3 * float(td.max())},

@@ -223,14 +223,21 @@ def main():
     feats[:, 20::21] = -1.0                                                     # aux symbol (radae_txe.py:117)
     zin = (0.8 * rng.standard_normal((T, 80))).astype(np.float32)
     enc, dec = modelA.core_encoder_statefull, modelA.core_decoder_statefull
+    enc_m = enc.module if hasattr(enc, "module") else enc
+    assert enc_m.bottleneck == 1                                                  # RADAE's default, as export_rade_weights.py:211 builds it: z = tanh(z_dense(.))
     with torch.no_grad():
+        z_b1 = np.stack([enc(torch.tensor(feats[t].reshape(1, 4, 21))).numpy().reshape(80) for t in range(T)])
+        for g in (enc_m.gru1, enc_m.gru2, enc_m.gru3, enc_m.gru4, enc_m.gru5, enc_m.conv1, enc_m.conv2, enc_m.conv3, enc_m.conv4, enc_m.conv5):
+            g.reset()
+        enc_m.bottleneck = 3; modelA.core_encoder.module.bottleneck = 3           # model19_check3's setting (radae_txe.py:57-63): linear z (radae_base.py:281-284)
         z = np.stack([enc(torch.tensor(feats[t].reshape(1, 4, 21))).numpy().reshape(80) for t in range(T)])
         fo = np.stack([dec(torch.tensor(zin[t].reshape(1, 1, 80))).numpy().reshape(84) for t in range(T)])
         # the stateless modules over the whole sequence (CoreEncoder / CoreDecoder, radae_base.py:157-221, :291-356) as a cross-check of the stepping
         z_sl = modelA.core_encoder.module(torch.tensor(feats.reshape(1, 4 * T, 21))).numpy().reshape(T, 80)
         f_sl = modelA.core_decoder.module(torch.tensor(zin.reshape(1, T, 80))).numpy().reshape(T, 84)
     print(f"stateful vs stateless: enc {np.abs(z - z_sl).max():.2e} dec {np.abs(fo - f_sl).max():.2e}; |z| rms {np.sqrt((z**2).mean()):.3f} |f| rms {np.sqrt((fo**2).mean()):.3f}", file=sys.stderr)
-    fx["A/run/features"] = feats; fx["A/run/z"] = z.astype(np.float32)
+    assert np.abs(np.tanh(z) - z_b1).max() < 1e-6
+    fx["A/run/features"] = feats; fx["A/run/z"] = z.astype(np.float32); fx["A/run/z_bottleneck1"] = z_b1.astype(np.float32)
     fx["A/run/z_hat"] = zin; fx["A/run/features_out"] = fo.astype(np.float32)
     # ---- checkpoint B: generic floats -> digests of the reference-exported blob (the writer's byte-identity target) ----
     mB = dnnw_synth.synth_model(SEED_B, lossless=False)

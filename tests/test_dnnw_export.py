@@ -159,6 +159,16 @@ def test_writer_is_byte_identical_to_the_reference_export(fx, ckpt_a, tmp_path):
         dnnw.write_blob(z, str(tmp_path / "z.bin"))
 
 
+def test_oracle_core_on_the_exported_blob_vs_reference_modules(oracle, fx):
+    """The CPU oracle's core encoder / decoder on the reference-exported blob against the reference's float modules holding the same checkpoint."""
+    m = oracle.Model(BLOB_A)
+    e, e1, d = oracle.Encoder(m), oracle.Encoder(m), oracle.Decoder(m)
+    z = np.stack([e.step(f) for f in fx["A/run/features"]]); z1 = np.stack([e1.step(f, bottleneck=1) for f in fx["A/run/features"]])
+    fo = np.stack([d.step(v) for v in fx["A/run/z_hat"]])
+    for got, want in ((z, fx["A/run/z"]), (z1, fx["A/run/z_bottleneck1"]), (fo, fx["A/run/features_out"])):
+        assert np.sqrt(np.mean((got - want) ** 2)) < 2e-6 and np.abs(got - want).max() < 2e-5
+
+
 # ------------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_core_encoder_decoder_on_the_exported_blob_vs_reference_modules(fx):
@@ -172,7 +182,10 @@ def test_core_encoder_decoder_on_the_exported_blob_vs_reference_modules(fx):
     rms = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)))
     enc, dec = CoreEncoder(BLOB_A, 84), CoreDecoder(BLOB_A, 84)
     z = np.stack([enc.step(f) for f in feats]); fo = np.stack([dec.step(v) for v in z_hat])
+    enc.reset()
+    z1 = np.stack([enc.step(f, bottleneck=1) for f in feats])                              # RADAE's default bottleneck: z = tanh(.) (rade_enc.c:110-113)
     enc.close(); dec.close()
+    assert rms(z1, fx["A/run/z_bottleneck1"]) < 1e-5
     assert rms(z, z_ref) < 1e-5 and np.abs(z - z_ref).max() < 1e-4, (rms(z, z_ref), np.abs(z - z_ref).max())
     assert rms(fo, f_ref) < 1e-5 and np.abs(fo - f_ref).max() < 1e-4, (rms(fo, f_ref), np.abs(fo - f_ref).max())
     assert rms(z, 0 * z) > 0.1 and rms(fo, 0 * fo) > 0.1
