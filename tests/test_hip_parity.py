@@ -239,6 +239,32 @@ def test_rx_trace_golden(Engine, torch_dev, golden, name, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["slipdrops", "dfs8001", "eoo_mpp"])
+def test_rx_trace_edge_cases(Engine, torch_dev, golden, name):
+    """The reference's remaining streaming ctests as golden traces (oracle/gen_golden_r6.py), whole trace bit-exact in one receiver launch:
+    slipdrops = radae_rx_slip_plus_drops (CMakeLists.txt:397-407): 61 s of a real-valued int16 signal at 8020 Hz with three drop-outs; sync is lost and regained, 1120-sample
+    calls all along, the last state is sync.  dfs8001 = radae_rx_dfs (:374-382).  eoo_mpp = radae_eoo_data_mpp (:595-607): the data bits of five end-of-over
+    frames through MPP at the ctest's SNR, decisions equal to the reference's, one over below 5 % BER."""
+    import torch
+    from test_oracle_golden import check_edge_trace, edge_case_input
+    g = golden("rxtrace_" + name)
+    x = edge_case_input(g)
+    eng = Engine(1, max_tx_mf=1, rx_trace_calls=len(g["ret"]) + 8)
+    feats, st, eoo = eng.rx(torch.tensor(x[None], device=torch_dev))
+    d = eng.rx_trace(0)
+    nv = st[0].n_valid
+    d["features_out"] = feats.cpu().numpy()[0, :nv]
+    assert st[0].n_calls == len(g["ret"]) and st[0].state == g["state_after"][-1]
+    check_edge_trace(d, g)
+    if name == "slipdrops":
+        assert st[0].state == 2 and st[0].sync == 1                      # the ctest's `grep 'state: sync'`
+    if name == "eoo_mpp":
+        ber = np.array([np.mean(e * g["tx_bits"] < 0) for e in d["eoo_out"]])
+        assert np.allclose(ber, g["eoo_ber"]) and ber.min() < 0.05 and np.abs(d["eoo_out"] - g["eoo_out"]).max() < 1e-4 * np.abs(g["eoo_out"]).max() + 1e-4
+        assert np.array_equal(eoo.cpu().numpy()[0] > 0, g["eoo_out"][-1] > 0)
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["slip_plus", "slip_minus", "mpp"])
 def test_bpf_prepass_matches_oracle_filter(Engine, torch_dev, golden, oracle, name):
     """The band-pass filter runs ahead of the receiver kernel for a whole invocation (k_rx_bpf); a stream whose nin changes inside an invocation
