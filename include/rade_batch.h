@@ -37,11 +37,17 @@ typedef struct rade_batch rade_batch;
  * (radae_txe.py:74-83, :130-132, :141-143; ctest radae_tx_basic).  Off by default, as in the reference. */
 #define RADE_BATCH_TX_BPF 0x400
 
+/* Receiver without the core decoder: `radae_rxe.py --bypass_dec` (radae_rxe.py:67, :113-123, :300-302, :315), the mode the reference's rade_api.c drives when an
+ * external C decoder follows (rade_api.c:491-513).  Every valid modem frame appends its 240 equalised latents (3 x 80, what receiver_one returned) to
+ * features_out instead of 432 feature floats -- rows are 240 floats, feat_stride / 240 is the capacity -- and, as in the reference, the aux-bit (UW) errors are
+ * never summed in this mode (sum_uw_errors sits behind the decoder), so a UW failure cannot end sync; everything else of do_radae_rx is unchanged. */
+#define RADE_BATCH_BYPASS_DEC 0x800
+
 typedef struct {
     int n_streams;        /* B */
     int max_tx_mf;        /* largest n_mf a single rade_batch_tx call may carry */
     int device;           /* HIP device ordinal */
-    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm); RADE_BATCH_TX_BPF */
+    int flags;            /* RADE_FOFF_TEST from rade_api.h is honoured; RADE_BATCH_BOTTLENECK1: z = tanh(.) (model05, bbfm); RADE_BATCH_TX_BPF; RADE_BATCH_BYPASS_DEC */
     int rx_trace_calls;   /* >0: keep a per-call trace of this many do_radae_rx calls per stream (tests) */
     float disable_unsync; /* test mode of radae_rxe.py --disable_unsync (:277-281, :337): after this many seconds in sync the receiver no longer
                            * drops back to search (pilot loss, end-of-over, UW failure); 0 = normal operation */
@@ -61,6 +67,9 @@ int rade_batch_n_streams(const rade_batch *h);
 int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride,
                   float *z_out_dev, void *stream);
 /* bits_host: [B][180] +-1 floats, or NULL to restore the default (all-zero data symbols) EOO frame */
+/* `radae_txe.py --bypass_enc` (radae_txe.py:124-126; rade_api.c with RADE_USE_C_ENCODER): latents from an external core encoder, z_dev [B][3 n_mf][80] float32,
+ * straight into the OFDM modulator (and the Tx band-pass filter when the engine has it).  The engine's own encoder state is not touched.  Returns n_mf * 960. */
+int rade_batch_tx_latents(rade_batch *h, const float *z_dev, int n_mf, void *iq_out_dev, long iq_stride, void *stream);
 int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host);
 /* writes the 1152-sample end-of-over frame of every stream; returns 1152 */
 int rade_batch_tx_eoo(rade_batch *h, void *iq_out_dev, long iq_stride, void *stream);
@@ -117,6 +126,12 @@ int rade_batch_tx_channel(rade_batch *h, const float *features_dev, int n_mf, vo
  * G_out_dev     : [B][n_out][2] complex64, the layout rade_channel_params.G_dev takes.  Returns n_out or <0. */
 int rade_batch_multipath_gen(rade_batch *h, const float *fir_taps_host, int n_taps, int low_ratio, int n_out,
                              const void *noise_low_dev, unsigned long long seed, void *G_out_dev, void *stream);
+/* The rate-Rs channel matrix multipath_samples.m:33-40 derives from the same Doppler samples (what `multipath_samples("lmr60", 8000, 2000, 1, ...)` writes for the
+ * BBFM model, BBFM.md:37, and the `h_*.f32` files of the rate-Rs RADE model): H[b][t][c] = G1[t M] + G2[t M] exp(-j 2 pi c delay Rs), M = Fs / Rs = fs_over_rs,
+ * as magnitudes (float32 [B][n_sym][Nc], the default file form) or complex (want_complex: [B][n_sym][Nc][2]).  G_dev [B][n_g][2] complex64 as
+ * rade_batch_multipath_gen leaves it (hf_gain included), n_g > (n_sym - 1) M.  Returns n_sym or <0. */
+int rade_batch_multipath_h(rade_batch *h, const void *G_dev, int n_g, int fs_over_rs, int n_sym, int Nc, float delay_s, float Rs, int want_complex,
+                           float *H_out_dev, void *stream);
 float rade_sigma_from_EbNodB(float EbNodB);
 
 /* ---- receive --------------------------------------------------------------------------------

@@ -3,7 +3,7 @@
 Restates (numpy only, no Octave/scipy dependency at run time)
   * `/root/reference/doppler_spread.m:7-50`  -- Gaussian-PSD filtered complex noise at a low
     sample rate, linearly interpolated up to Fs,
-  * `/root/reference/multipath_samples.m:10-31` -- channel presets (mpg/mpp/mpd) and the
+  * `/root/reference/multipath_samples.m:10-31` -- channel presets (mpg/mpp/mpd/lmr60), the rate-Rs H matrix (:33-40) and the
     `hf_gain = 1/sqrt(var(G1)+var(G2))` normalisation,
 and the synthetic 20-dim vocoder-feature generator fixed in SURVEY.md section 8(d).
 
@@ -16,10 +16,13 @@ import math
 
 import numpy as np
 
-PRESETS = {  # multipath_samples.m:10-16  (doppler spread Hz, path delay s)
+PRESETS = {  # multipath_samples.m:10-21  (doppler spread Hz, path delay s)
     "mpg": (0.1, 0.5e-3),
     "mpp": (1.0, 2.0e-3),
     "mpd": (2.0, 4.0e-3),
+    # land mobile radio, 60 km/h at 450 MHz (multipath_samples.m:17-21): fd = 450e6 * (60e3 / 3600 / 3e8) = 25 Hz, spread = 2 fd; BBFM.md:37 makes the
+    # BBFM model's |H| file from it (Rs = 2000, Nc = 1): multipath_h() below
+    "lmr60": (2.0 * 450e6 * (60 * 1e3 / 3600 / 3e8), 200e-6),
 }
 
 
@@ -84,6 +87,18 @@ def multipath_g(channel: str, fs: int, nsam: int, seed: int) -> np.ndarray:
     g2 = doppler_spread(spread, fs, nsam, rng)
     hf_gain = 1.0 / math.sqrt(np.var(g1) + np.var(g2))
     return (hf_gain * np.stack([g1, g2], axis=1)).astype(np.complex64)
+
+
+def multipath_h(channel: str, fs: int, rs: int, nc: int, nsym: int, seed: int, complex_: bool = False) -> np.ndarray:
+    """The rate-Rs channel matrix of `multipath_samples.m:25-40, :73-80` (what it writes to H_fn): H[t][c] = hf_gain (G1[t M] + G2[t M] exp(-j 2 pi c d Rs)),
+    M = Fs / Rs, (nsym, nc); magnitudes unless complex_ (the script's H_complex).  `multipath_samples("lmr60", 8000, 2000, 1, 10, "h_lmr60.f32")` (BBFM.md:37)
+    = multipath_h("lmr60", 8000, 2000, 1, 20000, seed)."""
+    m = fs // rs
+    assert m * rs == fs
+    g = multipath_g(channel, fs, (nsym - 1) * m + 1, seed).astype(np.complex128)
+    d = PRESETS[channel][1]
+    h = g[::m, 0][:nsym, None] + g[::m, 1][:nsym, None] * np.exp(-2j * np.pi * np.arange(nc)[None, :] * d * rs)
+    return h.astype(np.complex64) if complex_ else np.abs(h).astype(np.float32)
 
 
 def synth_features(seed: int, nframes: int, stride: int = 36) -> np.ndarray:

@@ -191,7 +191,9 @@ typedef struct {
 } rd_chan_args;
 int rd_launch_channel(const rd_chan_args *a, rd_stream_t s);
 /* Doppler-spread generator: taps_dev [n_taps] f32, noise optional, G [B][n_out][2] c64 */
-int rd_launch_multipath_gen(const float *taps_dev, int n_taps, int low_ratio, int n_out, const void *noise_low, unsigned long long seed, void *G, int B, rd_stream_t s);
+int rd_launch_multipath_gen(const float *taps_dev, int n_taps, int low_ratio, int n_out, const void *noise_low, unsigned long long seed, void *G, void *ybuf, int B, rd_stream_t s);
+int rd_multipath_gen_needs_scratch(int low_ratio, int n_out);
+int rd_launch_multipath_h(const void *G, int n_g, int M, int n_sym, int Nc, float dRs, int want_complex, float *H, int B, rd_stream_t s);
 
 /* CoreDecoderStatefull.forward (radae_base.py:388-430) for the pending rows of one stream, run inside the receiver
  * kernel by the stream's own workgroup (rx_decode_pending -> ds_layers): buffers and weights of that stage. */
@@ -224,6 +226,7 @@ typedef struct {
     rd_decs_args dec;                                    /* the decoder runs inside the stream's workgroup (rx_decode_pending) */
     float *features_out; long feat_stride;               /* [B][cap][432] */
     int feat_cap;                                        /* valid modem frames features_out holds per stream: a stream stops making calls once it has produced that many */
+    int bypass_dec;                                      /* radae_rxe.py --bypass_dec (:300-302, :315): rows of features_out are the 240 latents of a valid modem frame, no decoder, no UW accounting */
     const unsigned short *corr16;                        /* rd_corr16_table_fill(): [5][10][2][64][8] binary16 (the one-stage correlator: -DRX2_ONE_STAGE builds) */
     const unsigned short *corrq16, *corra16;             /* rd_corrq16_table_fill() [2][10][2][64][8] / rd_corra16_table_fill() [5][2][64][8]: the two-stage pilot correlator */
     float *zrows;                                        /* [B][dec_rows][80] */

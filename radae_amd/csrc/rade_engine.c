@@ -89,6 +89,7 @@ struct rade_batch {
     unsigned short *enc_xf; int enc_nq, enc_unfused, enc_seq_taps, enc_no_pair;
     int enc_hist_frag;                   /* the history tile of enc_xf holds what enc_x's two float32 history rows hold (set by a fragment pass, cleared by a reset or a float32-row pass) */   /* the concat buffer as matrix-core operand fragments (rade_enc.hip: [B][enc_nq][RD_EF_TILE] binary16), engines with enough rows for the batched GEMMs only */
     /* optional Tx band-pass filter + clip (RADE_BATCH_TX_BPF; radae_txe.py:74-83): filter state per stream, its initial value, the modulator's raw output, block phases */
+    int bypass_dec;                          /* RADE_BATCH_BYPASS_DEC */
     rd_bpf_state *tx_bpf, *tx_bpf_init; void *tx_raw; float *tx_chain; float *eoo_filt;   /* eoo_filt [B][Neoo] c64: the end-of-over frame as transmitted (filtered + clipped) for the channel's with_eoo */
     void *chan_scratch; void *chan_mp;        /* chan_mp [B][max_tx_mf * 960] c64: multipath output of the fused modulator (rade_batch_tx_channel), allocated on first use */
     /* receive side */
@@ -337,6 +338,7 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->enc_z = dev_zeros(sizeof(float) * B * T * RD_LATENT);
     h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
     h->eoo_bits = dev_zeros(sizeof(float) * B * RD_NEOOBITS);
+    h->bypass_dec = (cfg->flags & RADE_BATCH_BYPASS_DEC) != 0;
     if (cfg->flags & RADE_BATCH_TX_BPF) {
         const long nraw = (long)(cfg->max_tx_mf > 2 ? cfg->max_tx_mf : 2) * RD_NMF;          /* (>= the 1152-sample end-of-over frame) */
         rd_bpf_state *init = calloc(B, sizeof *init);
@@ -650,6 +652,19 @@ int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_o
     return e ? -1 : n_mf * RD_NMF;
 }
 
+/* radae_txe.py --bypass_enc (:124-126): latents in, the modulator (+ Tx band-pass filter) as rade_batch_tx runs it */
+int rade_batch_tx_latents(rade_batch *h, const float *z_dev, int n_mf, void *iq_out_dev, long iq_stride, void *stream)
+{
+    ON_DEV(h);
+    if (!h || !z_dev || !iq_out_dev || n_mf <= 0 || n_mf > h->max_tx_mf) return -1;
+    const int B = h->B;
+    int e = 0;
+    void *mod_out = h->tx_bpf ? h->tx_raw : iq_out_dev; const long mod_stride = h->tx_bpf ? (long)(h->max_tx_mf > 2 ? h->max_tx_mf : 2) * RD_NMF : iq_stride;
+    PROF_BEGIN(h, stream); e |= rd_launch_ofdm_mod(h->d_tab, z_dev, mod_out, mod_stride, B, n_mf, stream); PROF_END(h, stream, RADE_PROF_MOD, 8.0 * B * n_mf * 5 * 30 * 160);
+    if (h->tx_bpf) e |= tx_bpf_pass(h, n_mf * RD_NMF, RD_NMF, iq_out_dev, iq_stride, stream);
+    return e ? -1 : n_mf * RD_NMF;
+}
+
 /* ---- core encoder / decoder alone (the rade_core_encoder / rade_core_decoder level, src/rade_core.h:42-46) ---- */
 int rade_batch_encode(rade_batch *h, const float *features_dev, int n_steps, float *z_out_dev, void *stream)
 {
@@ -744,10 +759,24 @@ int rade_batch_multipath_gen(rade_batch *h, const float *fir_taps_host, int n_ta
     if (!h || !fir_taps_host || n_taps <= 0 || n_taps > 1024 || !G_out_dev) return -1;
     float *taps = dev_upload(fir_taps_host, sizeof(float) * n_taps);
     if (!taps) return -1;
-    const int rc = rd_launch_multipath_gen(taps, n_taps, low_ratio, n_out, noise_low_dev, seed, G_out_dev, h->B, stream);
+    void *ybuf = NULL;                                  /* more low-rate points than the kernel keeps in LDS (lmr60: Fs / 16): they live in HBM for the call */
+    if (rd_multipath_gen_needs_scratch(low_ratio, n_out)) {
+        const size_t n_low = (size_t)(n_out + low_ratio - 1) / low_ratio;
+        if (hipMalloc(&ybuf, sizeof(double) * 2 * 2 * n_low * h->B) != hipSuccess) { hipFree(taps); return -1; }
+    }
+    const int rc = rd_launch_multipath_gen(taps, n_taps, low_ratio, n_out, noise_low_dev, seed, G_out_dev, ybuf, h->B, stream);
     hipStreamSynchronize((hipStream_t)stream);          /* the tap buffer is released right away */
     hipFree(taps);
+    if (ybuf) hipFree(ybuf);
     return rc ? -1 : n_out;
+}
+
+/* multipath_samples.m:33-40: the rate-Rs channel matrix from rate-Fs Doppler samples */
+int rade_batch_multipath_h(rade_batch *h, const void *G_dev, int n_g, int fs_over_rs, int n_sym, int Nc, float delay_s, float Rs, int want_complex, float *H_out_dev, void *stream)
+{
+    ON_DEV(h);
+    if (!h || !G_dev || !H_out_dev) return -1;
+    return rd_launch_multipath_h(G_dev, n_g, fs_over_rs, n_sym, Nc, delay_s * Rs, want_complex, H_out_dev, h->B, stream) ? -1 : n_sym;
 }
 
 /* ---- receive ----------------------------------------------------------------------------------- */
@@ -836,7 +865,8 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
                   float *features_out_dev, long feat_stride, float *eoo_out_dev, rade_rx_status *status_host, void *stream)
 {
     ON_DEV(h);
-    if (!h || !n_avail_host || max_calls <= 0 || h->feat_in != 84 || !features_out_dev || feat_stride < RD_FEAT_MF) return -1;
+    const int row_floats = h && h->bypass_dec ? RD_ZMF : RD_FEAT_MF;       /* RADE_BATCH_BYPASS_DEC: 240 latents per valid modem frame instead of 432 feature floats */
+    if (!h || !n_avail_host || max_calls <= 0 || h->feat_in != 84 || !features_out_dev || feat_stride < row_floats) return -1;
     const int B = h->B;
     hipStream_t st = (hipStream_t)stream;
     int *hs = h->h_small;
@@ -879,7 +909,8 @@ int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *
     sa.corr16 = h->corr16; sa.corrq16 = h->corrq16; sa.corra16 = h->corra16; sa.zrows = h->zrows; sa.status = h->rx_status; sa.eoo_out = eoo_out_dev; sa.dtcache = h->dtcache;
     sa.trace = h->trace; sa.trace_z = h->trace_z; sa.trace_cap = h->trace_cap; sa.progress = h->rx_progress; sa.wg_cycles = h->wg_cycles; sa.B = B; sa.vm = h->vm; sa.wfwd16 = h->wfwd16; sa.variant = h->rx_census << 8; sa.lds_bytes = h->rx_lds;
     fill_dec_args(h, &sa.dec); sa.features_out = features_out_dev; sa.feat_stride = feat_stride;
-    sa.feat_cap = (int)(feat_stride / RD_FEAT_MF);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
+    sa.bypass_dec = h->bypass_dec;
+    sa.feat_cap = (int)(feat_stride / row_floats);      /* the kernel never writes past the caller's rows: a stream pauses once its buffer is full (status.consumed tells how far it got) */
     /* one launch normally takes every stream through all of its samples (calls, decoder, output); the loop only
      * continues when a stream ran into the per-launch call limit */
     for (;;) {

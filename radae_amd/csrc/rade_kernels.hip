@@ -926,13 +926,16 @@ __global__ __launch_bounds__(256) void k_chan_apply(rd_chan_args a, const float 
 // Watterson / Doppler-spread samples (doppler_spread.m:7-50, multipath_samples.m:25-31): one workgroup per stream.
 // Low-rate noise -> FIR (double) into LDS, then two sweeps over the Fs-rate interpolation: variance, scaled write.
 #define DG_MAXLOW 2048
+// ybuf: [B][2][n_low] double2 in HBM for sequences of more than DG_MAXLOW low-rate points (lmr60: 500 low-rate points per second), else NULL (LDS)
 __global__ __launch_bounds__(256) void k_multipath_gen(const float *taps, int n_taps, int low_ratio, int n_out, const float2 *noise_low,
-                                                       unsigned long long seed, float2 *G)
+                                                       unsigned long long seed, float2 *G, double2 *ybuf)
 {
-    __shared__ double2 y[2][DG_MAXLOW];
+    __shared__ double2 ylds[2][DG_MAXLOW];
     __shared__ double red[256][6];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n_low = max((n_out + low_ratio - 1) / low_ratio, 2), n_x = n_low + n_taps;
+    double2 *y = ybuf ? ybuf + (size_t)b * 2 * n_low : &ylds[0][0];
+    const int ys = ybuf ? n_low : DG_MAXLOW;
     for (int idx = tid; idx < 2 * n_low; idx += 256) {
         const int p = idx / n_low, i = idx - p * n_low;
         double ar = 0.0, ai = 0.0;
@@ -943,14 +946,15 @@ __global__ __launch_bounds__(256) void k_multipath_gen(const float *taps, int n_
             else { uint32_t r[4]; philox4x32((uint32_t)xi, (uint32_t)(b * 2 + p), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r); x = gauss_pair(r[0], r[1]); }
             ar += (double)taps[k] * x.x; ai += (double)taps[k] * x.y;
         }
-        y[p][i] = make_double2(ar, ai);
+        y[p * ys + i] = make_double2(ar, ai);
     }
+    __threadfence_block();
     __syncthreads();
     auto interp = [&](int p, int n) {                               // linear interpolation, extrapolating past the last low-rate point
         const double pos = (double)n / (double)low_ratio;
         const int i0 = min((int)pos, n_low - 2);
         const double fr = pos - (double)i0;
-        const double2 a0 = y[p][i0], a1 = y[p][i0 + 1];
+        const double2 a0 = y[p * ys + i0], a1 = y[p * ys + i0 + 1];
         return make_double2(a0.x + (a1.x - a0.x) * fr, a0.y + (a1.y - a0.y) * fr);
     };
     double s[6] = { 0, 0, 0, 0, 0, 0 };                             // per path: sum re, sum im, sum |g|^2
@@ -969,11 +973,37 @@ __global__ __launch_bounds__(256) void k_multipath_gen(const float *taps, int n_
         Gb[2 * n + 1] = make_float2((float)(hf_gain * g2.x), (float)(hf_gain * g2.y));
     }
 }
-extern "C" int rd_launch_multipath_gen(const float *taps_dev, int n_taps, int low_ratio, int n_out, const void *noise_low, unsigned long long seed, void *G, int B, rd_stream_t s)
+extern "C" int rd_multipath_gen_needs_scratch(int low_ratio, int n_out) { return low_ratio >= 1 && (n_out + low_ratio - 1) / low_ratio > DG_MAXLOW; }
+extern "C" int rd_launch_multipath_gen(const float *taps_dev, int n_taps, int low_ratio, int n_out, const void *noise_low, unsigned long long seed, void *G, void *ybuf, int B, rd_stream_t s)
 {
     if (B <= 0 || n_out <= 0) return 0;
-    if (low_ratio < 1 || n_taps < 1 || (n_out + low_ratio - 1) / low_ratio > DG_MAXLOW) return -1;
-    hipLaunchKernelGGL(k_multipath_gen, dim3(B), dim3(256), 0, (hipStream_t)s, taps_dev, n_taps, low_ratio, n_out, (const float2 *)noise_low, seed, (float2 *)G);
+    if (low_ratio < 1 || n_taps < 1 || (!ybuf && (n_out + low_ratio - 1) / low_ratio > DG_MAXLOW)) return -1;
+    hipLaunchKernelGGL(k_multipath_gen, dim3(B), dim3(256), 0, (hipStream_t)s, taps_dev, n_taps, low_ratio, n_out, (const float2 *)noise_low, seed, (float2 *)G, (double2 *)ybuf);
+    return (int)hipGetLastError();
+}
+
+// Rate-Rs channel matrix from the rate-Fs Doppler samples (multipath_samples.m:33-40, :73-80): H[t][c] = G1[t M] + G2[t M] exp(-j 2 pi c d Rs), M = Fs / Rs
+// (hf_gain is already in G); magnitudes (the default `.f32` form, what BBFM.forward and the rate-Rs model take) or complex.
+__global__ void k_multipath_h(const float2 *G, int n_g, int M, int n_sym, int Nc, float dRs, int want_complex, float *H)
+{
+    const int b = blockIdx.y;
+    const float2 *Gb = G + (size_t)b * n_g * 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)n_sym * Nc; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / Nc), c = (int)(i - (long)t * Nc);
+        const float2 g1 = Gb[2 * (size_t)t * M], g2 = Gb[2 * (size_t)t * M + 1];
+        float sn, cs;
+        sincosf(-6.283185307179586f * (float)c * dRs, &sn, &cs);
+        const float hr = g1.x + g2.x * cs - g2.y * sn, hi = g1.y + g2.x * sn + g2.y * cs;
+        if (want_complex) { H[2 * ((size_t)b * n_sym * Nc + i)] = hr; H[2 * ((size_t)b * n_sym * Nc + i) + 1] = hi; }
+        else H[(size_t)b * n_sym * Nc + i] = sqrtf(hr * hr + hi * hi);
+    }
+}
+extern "C" int rd_launch_multipath_h(const void *G, int n_g, int M, int n_sym, int Nc, float dRs, int want_complex, float *H, int B, rd_stream_t s)
+{
+    if (B <= 0 || n_sym <= 0) return 0;
+    if (M < 1 || Nc < 1 || (long)(n_sym - 1) * M >= n_g) return -1;
+    int gx = (int)(((long)n_sym * Nc + 255) / 256); if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_multipath_h, dim3(gx, B), dim3(256), 0, (hipStream_t)s, (const float2 *)G, n_g, M, n_sym, Nc, dRs, want_complex, H);
     return (int)hipGetLastError();
 }
 

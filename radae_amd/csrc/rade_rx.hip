@@ -1083,6 +1083,21 @@ __device__ __forceinline__ void rx2_decode_pending(RxShared2 *sh, const rd_sync_
     PH2(19);
 }
 
+// radae_rxe.py --bypass_dec (:300-302, :315; the mode rade_api.c drives with the external C decoder): the pending z_hat rows leave as they are -- 240 floats per
+// valid modem frame -- and the aux-bit (UW) errors are never summed, so uw_fail cannot occur (sum_uw_errors is only called behind the decoder, :303-312)
+__device__ __forceinline__ void rx2_bypass_pending(RxShared2 *sh, const rd_sync_args &a, int b)
+{
+    RxScalars *S = &sh->S;
+    const int tid = rx_tid();
+    const int Tb = S->n_rows;
+    const float *z = a.dec.z + (size_t)b * a.dec.z_sb;
+    float *out = a.features_out + (size_t)b * a.feat_stride + (size_t)S->out_base * RD_ZMF;
+    for (int i = tid; i < Tb * RD_LATENT; i += NT2) out[i] = z[i];
+    __syncthreads();
+    if (tid == 0) { S->out_base += Tb / 3; S->n_rows = 0; S->uw_from_row = 0; S->pending_valid = 0; S->batch_call0 = S->n_calls; S->need_decode = 0; }
+    __syncthreads();
+}
+
 // check_pilots' row refreshes of one modem frame, NRT tiles of 16 row draws per wavefront, by the two-stage correlator (rx2_detect_q's algebra): the three tiles of 16 row draws against the
 // moment table (A fragments straight from L2, two k-steps ahead: 40 KB per call and wavefront instead of 60 + 40 over the two wavefronts a frame had), the moments
 // expanded to the 40 frequencies, |Dt| summed over them in the wavefront -> rowsum1 / rowsum2 directly (rounds 3-4: partial sums of two wavefronts through a table and
@@ -1373,7 +1388,7 @@ __global__ __launch_bounds__(NT2, RX2_WG_PER_CU) void k_rx_sync2(rd_sync_args a)
             tid = rx2_tid(wv);
         }
         PH2(1);
-        if (S->need_decode) { rx2_decode_pending(sh, a, b); PH2(2); }
+        if (S->need_decode) { if (a.bypass_dec) rx2_bypass_pending(sh, a, b); else rx2_decode_pending(sh, a, b); PH2(2); }
         if (!S->go) break;
         const int nin = S->nin, state = S->state;
         if (tid == 0 && state != ST_SYNC) S->tab_ok = 0;

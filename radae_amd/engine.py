@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("RADE_LIBRADEHIP") or os.path.join(_HERE, "libradehip.
 DEFAULT_BLOB = os.path.join(os.path.dirname(_HERE), "weights", "model19_check3.bin")
 
 NMF, NEOO, NIN_MAX, FEAT_MF, NEOO_BITS, ZMF = 960, 1152, 1120, 432, 180, 240
+BOTTLENECK1, TX_BPF, BYPASS_DEC = 0x100, 0x400, 0x800          # include/rade_batch.h flags
 
 
 class BatchConfig(C.Structure):
@@ -58,12 +59,14 @@ def load_library() -> C.CDLL:
     L.rade_batch_close.argtypes = [vp]
     L.rade_batch_n_streams.argtypes = [vp]
     L.rade_batch_tx.argtypes = [vp, vp, C.c_int, vp, C.c_long, vp, vp]
+    L.rade_batch_tx_latents.argtypes = [vp, vp, C.c_int, vp, C.c_long, vp]
     L.rade_batch_tx_channel.argtypes = [vp, vp, C.c_int, vp, C.c_long, vp, C.c_long, vp, vp]
     L.rade_batch_tx_set_eoo_bits.argtypes = [vp, vp]
     L.rade_batch_tx_eoo.argtypes = [vp, vp, C.c_long, vp]
     L.rade_batch_tx_reset.argtypes = [vp]
     L.rade_batch_channel.argtypes = [vp, vp, C.c_long, vp, C.c_long, C.POINTER(ChannelParams), vp]
     L.rade_batch_multipath_gen.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, vp, C.c_ulonglong, vp, vp]
+    L.rade_batch_multipath_h.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp]
     L.rade_sigma_from_EbNodB.restype = C.c_float; L.rade_sigma_from_EbNodB.argtypes = [C.c_float]
     L.rade_batch_rx.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_int), C.c_int, vp, C.c_long, vp, C.POINTER(RxStatus), vp]
     L.rade_batch_rx_reset.argtypes = [vp]
@@ -92,8 +95,8 @@ EXPORTED_SYMBOLS = [
     "rade_n_features_in_out", "rade_n_eoo_bits", "rade_tx", "rade_tx_set_eoo_bits", "rade_tx_eoo", "rade_nin", "rade_rx", "rade_sync",
     "rade_freq_offset", "rade_snrdB_3k_est",
     # include/rade_batch.h
-    "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_set_eoo_bits",
-    "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_tx_channel", "rade_batch_multipath_gen", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
+    "rade_batch_open", "rade_batch_open_mem", "rade_batch_close", "rade_batch_n_streams", "rade_batch_tx", "rade_batch_tx_latents", "rade_batch_tx_set_eoo_bits",
+    "rade_batch_tx_eoo", "rade_batch_tx_reset", "rade_batch_channel", "rade_batch_tx_channel", "rade_batch_multipath_gen", "rade_batch_multipath_h", "rade_sigma_from_EbNodB", "rade_batch_rx", "rade_batch_rx_reset",
     "rade_batch_rx_set_lcg", "rade_batch_rx_get_trace", "rade_batch_reset", "rade_batch_profile", "rade_batch_profile_get", "rade_batch_profile_ref", "rade_batch_profile_intervals",
     "rade_batch_encode", "rade_batch_decode", "rade_batch_channel_symbol",
     "rade_batch_rx_stream_cycles", "rade_batch_rx_filtered", "rade_host_cpu_quota", "rade_sync_policy", "rade_batch_sync_counts",
@@ -123,6 +126,7 @@ class BatchEngine:
         self.B = n_streams
         self.device = torch.device("cuda", device)
         self.trace_calls = rx_trace_calls
+        self.rx_row_floats = ZMF if flags & BYPASS_DEC else FEAT_MF      # RADE_BATCH_BYPASS_DEC: 240 latents per valid modem frame instead of 432 feature floats
         cfg = BatchConfig(n_streams, max_tx_mf, device, flags, rx_trace_calls, disable_unsync)
         if blob_bytes is not None:
             buf = C.create_string_buffer(blob_bytes, len(blob_bytes))
@@ -194,6 +198,21 @@ class BatchEngine:
                 z[:, done * 3:(done + k) * 3] = zc
             done += k
         return (iq, z) if want_z else iq
+
+    def tx_latents(self, z):
+        """`radae_txe.py --bypass_enc` (radae_txe.py:124-126): z cuda float32 [B, n_mf*3, 80] from an external core encoder -> iq complex64 [B, n_mf*960]."""
+        import torch
+        assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and z.shape[0] == self.B and z.shape[2] == 80 and z.shape[1] % 3 == 0
+        n_mf = z.shape[1] // 3
+        iq = torch.empty((self.B, n_mf * NMF), dtype=torch.complex64, device=z.device)
+        done = 0
+        while done < n_mf:
+            k = min(self.max_tx_mf, n_mf - done)
+            zc = z[:, done * 3:(done + k) * 3, :].contiguous()
+            if self.lib.rade_batch_tx_latents(self.h, zc.data_ptr(), k, iq.data_ptr() + done * NMF * 8, n_mf * NMF, _stream_ptr()) != k * NMF:
+                raise RuntimeError("rade_batch_tx_latents failed")
+            done += k
+        return iq
 
     def tx_reset(self):
         self.lib.rade_batch_tx_reset(self.h)
@@ -311,6 +330,20 @@ class BatchEngine:
             raise RuntimeError("rade_batch_multipath_gen failed")
         return G
 
+    def multipath_h_gen(self, channel: str, n_sym: int, rs: int = 2000, nc: int = 1, fs: int = 8000, seed: int = 1, noise_low=None, complex_: bool = False):
+        """multipath_samples.m's H output generated on the device: |H| float32 [B, n_sym, nc] (complex64 with complex_) at symbol rate rs from the preset's
+        Doppler process at fs (BBFM.md:37: multipath_h_gen("lmr60", 20000) is `multipath_samples("lmr60", 8000, 2000, 1, 10, ...)` per stream)."""
+        import torch
+        from .channel_tools import PRESETS
+        m = fs // rs
+        assert m * rs == fs
+        n_g = (n_sym - 1) * m + 1
+        G = self.multipath_gen(channel, n_g, seed=seed, noise_low=noise_low, fs=fs)
+        H = torch.empty((self.B, n_sym, nc, 2) if complex_ else (self.B, n_sym, nc), dtype=torch.float32, device=self.device)
+        if self.lib.rade_batch_multipath_h(self.h, G.data_ptr(), n_g, m, n_sym, nc, PRESETS[channel][1], float(rs), int(complex_), H.data_ptr(), _stream_ptr()) != n_sym:
+            raise RuntimeError("rade_batch_multipath_h failed")
+        return torch.view_as_complex(H) if complex_ else H
+
     # ---- receive ----------------------------------------------------------------------------
     def rx_reset(self, lcg_seeds: Optional[Sequence[int]] = None):
         if lcg_seeds is None:
@@ -321,7 +354,7 @@ class BatchEngine:
 
     def rx(self, rx, n_avail=None, max_calls: int = 1 << 20, features_out=None, eoo_out=None):
         """rx complex64 [B, N] holding each stream's not-yet-consumed samples.  Returns
-        (features [B, cap, 432], status list[RxStatus], eoo [B, 180]).  features_out / eoo_out: caller-owned device buffers (as a C host passes
+        (features [B, cap, 432] -- [B, cap, 240] latents for an engine opened with BYPASS_DEC --, status list[RxStatus], eoo [B, 180]).  features_out / eoo_out: caller-owned device buffers (as a C host passes
         them: rows beyond status.n_valid, and the EOO bits of a stream without status.has_eoo, keep whatever they held); without them fresh zeroed
         ones are allocated per call."""
         import torch
@@ -330,16 +363,16 @@ class BatchEngine:
         avail = np.full(self.B, N, np.int32) if n_avail is None else np.ascontiguousarray(n_avail, dtype=np.int32)
         cap = min(max_calls, int(avail.max()) // 800 + 1)
         if features_out is None:
-            features_out = torch.zeros((self.B, cap, FEAT_MF), dtype=torch.float32, device=rx.device)
+            features_out = torch.zeros((self.B, cap, self.rx_row_floats), dtype=torch.float32, device=rx.device)
         # features_out.shape[1] is the per-stream frame capacity handed to the C ABI: a stream pauses (status.consumed < avail)
         # once it has filled its rows, so a short buffer never makes the kernel write into the next stream's region
         assert features_out.is_cuda and features_out.dtype == torch.float32 and features_out.is_contiguous() and features_out.dim() == 3 \
-            and features_out.shape[0] == self.B and features_out.shape[1] >= 1 and features_out.shape[2] == FEAT_MF
+            and features_out.shape[0] == self.B and features_out.shape[1] >= 1 and features_out.shape[2] == self.rx_row_floats
         eoo = eoo_out if eoo_out is not None else torch.zeros((self.B, NEOO_BITS), dtype=torch.float32, device=rx.device)
         assert eoo.is_cuda and eoo.dtype == torch.float32 and eoo.is_contiguous() and tuple(eoo.shape) == (self.B, NEOO_BITS)
         status = (RxStatus * self.B)()
         r = self.lib.rade_batch_rx(self.h, rx.data_ptr(), N, avail.ctypes.data_as(C.POINTER(C.c_int)), max_calls, features_out.data_ptr(),
-                                   features_out.shape[1] * FEAT_MF, eoo.data_ptr(), status, _stream_ptr())
+                                   features_out.shape[1] * self.rx_row_floats, eoo.data_ptr(), status, _stream_ptr())
         if r:
             raise RuntimeError("rade_batch_rx failed")
         return features_out, list(status), eoo

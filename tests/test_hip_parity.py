@@ -265,6 +265,39 @@ def test_rx_trace_edge_cases(Engine, torch_dev, golden, name):
     eng.close()
 
 
+def test_bypass_dec_and_bypass_enc(Engine, torch_dev, golden):
+    """`radae_rxe.py --bypass_dec` (radae_rxe.py:300-302, :315) = an engine opened with RADE_BATCH_BYPASS_DEC: 240 latents per valid modem frame out, no decoder, no UW
+    accounting; `radae_txe.py --bypass_enc` (radae_txe.py:124-126) = rade_batch_tx_latents.  Fixture: oracle/gen_golden_r6.py (the awgn trace's samples)."""
+    import torch
+    from radae_amd.engine import BYPASS_DEC
+    g = golden("bypass")
+    eng = Engine(1, max_tx_mf=6, rx_trace_calls=64, flags=BYPASS_DEC)
+    rows, st, eoo = eng.rx(torch.tensor(g["rx_in"][None], device=torch_dev))
+    assert rows.shape[2] == 240
+    d = eng.rx_trace(0)
+    assert np.array_equal(d["ret"], g["ret"]) and np.array_equal(d["state_after"], g["state_after"]) and np.array_equal(d["uw_errors"], g["uw_errors"]) and not d["uw_errors"].any()
+    nv = st[0].n_valid
+    assert nv == len(g["z_hat_out"])
+    z = rows.cpu().numpy()[0, :nv]
+    assert rms(z, g["z_hat_out"]) < 1e-4 and np.abs(z - g["z_hat_out"]).max() < 1e-3 and rms(z, 0 * z) > 0.3
+    assert st[0].has_eoo and np.array_equal(eoo.cpu().numpy()[0] > 0, g["eoo_out"][-1] > 0)
+    # rows beyond n_valid untouched; a short buffer pauses the stream exactly like the 432-float mode
+    assert not rows.cpu().numpy()[0, nv:].any()
+    eng.rx_reset()
+    small = torch.zeros((1, 3, 240), dtype=torch.float32, device=torch_dev)
+    _, st2, _ = eng.rx(torch.tensor(g["rx_in"][None], device=torch_dev), features_out=small)
+    assert st2[0].n_valid == 3 and np.array_equal(small.cpu().numpy()[0], z[:3]) and st2[0].consumed < g["rx_in"].size
+    # latents in -> transmit frames
+    tx = eng.tx_latents(torch.tensor(g["z_in"].reshape(1, 18, 80), device=torch_dev)).cpu().numpy().reshape(6, 960)
+    assert np.abs(tx - g["tx"]).max() < 2e-5 and rms(tx, g["tx"]) < 5e-6
+    eng.close()
+    # the same latents through an engine with the Tx band-pass filter differ (the filter is applied), and the decoder-side default is untouched
+    plain = Engine(1, max_tx_mf=6, rx_trace_calls=64)
+    f, stp, _ = plain.rx(torch.tensor(g["rx_in"][None], device=torch_dev))
+    assert f.shape[2] == 432 and stp[0].n_valid == nv
+    plain.close()
+
+
 @pytest.mark.parametrize("name", ["slip_plus", "slip_minus", "mpp"])
 def test_bpf_prepass_matches_oracle_filter(Engine, torch_dev, golden, oracle, name):
     """The band-pass filter runs ahead of the receiver kernel for a whole invocation (k_rx_bpf); a stream whose nin changes inside an invocation
@@ -912,6 +945,41 @@ def test_device_multipath_generator(Engine, torch_dev):
         num = np.mean([np.real(np.vdot(G[b, :-lag, p], G[b, lag:, p])) / np.real(np.vdot(G[b, :, p], G[b, :, p])) for b in range(Bs) for p in range(2)])
         assert abs(num - np.exp(-(np.pi * sigma * tau) ** 2)) < tol, (tau, num)
     assert np.abs(G[0] - G[1]).max() > 0.1                 # streams are independent
+    eng.close()
+
+
+def test_lmr60_rate_rs_channel_matrix(Engine, torch_dev):
+    """multipath_samples.m:17-21 + :33-40 (BBFM.md:37: `multipath_samples("lmr60", 8000, 2000, 1, 10, "h_lmr60.f32")`): the land-mobile preset (60 km/h at 450 MHz: 50 Hz spread,
+    200 us) and the rate-Rs |H| the script derives from the rate-Fs Doppler samples, generated on the device.  10 s = 5000 low-rate points, more than the generator
+    keeps in LDS (HBM scratch path).  With the host's noise as input it reproduces channel_tools.multipath_h; from Philox noise mean |H|^2 ~ 1 and the level-crossing
+    rate the script itself checks (:48-61) is near sqrt(2 pi P / Pav) fd exp(-P / Pav)."""
+    import torch
+    from radae_amd.channel_tools import PRESETS, doppler_plan, multipath_h
+    B, n_sym = 3, 20000
+    n_g = (n_sym - 1) * 4 + 1
+    taps, ratio, n_low = doppler_plan(PRESETS["lmr60"][0], 8000, n_g)
+    assert ratio == 16 and n_low > 2048
+    eng = Engine(B, max_tx_mf=1)
+    noise = np.zeros((B, 2, n_low + len(taps)), np.complex64); ref = []
+    for b in range(B):
+        rng = np.random.default_rng(60 + b)
+        for p in range(2):
+            noise[b, p] = rng.standard_normal(n_low + len(taps)) + 1j * rng.standard_normal(n_low + len(taps))
+        ref.append(multipath_h("lmr60", 8000, 2000, 1, n_sym, 60 + b))
+    H = eng.multipath_h_gen("lmr60", n_sym, noise_low=torch.tensor(noise, device=torch_dev)).cpu().numpy()
+    assert H.shape == (B, n_sym, 1) and np.abs(H - np.stack(ref)).max() < 3e-5
+    # several carriers, complex form (the rate-Rs RADE model's H: Rs = 50, Nc = 20 would need Fs / Rs = 160; here the BBFM rates with Nc = 3 to exercise the phase term)
+    Hc = eng.multipath_h_gen("lmr60", 2000, nc=3, noise_low=None, seed=5, complex_=True).cpu().numpy()
+    G = eng.multipath_gen("lmr60", 1999 * 4 + 1, seed=5).cpu().numpy()
+    want = G[:, ::4, 0][:, :, None] + G[:, ::4, 1][:, :, None] * np.exp(-2j * np.pi * np.arange(3)[None, None, :] * 200e-6 * 2000)
+    assert np.abs(Hc - want).max() < 1e-5
+    Hp = eng.multipath_h_gen("lmr60", n_sym, seed=77).cpu().numpy()[:, :, 0].astype(np.float64)
+    for b in range(B):
+        pav = np.mean(Hp[b] ** 2)
+        assert 0.85 < pav < 1.15
+        lcr = np.sum((Hp[b, :-1] ** 2 < 1.0) & (Hp[b, 1:] ** 2 > 1.0)) / 10.0
+        th = np.sqrt(2 * np.pi / pav) * 25.0 * np.exp(-1.0 / pav)
+        assert 0.75 * th < lcr < 1.25 * th, (lcr, th)
     eng.close()
 
 

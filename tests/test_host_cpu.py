@@ -541,3 +541,22 @@ def test_doppler_process_statistics():
         r = np.real(np.vdot(g[:-k], g[k:]) / np.vdot(g, g))
         want = np.exp(-(np.pi * (spread / 2.0) * lag_s) ** 2)
         assert abs(r - want) < 0.03, (lag_s, r, want)
+
+
+def test_lmr60_preset_and_rate_rs_h():
+    """multipath_samples.m:17-21 (lmr60: fd = 450e6 * (60e3 / 3600 / 3e8) = 25 Hz, spread 2 fd, 200 us) and :33-40 (H from G): host restatement."""
+    from radae_amd.channel_tools import PRESETS, doppler_plan, multipath_g, multipath_h
+    spread, delay = PRESETS["lmr60"]
+    assert abs(spread - 50.0) < 1e-9 and delay == 200e-6
+    taps, ratio, n_low = doppler_plan(spread, 8000, 80000)
+    assert ratio == 16 and n_low == 5000 and len(taps) == 100          # lowFs = ceil(10 * 50) = 500 Hz (doppler_spread.m:12-19)
+    H = multipath_h("lmr60", 8000, 2000, 1, 20000, 3)
+    G = multipath_g("lmr60", 8000, 19999 * 4 + 1, 3)
+    assert H.shape == (20000, 1) and H.dtype == np.float32
+    assert np.abs(H[:, 0] - np.abs(G[::4, 0] + G[::4, 1])).max() < 1e-6  # Nc = 1: omega = 0, H = hf_gain |G1 + G2| at every M-th sample
+    Hc = multipath_h("lmr60", 8000, 2000, 4, 500, 3, complex_=True)
+    ph = np.exp(-2j * np.pi * np.arange(4) * 200e-6 * 2000)
+    assert np.abs(Hc - (G[:500 * 4:4, 0][:, None] + G[:500 * 4:4, 1][:, None] * ph[None])).max() < 1e-6
+    pav = np.mean(H.astype(np.float64) ** 2)
+    lcr = np.sum((H[:-1, 0] ** 2 < 1.0) & (H[1:, 0] ** 2 > 1.0)) / 10.0      # the script's own check (:48-61)
+    assert 0.8 < pav < 1.2 and abs(lcr - np.sqrt(2 * np.pi / pav) * 25.0 * np.exp(-1.0 / pav)) < 4.0

@@ -166,6 +166,17 @@ def test_rx_trace_edge_cases(oracle, oracle_model, golden, name):
         assert np.allclose(ber, g["eoo_ber"]) and ber.min() < 0.05 and len(ber) == 5      # the ctest's pass rule: one over below 5 %
 
 
+def test_bypass_fixture(oracle, oracle_model, golden):
+    """bypass.npz (radae_rxe.py --bypass_dec, radae_txe.py --bypass_enc): the oracle's per-call latents are what the reference wrote out, and its modulator on
+    supplied latents reproduces the reference's transmit frames."""
+    g = golden("bypass")
+    d = oracle.run_rx_stream(oracle_model, g["rx_in"])
+    assert np.array_equal(d["ret"], g["ret"]) and np.array_equal(d["state_after"], g["state_after"])
+    assert rms(d["z_hat"], g["z_hat_out"]) < 1e-4
+    tx = np.array([oracle.ofdm_mod(g["z_in"][k]) for k in range(6)])
+    assert np.abs(tx - g["tx"]).max() < 5e-6
+
+
 def test_decoder_and_loss(oracle, oracle_model, golden):
     g = golden("dec_loss")
     dec = oracle.Decoder(oracle_model)
