@@ -20,7 +20,7 @@ PRESETS = {  # multipath_samples.m:10-21  (doppler spread Hz, path delay s)
     "mpg": (0.1, 0.5e-3),
     "mpp": (1.0, 2.0e-3),
     "mpd": (2.0, 4.0e-3),
-    # land mobile radio, 60 km/h at 450 MHz (multipath_samples.m:17-21): fd = 450e6 * (60e3 / 3600 / 3e8) = 25 Hz, spread = 2 fd; BBFM.md:37 makes the
+    # land mobile radio, 60 km/h at 450 MHz (multipath_samples.m:17-21): fd = 450e6 * (60e3 / 3600 / 3e8) = 25 Hz, spread = 2 fd (50.00000000000001 in doubles, as in Octave: lowFs becomes 501 -> M = 15); BBFM.md:37 makes the
     # BBFM model's |H| file from it (Rs = 2000, Nc = 1): multipath_h() below
     "lmr60": (2.0 * 450e6 * (60 * 1e3 / 3600 / 3e8), 200e-6),
 }

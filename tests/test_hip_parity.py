@@ -950,7 +950,7 @@ def test_device_multipath_generator(Engine, torch_dev):
 
 def test_lmr60_rate_rs_channel_matrix(Engine, torch_dev):
     """multipath_samples.m:17-21 + :33-40 (BBFM.md:37: `multipath_samples("lmr60", 8000, 2000, 1, 10, "h_lmr60.f32")`): the land-mobile preset (60 km/h at 450 MHz: 50 Hz spread,
-    200 us) and the rate-Rs |H| the script derives from the rate-Fs Doppler samples, generated on the device.  10 s = 5000 low-rate points, more than the generator
+    200 us) and the rate-Rs |H| the script derives from the rate-Fs Doppler samples, generated on the device.  10 s = 5334 low-rate points, more than the generator
     keeps in LDS (HBM scratch path).  With the host's noise as input it reproduces channel_tools.multipath_h; from Philox noise mean |H|^2 ~ 1 and the level-crossing
     rate the script itself checks (:48-61) is near sqrt(2 pi P / Pav) fd exp(-P / Pav)."""
     import torch
@@ -958,7 +958,7 @@ def test_lmr60_rate_rs_channel_matrix(Engine, torch_dev):
     B, n_sym = 3, 20000
     n_g = (n_sym - 1) * 4 + 1
     taps, ratio, n_low = doppler_plan(PRESETS["lmr60"][0], 8000, n_g)
-    assert ratio == 16 and n_low > 2048
+    assert ratio == 15 and n_low > 2048        # 2 * 450e6 * (60e3 / 3600 / 3e8) = 50.00000000000001 in doubles (Octave's too): lowFs = ceil(500.0000000000001) = 501 -> M = floor(8000 / 501) = 15
     eng = Engine(B, max_tx_mf=1)
     noise = np.zeros((B, 2, n_low + len(taps)), np.complex64); ref = []
     for b in range(B):

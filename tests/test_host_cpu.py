@@ -499,7 +499,7 @@ def test_refine_moment_expansion_is_complex128_accurate():
 def test_doppler_filter_design_against_scipy_firwin2():
     """the reference designs its Doppler-spread filter with Octave's fir2 (doppler_spread.m:27-29: `fir2(Ntaps-1, x/(lowFs/2), y)`), which
     cannot be run here.  scipy's firwin2 is an independent implementation of the same frequency-sampling algorithm: the module's restatement of fir2's recipe
-    equals it to rounding for the three channel presets' spreads, and it is the design IN USE: doppler_plan (the device generator's taps) returns exactly these
+    equals it to rounding for the channel presets' spreads (mpg, mpp, mpd, lmr60), and it is the design IN USE: doppler_plan (the device generator's taps) returns exactly these
     taps, and doppler_spread / multipath_g (every golden G, bench.py's workload) filter with them."""
     import math
     import scipy.signal as ss
@@ -507,7 +507,8 @@ def test_doppler_filter_design_against_scipy_firwin2():
     for name, (spread, _) in ct.PRESETS.items():
         low_fs = math.ceil(10 * spread); m = 8000 / low_fs
         if m != math.floor(m):
-            low_fs = 8000 / math.floor(m)
+            m = math.floor(m); low_fs = 8000 / m
+        m = int(m)
         sigma = spread / 2.0
         x = np.arange(51) * low_fs / 100.0
         y = (1.0 / (sigma * math.sqrt(2 * math.pi))) * np.exp(-(x ** 2) / (2 * sigma * sigma))
@@ -517,7 +518,7 @@ def test_doppler_filter_design_against_scipy_firwin2():
         ours = ct.fir2_from_gaussian_psd(spread, low_fs, 100)
         assert np.abs(ours - ref).max() < 1e-12 * np.abs(ref).max(), name
         taps, ratio, n_low = ct.doppler_plan(spread, 8000, 16000)
-        assert np.array_equal(taps, ours) and ratio == int(8000 / low_fs)
+        assert np.array_equal(taps, ours) and ratio == m
         # doppler_spread() filters with the same taps: rebuild its output from its own noise draw
         rng = np.random.default_rng(11); g = ct.doppler_spread(spread, 8000, 16000, rng)
         rng = np.random.default_rng(11); xs = rng.standard_normal(n_low + 100) + 1j * rng.standard_normal(n_low + 100)
@@ -549,14 +550,17 @@ def test_lmr60_preset_and_rate_rs_h():
     spread, delay = PRESETS["lmr60"]
     assert abs(spread - 50.0) < 1e-9 and delay == 200e-6
     taps, ratio, n_low = doppler_plan(spread, 8000, 80000)
-    assert ratio == 16 and n_low == 5000 and len(taps) == 100          # lowFs = ceil(10 * 50) = 500 Hz (doppler_spread.m:12-19)
+    # the preset's spread is 50.00000000000001 in IEEE doubles (the script's own expression, same in Octave): lowFs = ceil(10 * spread) = 501, M = floor(8000 / 501) = 15,
+    # lowFs = 8000 / 15 (doppler_spread.m:12-19) -- not the 500 Hz / M = 16 of an exact 50
+    assert spread > 50.0 and ratio == 15 and n_low == 5334 and len(taps) == 100
     H = multipath_h("lmr60", 8000, 2000, 1, 20000, 3)
     G = multipath_g("lmr60", 8000, 19999 * 4 + 1, 3)
     assert H.shape == (20000, 1) and H.dtype == np.float32
     assert np.abs(H[:, 0] - np.abs(G[::4, 0] + G[::4, 1])).max() < 1e-6  # Nc = 1: omega = 0, H = hf_gain |G1 + G2| at every M-th sample
     Hc = multipath_h("lmr60", 8000, 2000, 4, 500, 3, complex_=True)
+    G4 = multipath_g("lmr60", 8000, 499 * 4 + 1, 3)                      # (hf_gain is the variance over the generated length: same length, same G)
     ph = np.exp(-2j * np.pi * np.arange(4) * 200e-6 * 2000)
-    assert np.abs(Hc - (G[:500 * 4:4, 0][:, None] + G[:500 * 4:4, 1][:, None] * ph[None])).max() < 1e-6
+    assert np.abs(Hc - (G4[::4, 0][:, None] + G4[::4, 1][:, None] * ph[None])).max() < 1e-6
     pav = np.mean(H.astype(np.float64) ** 2)
     lcr = np.sum((H[:-1, 0] ** 2 < 1.0) & (H[1:, 0] ** 2 > 1.0)) / 10.0      # the script's own check (:48-61)
     assert 0.8 < pav < 1.2 and abs(lcr - np.sqrt(2 * np.pi / pav) * 25.0 * np.exp(-1.0 / pav)) < 4.0
