@@ -59,6 +59,13 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
 void rade_batch_close(rade_batch *h);
 int rade_batch_n_streams(const rade_batch *h);
 
+/* Arithmetic of the encoder depends on the SIZE of the call, in the last bits only: calls with more than 16384 rows (B x 3 n_mf) run the batched kernels on operand
+ * fragments (rade_enc.hip), whose two conv taps alternate per k-block -- another summation order of the same float32 partial products than the float32-row kernels that
+ * serve smaller calls ($RADE_ENCF_SEQ_TAPS restores the sequential order, $RADE_ENC_ROWS the row kernels for every size).  Both are inside every parity bar (latents
+ * < 2e-5 of full scale against the float32 oracle, tests/test_hip_parity.py), but the same stream encoded in a batch of 32 and in a batch of 256 is not bit-identical.
+ * The batched path also keeps one bit of HOST state per engine (whether the history tile of its fragment buffer is current): rade_batch_tx / rade_batch_encode are
+ * stream-ordered but not capturable into a hipGraph that is replayed across resets or mixed with short calls (rade_tx() of rade_api.h, which IS captured, always takes
+ * the row path). */
 /* ---- transmit ------------------------------------------------------------------------------
  * features_dev : [B][n_mf*12][36] float32 (first 20 of each 36 used; aux symbol -1 added inside)
  * iq_out_dev   : stream b written at iq_out_dev + b*iq_stride (units: complex samples), n_mf*960 samples
@@ -66,10 +73,10 @@ int rade_batch_n_streams(const rade_batch *h);
  * returns n_mf*960 or <0 on error */
 int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride,
                   float *z_out_dev, void *stream);
-/* bits_host: [B][180] +-1 floats, or NULL to restore the default (all-zero data symbols) EOO frame */
 /* `radae_txe.py --bypass_enc` (radae_txe.py:124-126; rade_api.c with RADE_USE_C_ENCODER): latents from an external core encoder, z_dev [B][3 n_mf][80] float32,
  * straight into the OFDM modulator (and the Tx band-pass filter when the engine has it).  The engine's own encoder state is not touched.  Returns n_mf * 960. */
 int rade_batch_tx_latents(rade_batch *h, const float *z_dev, int n_mf, void *iq_out_dev, long iq_stride, void *stream);
+/* bits_host: [B][180] +-1 floats, or NULL to restore the default (all-zero data symbols) EOO frame */
 int rade_batch_tx_set_eoo_bits(rade_batch *h, const float *bits_host);
 /* writes the 1152-sample end-of-over frame of every stream; returns 1152 */
 int rade_batch_tx_eoo(rade_batch *h, void *iq_out_dev, long iq_stride, void *stream);
@@ -93,7 +100,9 @@ int rade_batch_channel_symbol(rade_batch *h, const float *z_dev, const float *H_
 typedef struct {
     int n_sig;            /* signal samples per stream (multiple of 960) */
     int n_pre, n_post;    /* noise-only samples before / after (inference.py --prepend_noise/--append_noise) */
-    int with_eoo;         /* append the stream's EOO frame, phase-continued (inference.py --end_of_over) */
+    int with_eoo;         /* append the stream's EOO frame, phase-continued (inference.py --end_of_over).  On an engine with RADE_BATCH_TX_BPF the appended frame is the EOO
+                           * through the Tx band-pass filter + clip, continuing from the filter state the transmitted frames left (radae_txe.py:138-144); the channel call
+                           * only READS that state (calling it twice gives the same samples).  Do not call rade_batch_tx_eoo first: that advances the state past the EOO. */
     float sigma;          /* AWGN std-dev, see rade_sigma_from_EbNodB */
     float freq_offset;    /* Hz */
     float df_dt;          /* Hz/s */

@@ -42,6 +42,7 @@ class Rade:
     def __init__(self, model_file: str = "", flags: int = RADE_VERBOSE_0):
         self.L = _bind()
         self.L.rade_initialize()
+        self.flags = flags
         self.r = self.L.rade_open(model_file.encode(), flags)
         if not self.r:
             raise RuntimeError("rade_open failed: no GPU or no weight blob (libradehip.so has no CPU fallback)")
@@ -64,6 +65,9 @@ class radae_tx:
     def __init__(self, model_name: str = "", handle: Rade | None = None, flags: int = RADE_VERBOSE_0, txbpf_en: bool = False):
         if txbpf_en:
             flags |= RADE_BATCH_TX_BPF
+        if handle is not None and bool(handle.flags & RADE_BATCH_TX_BPF) != bool(txbpf_en):
+            # the reference's radae_tx always honours txbpf_en; here the filter belongs to the handle, so a mismatch would silently transmit the other signal
+            raise ValueError(f"radae_tx(txbpf_en={bool(txbpf_en)}) on a handle opened {'with' if handle.flags & RADE_BATCH_TX_BPF else 'without'} RADE_BATCH_TX_BPF")
         self.h = handle or Rade(model_name, flags)
         self.txbpf_en = bool(txbpf_en)
         L, r = self.h.L, self.h.r

@@ -334,6 +334,9 @@ rade_batch *rade_batch_open_mem(const void *blob, size_t blob_len, const rade_ba
     h->enc_no_pair = getenv("RADE_ENCF_NO_PAIR") != NULL;
     if (B * T > 16384 && !getenv("RADE_ENC_ROWS")) {       /* $RADE_ENC_ROWS: the float32-row path (k_gemm16p) for every size: A/B and the equality test */
         h->enc_xf = dev_zeros(sizeof(unsigned short) * B * h->enc_nq * RD_EF_TILE);      /* (NULL = no memory for it: the float32-row kernels serve every call) */
+        if (!h->enc_xf && !getenv("RADE_VERBOSE_0"))
+            fprintf(stderr, "rade: no device memory for the encoder's fragment buffer (%.1f MB): the float32-row kernels serve every call (slower encoder GEMMs, same results to the last bits documented in rade_batch.h)\n",
+                    1e-6 * sizeof(unsigned short) * (double)B * h->enc_nq * RD_EF_TILE);
     }
     h->enc_z = dev_zeros(sizeof(float) * B * T * RD_LATENT);
     h->eoo = dev_zeros(sizeof(float) * B * RD_NEOO * 2);
@@ -623,18 +626,19 @@ static int encode_core(rade_batch *h, int T, float *z, void *stream)
 
 /* the optional Tx band-pass filter + magnitude clip (radae_txe.py:130-132, :141-143) over the n samples the modulator left in tx_raw: the receiver's
  * filtering pass with frames as blocks (len0 = the first frame: 960, or the 1152-sample end-of-over frame), every sample consumed */
-static int tx_bpf_pass(rade_batch *h, int n, int len0, void *out, long out_stride, void *stream)
+static int tx_bpf_pass_adv(rade_batch *h, int n, int len0, void *out, long out_stride, void *stream, int advance)
 {
     rd_bpf_args ba;
     memset(&ba, 0, sizeof ba);
     ba.state = h->tx_bpf; ba.state_stride = sizeof(rd_bpf_state); ba.len0_const = len0; ba.avail_const = n;
     ba.tab = h->d_tab; ba.bpf16 = h->bpf16; ba.x = h->tx_raw; ba.x_stride = (long)(h->max_tx_mf > 2 ? h->max_tx_mf : 2) * RD_NMF; ba.y = out; ba.y_stride = out_stride;
-    ba.chain = h->tx_chain; ba.chain_stride = h->max_tx_mf + 8; ba.n_blocks = 1 + (n > len0 ? (n - len0 + RD_NMF - 1) / RD_NMF : 0); ba.B = h->B; ba.clip = 1; ba.advance = 1;
+    ba.chain = h->tx_chain; ba.chain_stride = h->max_tx_mf + 8; ba.n_blocks = 1 + (n > len0 ? (n - len0 + RD_NMF - 1) / RD_NMF : 0); ba.B = h->B; ba.clip = 1; ba.advance = advance;
     PROF_BEGIN(h, stream);
     const int rc = rd_launch_bpf(&ba, stream);
     PROF_END(h, stream, RADE_PROF_BPF, 8.0 * 101.0 * (double)h->B * n);
     return rc;
 }
+static int tx_bpf_pass(rade_batch *h, int n, int len0, void *out, long out_stride, void *stream) { return tx_bpf_pass_adv(h, n, len0, out, out_stride, stream, 1); }
 
 /* ---- transmit (radae_txe.py:108-135 for n_mf modem frames and B streams at once) -------------- */
 int rade_batch_tx(rade_batch *h, const float *features_dev, int n_mf, void *iq_out_dev, long iq_stride, float *z_out_dev, void *stream)
@@ -710,7 +714,10 @@ int rade_batch_channel(rade_batch *h, const void *tx_dev, long tx_stride, void *
     a.sine_amp = p->sine_amp; a.sine_freq = p->sine_freq; a.rx_gain = p->rx_gain != 0.0f ? p->rx_gain : 1.0f;
     if (h->tx_bpf && p->with_eoo) {        /* what radae_tx --txbpf transmits after the last frame: the end-of-over frame through the Tx band-pass filter and the clip,
                                             * the filter state carried on from the frames before it (radae_txe.py:138-144) */
-        if (rade_batch_tx_eoo(h, h->eoo_filt, RD_NEOO, stream) != RD_NEOO) return -1;
+        /* a pure channel call: the filter state is READ, not advanced (two passes over the same tx -- two SNR points, a two-pass bench -- see the same EOO);
+         * tx_raw is the modulator's scratch and holds nothing a caller can see */
+        if (rd_launch_copy_eoo(h->eoo, h->tx_raw, (long)(h->max_tx_mf > 2 ? h->max_tx_mf : 2) * RD_NMF, h->B, stream) ||
+            tx_bpf_pass_adv(h, RD_NEOO, RD_NEOO, h->eoo_filt, RD_NEOO, stream, 0)) return -1;
         a.eoo = h->eoo_filt;
     }
     PROF_BEGIN(h, stream);
@@ -845,20 +852,45 @@ int rade_batch_channel_symbol(rade_batch *h, const float *z_dev, const float *H_
 /* The wait of rade_batch_rx when the host is short of CPUs (sync_blocking_now): SLEEP until the receiver launch is done.  hipEventSynchronize on a
  * hipEventBlockingSync event does not do that on this runtime -- measured (tools/host_threads_cpu.py, round 5): a lane thread sitting in it burns its whole
  * wall time, 3.0 cores busy for three engines against 3.8 with hipStreamSynchronize -- so the thread sleeps itself: through three quarters of what the last
- * waits took (a receiver launch lasts milliseconds and as long as the one before it), then in short naps between hipEventQuery calls.  A nap costs a wake-up,
+ * measured waits took (a receiver launch lasts milliseconds and as long as the one before it), then in short naps between hipEventQuery calls.  A nap costs a wake-up,
  * not a core; the launch's end is noticed at most one nap (plus the timer slack) late, which the other engines' batches in flight cover. */
 static double now_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec; }
 static void nap_us(double us) { if (us > 0.0) { struct timespec t = { (time_t)(us / 1e6), (long)(1e3 * (us - 1e6 * (double)(time_t)(us / 1e6))) }; nanosleep(&t, NULL); } }
+/* The estimate must not feed on its own nap: a wait that ends INSIDE the long nap says only "the launch took at most the nap", so the estimate is halved (not
+ * averaged with a dt that is mostly the nap -- that form decayed 6 % per call and an outlier cost seconds of oversleeping); only a wait whose first query after the nap
+ * still found the launch running measures the launch, and only those are averaged in, an outlier counted as at most 8x the present estimate.  The long nap is capped
+ * (a receiver launch lasts milliseconds), and the engine's first wait -- lazy code-object load included -- does not seed the estimate. */
+#define RADE_NAP_CAP_US 20000.0
 static int sleep_until_event(rade_batch *h, hipEvent_t ev)
 {
     const double t0 = now_us();
+    int overslept = 0;
     hipError_t e = hipEventQuery(ev);
-    if (e == hipErrorNotReady && h->wait_est_us > 150.0) { nap_us(0.75 * h->wait_est_us); e = hipEventQuery(ev); }
+    if (e == hipErrorNotReady && h->wait_est_us > 150.0) {
+        const double nap = 0.75 * h->wait_est_us;
+        nap_us(nap < RADE_NAP_CAP_US ? nap : RADE_NAP_CAP_US); e = hipEventQuery(ev); overslept = e == hipSuccess;
+    }
     while (e == hipErrorNotReady) { nap_us(40.0); e = hipEventQuery(ev); }
     if (e != hipSuccess) { fprintf(stderr, "rade: %s while waiting for the receiver launch\n", hipGetErrorString(e)); return -1; }
-    const double dt = now_us() - t0;
-    h->wait_est_us = h->wait_est_us > 0.0 ? 0.75 * h->wait_est_us + 0.25 * dt : dt;
+    double dt = now_us() - t0;
+    if (overslept) h->wait_est_us *= 0.5;
+    else if (h->n_sync_block > 0) {
+        if (h->wait_est_us > 0.0 && dt > 8.0 * h->wait_est_us) dt = 8.0 * h->wait_est_us;
+        h->wait_est_us = h->wait_est_us > 0.0 ? 0.75 * h->wait_est_us + 0.25 * dt : dt;
+    }
     return 0;
+}
+/* test hook (tests/test_host_cpu.py): the estimate's update rule driven with synthetic waits -- `ready_after_us` is when the launch really ends; returns the
+ * time this wait would have kept the thread beyond that (the oversleep) and updates *est like sleep_until_event does */
+double rade_wait_model_step(double *est, double ready_after_us, int first)
+{
+    double t = 0.0; int overslept = 0;
+    if (ready_after_us > 0.0 && *est > 150.0) { const double nap = 0.75 * *est; t = nap < RADE_NAP_CAP_US ? nap : RADE_NAP_CAP_US; overslept = t >= ready_after_us; }
+    while (t < ready_after_us) t += 40.0;
+    double dt = t;
+    if (overslept) *est *= 0.5;
+    else if (!first) { if (*est > 0.0 && dt > 8.0 * *est) dt = 8.0 * *est; *est = *est > 0.0 ? 0.75 * *est + 0.25 * dt : dt; }
+    return t - ready_after_us;
 }
 
 int rade_batch_rx(rade_batch *h, const void *rx_dev, long rx_stride, const int *n_avail_host, int max_calls,

@@ -386,6 +386,8 @@ def test_tx_bpf_single_stream_c_abi_and_channel_eoo(Engine, torch_dev, golden):
         assert np.abs(out - g["tx"][960 * k:960 * k + 960]).max() < 2e-5, k
     tx.do_eoo(eo)
     assert np.abs(eo - g["eoo"]).max() < 2e-5 and np.abs(eo).max() <= 1.0 + 1e-6
+    with pytest.raises(ValueError):                   # a handle opened with the filter cannot serve a radae_tx that says it has none (and vice versa): no silent other signal
+        api.radae_tx(handle=tx.h, txbpf_en=False)
     tx.h.close()
     f1 = torch.tensor(g["features"][None], device=torch_dev)
     eng = Engine(1, max_tx_mf=n_mf, flags=0x400)
@@ -394,6 +396,8 @@ def test_tx_bpf_single_stream_c_abi_and_channel_eoo(Engine, torch_dev, golden):
     gain = np.vdot(g["tx"], rx[:n_mf * 960]) / np.vdot(g["tx"], g["tx"])                      # the channel's power normalisation of the signal part
     assert abs(gain.imag) < 1e-6 and np.abs(rx[:n_mf * 960] - gain.real * g["tx"]).max() < 3e-5
     assert np.abs(rx[n_mf * 960:n_mf * 960 + 1152] - gain.real * g["eoo"]).max() < 3e-5      # the EOO frame behind it: filtered + clipped, state carried on
+    rx_again = eng.channel(iq, 0.0, 0.0, n_pre=0, n_post=0, with_eoo=True).cpu().numpy()[0]  # the channel call only reads the Tx filter state: a second pass gives the same EOO
+    assert np.array_equal(rx_again, rx)
     eng.tx_reset()
     rx2 = eng.tx_channel(f1, 0.0, 0.0, n_pre=0, n_post=0, with_eoo=True).cpu().numpy()[0]
     assert np.array_equal(rx2, rx)

@@ -564,3 +564,26 @@ def test_lmr60_preset_and_rate_rs_h():
     pav = np.mean(H.astype(np.float64) ** 2)
     lcr = np.sum((H[:-1, 0] ** 2 < 1.0) & (H[1:, 0] ** 2 > 1.0)) / 10.0      # the script's own check (:48-61)
     assert 0.8 < pav < 1.2 and abs(lcr - np.sqrt(2 * np.pi / pav) * 25.0 * np.exp(-1.0 / pav)) < 4.0
+
+
+def test_sleeping_wait_estimate_recovers_from_an_outlier(lib):
+    """rade_engine.c: sleep_until_event's estimate (it fed on its own nap -- est' = 0.9375 est per call after one outlier, ~12 s of cumulative oversleep after a
+    1 s hiccup).  The update rule, driven with synthetic waits: steady 3 ms launches, one 1 s outlier, steady again -> the cumulative oversleep after the outlier stays
+    below 40 ms and the estimate is back within 2x of the launch time in under 10 calls; a cold first wait does not seed it."""
+    lib.rade_wait_model_step.restype = C.c_double
+    lib.rade_wait_model_step.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_int]
+    est = C.c_double(0.0)
+    lib.rade_wait_model_step(C.byref(est), 250000.0, 1)                      # first wait: 250 ms of lazy module load
+    assert est.value == 0.0
+    for _ in range(20):
+        over = lib.rade_wait_model_step(C.byref(est), 3000.0, 0)
+    assert 2500.0 < est.value < 3500.0 and over < 50.0
+    lib.rade_wait_model_step(C.byref(est), 1e6, 0)                           # the hiccup
+    assert est.value < 8.0 * 3500.0
+    total, calls_to_recover = 0.0, None
+    for k in range(60):
+        total += lib.rade_wait_model_step(C.byref(est), 3000.0, 0)
+        if calls_to_recover is None and est.value < 6000.0:
+            calls_to_recover = k + 1
+    assert total < 40000.0 and calls_to_recover is not None and calls_to_recover < 10, (total, calls_to_recover)
+    assert 1400.0 < est.value < 3500.0
