@@ -167,10 +167,16 @@ def main():
     peers = sync_peers(world, os.environ)
     if peers is not None:
         os.environ["RADE_SYNC_PEERS"] = peers
-    engs = [BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob) for _ in range(depth)]
+    # developer switch (tools/ab_bench.py: `spec=,RADE_BENCH_SPEC_DEC=1`): the OPTIMISTIC BOUND of a speculative batched decoder -- the receiver
+    # launch emits latents only (RADE_BATCH_BYPASS_DEC: no decoder, no UW accounting in the chain), the layer-wise batched decoder (rade_batch_decode) then decodes
+    # every stream's rows; no UW evaluation, no replay of the streams whose UW count would have ended sync, no decoder resets: NOT the product path (results differ),
+    # a ceiling on what that structure could reach
+    spec_dec = bool(os.environ.get("RADE_BENCH_SPEC_DEC"))
+    from radae_amd.engine import BYPASS_DEC
+    engs = [BatchEngine(B, max_tx_mf=n_mf, device=local, blob_bytes=blob, flags=BYPASS_DEC if spec_dec else 0) for _ in range(depth)]
     eng = engs[0]
     lanes = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-    out_bufs = [(torch.zeros((B, (n_pre + n_sig + 1152 + n_post) // 800 + 1, 432), dtype=torch.float32, device=dev), torch.zeros((B, 180), dtype=torch.float32, device=dev)) for _ in range(depth)]
+    out_bufs = [(torch.zeros((B, (n_pre + n_sig + 1152 + n_post) // 800 + 1, 240 if spec_dec else 432), dtype=torch.float32, device=dev), torch.zeros((B, 180), dtype=torch.float32, device=dev)) for _ in range(depth)]
 
     # ---- synthetic inputs, resident in HBM before the clock starts.  Utterance u uses seeds 1000 + u / 5000 + u; rank r owns the
     # contiguous shard [r B, r B + B) of the B x world utterances
@@ -193,6 +199,11 @@ def main():
         # the receiver's outputs go to caller-owned buffers, one set per engine as in hosts/rade_multi_bench.c (rows beyond status.n_valid keep what they
         # held: the C ABI never promised zeroes); without them the Python binding allocates and zero-fills 37 MB per step, two more launches in the lane
         i = engs.index(e)
+        if spec_dec:
+            z, st_, eo_ = e.rx(rx, features_out=out_bufs[i][0], eoo_out=out_bufs[i][1])
+            rows = 3 * max(s.n_valid for s in st_)
+            fo_ = e.decode(z.view(B, -1, 80)[:, :rows].contiguous(), 84) if rows else z
+            return fo_, st_, eo_, rx
         return e.rx(rx, features_out=out_bufs[i][0], eoo_out=out_bufs[i][1]) + (rx,)
 
     def run_steps(n, seed0):
@@ -271,7 +282,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "model19_check3 streaming radae_txe -> OFDM + MPP multipath/AWGN 3 dB/-11 Hz -> radae_rxe (configs[2])",
-                   "streams_per_gpu": B, "frames_per_stream": T, "global_streams": B * world, "batches_in_flight": depth, "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only",
+                   "streams_per_gpu": B, "frames_per_stream": T, "global_streams": B * world, "batches_in_flight": depth, **({"developer_variant": "RADE_BENCH_SPEC_DEC: latents-only receiver + batched decoder, no UW / replay (optimistic bound, not the product path)"} if spec_dec else {}), "parallelism": f"utterance-sharded x{world}, RCCL weight broadcast only",
                    "arithmetic": "f32 DSP, f64 refine, matrix products on split-binary16 (2 x 11 bit) MFMA with f32 accumulation"},
         "pipelining": f"{depth} batch(es) in flight per GPU (engines with their own state on their own HIP stream / host thread, steps dealt in turn); ms_per_step = wall time / steps; "
                       "roofline.sum_kernel_ms_per_step is one batch alone",
