@@ -64,7 +64,7 @@ def executed_flop(search_calls, sync_calls, decoded_mf):
     return sync_calls * SYNC_CALL_FLOP + decoded_mf * DEC_MF_FLOP + search_calls * FFT_SURFACE_FLOP
 
 
-def launch_plan(gpus, env, n_visible, argv, port=None):
+def launch_plan(gpus, env, n_visible, argv, port=None, oversubscribe=None):
     """What `bench.py --gpus N` has to do before any GPU work (pure function: the CPU tests call it).
     Returns ("inprocess", None) -- this process is the job (N == 1) or one rank of it (started by torch.distributed.run: WORLD_SIZE
     must then equal --gpus) -- or ("spawn", argv_of_child): N > 1 asked for by a plain `python bench.py --gpus N`, so this process
@@ -72,6 +72,23 @@ def launch_plan(gpus, env, n_visible, argv, port=None):
     Raises SystemExit (non-zero) when fewer than N devices are visible or the rank count disagrees with --gpus."""
     if gpus < 1:
         raise SystemExit(f"bench.py: --gpus {gpus} is not a GPU count")
+    if oversubscribe is not None:
+        # developer mode (--oversubscribe-device D): the N ranks of an N-GPU job, all on device D -- a HOST-contention proxy (N processes x 3 engines share the
+        # node's CPUs the way a real node's ranks would), not a scaling measurement; the line says so and reports n_gpus = 1
+        if n_visible < oversubscribe + 1:
+            raise SystemExit(f"bench.py: --oversubscribe-device {oversubscribe} but only {n_visible} HIP device(s) are visible")
+        if "WORLD_SIZE" in env:
+            if int(env["WORLD_SIZE"]) != gpus:
+                raise SystemExit(f"bench.py: --gpus {gpus} but the launcher started {env['WORLD_SIZE']} rank(s)")
+            return "inprocess", None
+        if gpus == 1:
+            return "inprocess", None
+        if port is None:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        return "spawn", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     if "WORLD_SIZE" in env:
         world = int(env["WORLD_SIZE"])
         if world != gpus:
@@ -125,11 +142,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--oversubscribe-device", type=int, default=None, metavar="D",
+                    help="developer mode: run the --gpus N ranks of an N-GPU job all on HIP device D (gloo for the two collectives): what N processes x 3 engines cost the HOST; not a scaling measurement")
     args = ap.parse_args()
     if args.pipeline > 3:                # HIP multiplexes a process's streams onto 4 hardware queues per device by default; streams that share one serialise
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-    mode, child = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0, sys.argv[1:])
+    mode, child = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0, sys.argv[1:], oversubscribe=args.oversubscribe_device)
     if mode == "spawn":                  # `python bench.py --gpus N`: one rank per GPU under torch.distributed.run; rank 0 of the child prints the line
         import subprocess
         env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env["RADE_BENCH_LAUNCHER"] = "self (bench.py re-executed under torch.distributed.run)"
@@ -137,15 +156,20 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, (world, args.gpus)
     launcher = os.environ.get("RADE_BENCH_LAUNCHER", "torch.distributed.run (caller)" if "WORLD_SIZE" in os.environ else "in-process, single rank")
+    oversub = args.oversubscribe_device is not None
+    if oversub:
+        local = args.oversubscribe_device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = torch.device("cpu") if oversub else dev       # where the two collectives' tensors live (gloo when every rank sits on one device: RCCL wants a device per rank)
     if args.config == 2:
         print(json.dumps(config2(args.frames)))
         return
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if oversub: dist.init_process_group("gloo", rank=rank, world_size=world)
+        else: dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from radae_amd.channel_tools import multipath_g, synth_features
     from radae_amd.engine import BatchEngine, DEFAULT_BLOB, sigma_from_EbNodB
@@ -156,7 +180,7 @@ def main():
     n_sig, n_pre, n_post = n_mf * NMF, 8000, 1152
 
     # ---- weights: rank 0 reads the blob, every other rank receives it over RCCL/xGMI
-    blob = broadcast_blob(DEFAULT_BLOB if rank == 0 else None, dev, world)
+    blob = broadcast_blob(DEFAULT_BLOB if rank == 0 else None, coll_dev, world)
     # `--pipeline` engines, each with its own state, HIP stream and host thread: the steps are dealt to them in turn, so the next batch's
     # encoder / channel kernels (and the head of its receiver launch) fill the CUs that the slowest streams of the previous batch's receiver
     # launch leave idle (a receiver launch lasts as long as its slowest stream; rade_batch_rx synchronises its stream, hence one thread each)
@@ -257,11 +281,11 @@ def main():
         per_rank_ms = [1e3 * dt_local / args.steps]
         if world > 1:
             import torch.distributed as dist
-            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-            allms = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-            dist.all_gather(allms, torch.tensor([1e3 * dt_local / args.steps], dtype=torch.float64, device=dev))
+            allms = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+            dist.all_gather(allms, torch.tensor([1e3 * dt_local / args.steps], dtype=torch.float64, device=coll_dev))
             per_rank_ms = [float(x.item()) for x in allms]
         reps.append((dt, per_rank_ms, cpu_s))
     dt, per_rank_ms, cpu_s = sorted(reps, key=lambda r: r[0])[(len(reps) - 1) // 2]      # median (lower middle for an even count)
@@ -275,10 +299,23 @@ def main():
     # job-wide statistics of the last step (the only other collective besides the blob broadcast: one small all-reduce)
     nv = np.array([s.n_valid for s in st]); ncalls = np.array([s.n_calls for s in st]); neoo = np.array([s.has_eoo for s in st])
     sync_calls = int((nv + neoo).sum()); search_calls = int(ncalls.sum()) - sync_calls
-    job = gather_stats(np.array([B * T, 12.0 * nv.sum(), ncalls.sum(), sync_calls, search_calls, neoo.sum()], dtype=np.float64), dev, world)
+    job = gather_stats(np.array([B * T, 12.0 * nv.sum(), ncalls.sum(), sync_calls, search_calls, neoo.sum()], dtype=np.float64), coll_dev, world)
+    # what the last timed step decoded on this rank, as a digest (outside the clock): rank 0 of an N-rank job owns the same utterances as a single-rank job,
+    # so its digest must equal the single-rank run's (tools/oversub8.sh checks it)
+    import hashlib
+    dig = hashlib.sha256()
+    fo_host = fo.cpu().numpy()
+    for b in range(B):
+        dig.update(np.ascontiguousarray(fo_host[b, :st[b].n_valid]).tobytes())
+    host_cpu = None
+    if world > 1:
+        import torch.distributed as dist
+        mine = torch.tensor([cpu_s / dt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        host_cpu = float(mine.item())
 
     out = {
-        "metric": "vocoder-feature frames/sec (enc+chan+dec), model19", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "metric": "vocoder-feature frames/sec (enc+chan+dec), model19", "value": value, "unit": "frames/s", "n_gpus": 1 if oversub else world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": "model19_check3 streaming radae_txe -> OFDM + MPP multipath/AWGN 3 dB/-11 Hz -> radae_rxe (configs[2])",
@@ -289,7 +326,9 @@ def main():
         "value_counts": "offered feature frames: every transmitted frame's samples pass through the receiver, decoded or not",
         "decoded_frames_per_s": value * job[1] / job[0],
         "timed_region_s": dt, "value_repeats": [B * T * args.steps * world / r[0] for r in reps], "timed_region_s_repeats": [r[0] for r in reps],
-        "launcher": launcher, "rccl_ranks": ranks_seen,
+        "launcher": launcher, "rccl_ranks": ranks_seen, "last_step_features_sha256_rank0": dig.hexdigest(),
+        **({"oversubscribed": {"ranks": world, "device": local, "collectives": "gloo", "cpu_cores_busy_all_ranks": host_cpu,
+                               "note": "developer mode: the ranks of a --gpus N job all on ONE device: a host-contention proxy (N processes x engines share the CPUs as a node's ranks would), NOT a scaling measurement; value = aggregate of the ranks sharing that one GPU"}} if oversub else {}),
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
         "job_last_step": {"offered_frames": int(job[0]), "decoded_frames": int(job[1]), "rx_calls": int(job[2]), "sync_calls": int(job[3]),
                           "search_calls": int(job[4]), "eoo_detected_streams": int(job[5])},

@@ -76,3 +76,18 @@ def test_ranks_of_a_node_tell_the_wait_policy_about_each_other():
     lib = engine.load_library()
     lib.rade_sync_policy.argtypes = [C.c_int, C.c_double]
     assert lib.rade_sync_policy(3 * 8, 16.0) == 1 and lib.rade_sync_policy(3 * 1, 16.0) == 0
+
+
+def test_oversubscribe_developer_mode_plan():
+    """`bench.py --gpus 8 --oversubscribe-device 0`: the eight ranks of an 8-GPU job on ONE device (host-contention proxy): spawned under
+    torch.distributed.run although a single device is visible; refused when the device does not exist; a rank of it checks WORLD_SIZE against --gpus."""
+    mode, cmd = bench.launch_plan(8, {}, 1, ["--gpus", "8", "--oversubscribe-device", "0"], port=29512, oversubscribe=0)
+    assert mode == "spawn" and "--nproc-per-node=8" in cmd and cmd[-4:] == ["--gpus", "8", "--oversubscribe-device", "0"]
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "5", "LOCAL_RANK": "5"}, 1, [], oversubscribe=0) == ("inprocess", None)
+    with pytest.raises(SystemExit):
+        bench.launch_plan(8, {"WORLD_SIZE": "4"}, 1, [], oversubscribe=0)
+    with pytest.raises(SystemExit):
+        bench.launch_plan(8, {}, 1, [], oversubscribe=1)
+    with pytest.raises(SystemExit):
+        bench.launch_plan(8, {}, 0, [], oversubscribe=0)
+    assert bench.launch_plan(1, {}, 1, [], oversubscribe=0) == ("inprocess", None)
