@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--as-shard", type=str, default=None, metavar="R/N", help="developer mode: a single process takes the utterance shard rank R of an N-rank job would own (its results must equal that rank's)")
     ap.add_argument("--oversubscribe-device", type=int, default=None, metavar="D",
                     help="developer mode: run the --gpus N ranks of an N-GPU job all on HIP device D (gloo for the two collectives): what N processes x 3 engines cost the HOST; not a scaling measurement")
     args = ap.parse_args()
@@ -205,6 +206,10 @@ def main():
     # ---- synthetic inputs, resident in HBM before the clock starts.  Utterance u uses seeds 1000 + u / 5000 + u; rank r owns the
     # contiguous shard [r B, r B + B) of the B x world utterances
     u0, u1 = shard_range(B * world, rank, world)
+    if args.as_shard:
+        assert world == 1
+        sr, sn = (int(v) for v in args.as_shard.split("/"))
+        u0, u1 = shard_range(B * sn, sr, sn)
     assert u1 - u0 == B
     feats_np = np.stack([synth_features(1000 + u, T) for u in range(u0, u1)])
     feats = torch.tensor(feats_np, device=dev)
@@ -307,12 +312,15 @@ def main():
     fo_host = fo.cpu().numpy()
     for b in range(B):
         dig.update(np.ascontiguousarray(fo_host[b, :st[b].n_valid]).tobytes())
-    host_cpu = None
+    host_cpu = None; all_digests = [dig.hexdigest()]
     if world > 1:
         import torch.distributed as dist
         mine = torch.tensor([cpu_s / dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
         host_cpu = float(mine.item())
+        dg = [torch.zeros(32, dtype=torch.uint8, device=coll_dev) for _ in range(world)]
+        dist.all_gather(dg, torch.tensor(list(dig.digest()), dtype=torch.uint8, device=coll_dev))
+        all_digests = [bytes(d.cpu().tolist()).hex() for d in dg]
 
     out = {
         "metric": "vocoder-feature frames/sec (enc+chan+dec), model19", "value": value, "unit": "frames/s", "n_gpus": 1 if oversub else world, "steps": args.steps,
@@ -326,7 +334,7 @@ def main():
         "value_counts": "offered feature frames: every transmitted frame's samples pass through the receiver, decoded or not",
         "decoded_frames_per_s": value * job[1] / job[0],
         "timed_region_s": dt, "value_repeats": [B * T * args.steps * world / r[0] for r in reps], "timed_region_s_repeats": [r[0] for r in reps],
-        "launcher": launcher, "rccl_ranks": ranks_seen, "last_step_features_sha256_rank0": dig.hexdigest(),
+        "launcher": launcher, "rccl_ranks": ranks_seen, "last_step_features_sha256_rank0": all_digests[0], "last_step_features_sha256_per_rank": all_digests, "utterances": [u0, u1],
         **({"oversubscribed": {"ranks": world, "device": local, "collectives": "gloo", "cpu_cores_busy_all_ranks": host_cpu,
                                "note": "developer mode: the ranks of a --gpus N job all on ONE device: a host-contention proxy (N processes x engines share the CPUs as a node's ranks would), NOT a scaling measurement; value = aggregate of the ranks sharing that one GPU"}} if oversub else {}),
         "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
