@@ -4,7 +4,7 @@
 # tools/make_profile_summary.py (run it afterwards in the repo).  Usage: bash tools/collect_profiles.sh [tag]
 # a rocprofv3 run that aborts can hang until the box's limit (round 5: 30 GPU-minutes lost on an unknown counter name): every run is bounded
 rocprofv3() { timeout -k 10 ${RP_TIMEOUT:-420} "$(which rocprofv3)" "$@"; }
-TAG=${1:-r04}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
