@@ -126,3 +126,66 @@ class radae_rx:
             floats_out[:] = 0
             floats_out[:self._eoo.size] = self._eoo        # radae_rxe.py:321-323
         return (1 if n else 0) | (2 if has_eoo.value else 0)
+
+
+# ---- the reference's bypass modes (radae_txe.py --bypass_enc, radae_rxe.py --bypass_dec): an external core encoder / decoder sits on the other side --------------------
+# rade_api.h has no switch for them (the reference's rade_api.c uses them internally with its C core, :421-431, :491-513), so these two classes drive a one-stream
+# batched engine (include/rade_batch.h: rade_batch_tx_latents, RADE_BATCH_BYPASS_DEC) behind the reference classes' method names.
+class radae_tx_bypass_enc:
+    """radae_txe.radae_tx(..., bypass_enc=True): 3 x 80 latents in (n_floats_in = 240, radae_txe.py:67-69) -> 960 IQ samples out per call."""
+
+    def __init__(self, model_name: str = "", txbpf_en: bool = False, device: int = 0):
+        import torch
+        self.eng = engine.BatchEngine(1, max_tx_mf=2, device=device, blob=model_name or None, flags=engine.TX_BPF if txbpf_en else 0)
+        self._torch, self.dev = torch, torch.device("cuda", device)
+        self.n_floats_in, self.Nmf, self.Neoo, self.txbpf_en, self.bypass_enc = engine.ZMF, engine.NMF, engine.NEOO, bool(txbpf_en), True
+
+    def get_n_floats_in(self): return self.n_floats_in
+    def get_Nmf(self): return self.Nmf
+    def get_Neoo(self): return self.Neoo
+    def get_Neoo_bits(self): return engine.NEOO_BITS
+    def set_eoo_bits(self, eoo_bits): self.eng.set_eoo_bits(np.ascontiguousarray(eoo_bits, dtype=np.float32).reshape(1, -1))
+
+    def do_radae_tx(self, buffer_f32, tx_out):
+        z = np.ascontiguousarray(buffer_f32, dtype=np.float32)
+        assert z.size == self.n_floats_in and tx_out.dtype == np.complex64 and tx_out.size == self.Nmf
+        tx_out[:] = self.eng.tx_latents(self._torch.tensor(z.reshape(1, 3, 80), device=self.dev)).cpu().numpy()[0]
+
+    def do_eoo(self, tx_out):
+        assert tx_out.dtype == np.complex64 and tx_out.size == self.Neoo
+        tx_out[:] = self.eng.tx_eoo().cpu().numpy()[0]
+
+
+class radae_rx_bypass_dec:
+    """radae_rxe.radae_rx(..., bypass_dec=True): `get_nin()` samples in per call; a valid call writes the modem frame's 240 equalised latents (n_floats_out = 240,
+    radae_rxe.py:121-123, :315), an end-of-over call the EOO soft bits; the UW errors are never summed (:300-312); returns valid | endofover << 1."""
+
+    def __init__(self, model_name: str = "", foff_err: float = 0.0, disable_unsync: float = 0.0, device: int = 0):
+        import torch
+        self.eng = engine.BatchEngine(1, max_tx_mf=1, device=device, blob=model_name or None, flags=engine.BYPASS_DEC | (RADE_FOFF_TEST if foff_err else 0), disable_unsync=disable_unsync)
+        self._torch, self.dev = torch, torch.device("cuda", device)
+        self.n_floats_out, self.bypass_dec = engine.ZMF, True
+        self._nin, self._sync, self._snr = engine.NMF, 0, 0
+        self._rows = torch.zeros((1, 1, engine.ZMF), dtype=torch.float32, device=self.dev)
+        self._eoo = torch.zeros((1, engine.NEOO_BITS), dtype=torch.float32, device=self.dev)
+
+    def get_n_floats_out(self): return self.n_floats_out
+    def get_nin_max(self): return engine.NIN_MAX
+    def get_nin(self): return self._nin
+    def get_sync(self): return bool(self._sync)
+    def get_snrdB_3k_est(self): return self._snr
+    def get_Neoo_bits(self): return engine.NEOO_BITS
+
+    def do_radae_rx(self, buffer_complex, floats_out):
+        x = np.ascontiguousarray(buffer_complex, dtype=np.complex64)
+        assert x.size >= self._nin and floats_out.dtype == np.float32 and floats_out.size == self.n_floats_out
+        _, st, _ = self.eng.rx(self._torch.tensor(x[None, :self._nin], device=self.dev), max_calls=1, features_out=self._rows, eoo_out=self._eoo)
+        s = st[0]
+        assert s.n_calls == 1
+        self._nin, self._sync, self._snr = s.nin, s.sync, s.snr_dB
+        if s.n_valid:
+            floats_out[:] = self._rows.cpu().numpy()[0, 0]
+        if s.has_eoo:
+            floats_out[:] = 0
+            floats_out[:engine.NEOO_BITS] = self._eoo.cpu().numpy()[0]      # radae_rxe.py:321-323
+        return (1 if s.n_valid else 0) | (2 if s.has_eoo else 0)

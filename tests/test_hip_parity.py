@@ -291,6 +291,23 @@ def test_bypass_dec_and_bypass_enc(Engine, torch_dev, golden):
     tx = eng.tx_latents(torch.tensor(g["z_in"].reshape(1, 18, 80), device=torch_dev)).cpu().numpy().reshape(6, 960)
     assert np.abs(tx - g["tx"]).max() < 2e-5 and rms(tx, g["tx"]) < 5e-6
     eng.close()
+    # the reference classes' own call pattern (radae_rxe.py:349-356, radae_txe.py:165-176) through the Python mirrors of the bypass modes
+    from radae_amd import api
+    rxb = api.radae_rx_bypass_dec()
+    fo = np.zeros(rxb.get_n_floats_out(), np.float32); assert fo.size == 240
+    x, pos, rets, zs = g["rx_in"], 0, [], []
+    while pos + rxb.get_nin() <= len(x):
+        nin = rxb.get_nin(); ret = rxb.do_radae_rx(x[pos:pos + nin], fo); pos += nin; rets.append(ret)
+        if ret & 1: zs.append(fo.copy())
+        if ret & 2: assert np.array_equal(fo[:180] > 0, g["eoo_out"][-1] > 0)
+    assert np.array_equal(np.array(rets), g["ret"]) and rms(np.array(zs), g["z_hat_out"]) < 1e-4
+    rxb.eng.close()
+    txb = api.radae_tx_bypass_enc()
+    out = np.zeros(960, np.complex64)
+    for k in range(6):
+        txb.do_radae_tx(g["z_in"][k], out)
+        assert np.abs(out - g["tx"][k]).max() < 2e-5
+    txb.eng.close()
     # the same latents through an engine with the Tx band-pass filter differ (the filter is applied), and the decoder-side default is untouched
     plain = Engine(1, max_tx_mf=6, rx_trace_calls=64)
     f, stp, _ = plain.rx(torch.tensor(g["rx_in"][None], device=torch_dev))
