@@ -1236,6 +1236,39 @@ def test_bbfm_config5(Engine, torch_dev, golden):
     eng.close()
 
 
+def test_bbfm_config5_over_the_lmr60_channel(Engine, torch_dev, oracle):
+    """SURVEY 8(d) config 5, its fading variant: BBFM at batch 256 through the land-mobile channel of multipath_samples.m:17-21 ("lmr60": 60 km/h at 450 MHz, fd = 25 Hz),
+    |H| at the 2000 symbols/s rate generated ON THE DEVICE (multipath_h_gen) per stream: encoder (bottleneck 1) -> FM-demodulator channel with that H and supplied noise ->
+    decoder, three streams against the oracle on the same H and noise (bbfm.py:157-197)."""
+    import os
+    import torch
+    from radae_amd.engine import DEFAULT_BLOB
+    blob = os.path.join(os.path.dirname(DEFAULT_BLOB), "bbfm_random_seed20240501.bin")
+    B, T = 256, 72
+    rng = np.random.default_rng(515)
+    feats = (0.7 * rng.standard_normal((B, T, 80))).astype(np.float32)
+    eng = Engine(B, max_tx_mf=T // 3, blob=blob, flags=0x100)
+    z = eng.encode(torch.tensor(feats, device=torch_dev))
+    H = eng.multipath_h_gen("lmr60", T * 80, seed=99)                       # [B, T * 80, 1]: one |H| per real symbol
+    Hn = H.cpu().numpy()[:, :, 0]
+    assert 0.7 < float(np.mean(Hn.astype(np.float64) ** 2)) < 1.3 and float((20 * np.log10(Hn) + 14.0 < 12).mean()) > 0.2      # a fading channel: a good part of the symbols below the FM threshold at 14 dB
+    noise = rng.standard_normal((B, T * 80)).astype(np.float32)
+    Gfm = 13.467874862246564                                                # bbfm.py's FM gain for the default deviation (tests/golden/bbfm.npz: Gfm)
+    zh = eng.channel_symbol(z, "bbfm", 14.0, Gfm, H=H.reshape(B, T * 80).contiguous(), noise=torch.tensor(noise, device=torch_dev))
+    fh = eng.decode(zh, 80).cpu().numpy()
+    zc, zhc = z.cpu().numpy(), zh.cpu().numpy()
+    m = oracle.Model(blob)
+    for b in (0, 131, 255):
+        enc, dec = oracle.Encoder(m), oracle.Decoder(m)
+        zo = np.array([enc.step(feats[b, t], bottleneck=1) for t in range(T)])
+        assert np.abs(zc[b] - zo).max() < 2e-5
+        zho = oracle.channel_bbfm(zc[b], Hn[b], noise[b], 14.0, Gfm).reshape(T, 80)
+        assert np.abs(zhc[b] - zho).max() < 5e-6
+        fo = np.array([dec.step(zhc[b, t]) for t in range(T)])
+        assert rms(fh[b], fo) < 1e-4
+    eng.close()
+
+
 @pytest.mark.parametrize("blobname,mode", [("model05.bin", "rs"), ("bbfm_random_seed20240501.bin", "bbfm")])
 def test_configs_1_and_5_at_batch_256_split_f16_gemm(Engine, torch_dev, oracle, blobname, mode):
     """BASELINE configs 1 and 5 at their stated batch (256 streams): with more than 16 k GEMM rows the 80-wide-input blobs run the
