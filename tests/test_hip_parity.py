@@ -1538,3 +1538,24 @@ def test_sc_wire_filters_match_reference_scripts(golden):
     assert zh.shape == g["zhat"].shape and np.abs(zh - g["zhat"]).max() < 2e-5 * max(1.0, np.abs(g["zhat"]).max())
     zh2 = sc_rx_stream(t)                                  # our own samples: +-1 LSB differences only
     assert zh2.shape == g["zhat"].shape and np.abs(zh2 - g["zhat"]).max() < 2e-3
+
+
+def test_config4_sharding_two_ranks_on_one_device():
+    """The N > 1 path of bench.py on the GPU there is: two ranks under torch.distributed.run, both on device 0 (--oversubscribe-device: gloo for the blob broadcast
+    and the statistics all-reduce), utterances sharded [0, 16) / [16, 32) as `--gpus 2` shards them; each rank's decoded features (sha256 of the last step) equal a single
+    process run on that rank's shard (--as-shard r/2), and the job-wide counts are the sums.  tools/oversub8.sh is the same at 8 x 256 utterances (profiles/r06_oversub8.json)."""
+    import json, subprocess, sys
+    common = ["--streams", "16", "--frames", "240", "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-roofline", "--no-parity"]
+    def run(extra):
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + extra + common, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    job = run(["--gpus", "2", "--oversubscribe-device", "0"])
+    assert job["oversubscribed"]["ranks"] == 2 and job["rccl_ranks"] == 2 and job["config"]["global_streams"] == 32 and len(job["last_step_features_sha256_per_rank"]) == 2
+    shards = [run(["--as-shard", f"{r}/2"]) for r in range(2)]
+    assert [s["utterances"] for s in shards] == [[0, 16], [16, 32]]
+    assert job["last_step_features_sha256_per_rank"] == [s["last_step_features_sha256_rank0"] for s in shards]
+    assert shards[0]["last_step_features_sha256_rank0"] != shards[1]["last_step_features_sha256_rank0"]
+    for k in ("offered_frames", "decoded_frames", "rx_calls", "sync_calls", "search_calls"):
+        assert job["job_last_step"][k] == shards[0]["job_last_step"][k] + shards[1]["job_last_step"][k], k
+    assert job["job_last_step"]["decoded_frames"] > 0
