@@ -156,19 +156,21 @@ class radae_tx_bypass_enc:
         tx_out[:] = self.eng.tx_eoo().cpu().numpy()[0]
 
 
-class radae_rx_bypass_dec:
-    """radae_rxe.radae_rx(..., bypass_dec=True): `get_nin()` samples in per call; a valid call writes the modem frame's 240 equalised latents (n_floats_out = 240,
-    radae_rxe.py:121-123, :315), an end-of-over call the EOO soft bits; the UW errors are never summed (:300-312); returns valid | endofover << 1."""
+class radae_rx_engine:
+    """radae_rxe.radae_rx over a one-stream batched engine instead of the rade_api.h handle: the form that also offers what the C ABI has no switch for --
+    `disable_unsync` (radae_rxe.py --disable_unsync) and, in the subclass below, `bypass_dec`.  Same methods and return convention as `radae_rx`."""
+    _flags, _row = 0, engine.FEAT_MF
 
     def __init__(self, model_name: str = "", foff_err: float = 0.0, disable_unsync: float = 0.0, device: int = 0):
         import torch
-        self.eng = engine.BatchEngine(1, max_tx_mf=1, device=device, blob=model_name or None, flags=engine.BYPASS_DEC | (RADE_FOFF_TEST if foff_err else 0), disable_unsync=disable_unsync)
+        self.eng = engine.BatchEngine(1, max_tx_mf=1, device=device, blob=model_name or None, flags=self._flags | (RADE_FOFF_TEST if foff_err else 0), disable_unsync=disable_unsync)
         self._torch, self.dev = torch, torch.device("cuda", device)
-        self.n_floats_out, self.bypass_dec = engine.ZMF, True
+        self.n_floats_out, self.bypass_dec = self._row, bool(self._flags & engine.BYPASS_DEC)
         self._nin, self._sync, self._snr = engine.NMF, 0, 0
-        self._rows = torch.zeros((1, 1, engine.ZMF), dtype=torch.float32, device=self.dev)
+        self._rows = torch.zeros((1, 1, self._row), dtype=torch.float32, device=self.dev)
         self._eoo = torch.zeros((1, engine.NEOO_BITS), dtype=torch.float32, device=self.dev)
 
+    def get_n_features_out(self): return self.n_floats_out
     def get_n_floats_out(self): return self.n_floats_out
     def get_nin_max(self): return engine.NIN_MAX
     def get_nin(self): return self._nin
@@ -189,3 +191,9 @@ class radae_rx_bypass_dec:
             floats_out[:] = 0
             floats_out[:engine.NEOO_BITS] = self._eoo.cpu().numpy()[0]      # radae_rxe.py:321-323
         return (1 if s.n_valid else 0) | (2 if s.has_eoo else 0)
+
+
+class radae_rx_bypass_dec(radae_rx_engine):
+    """radae_rxe.radae_rx(..., bypass_dec=True): `get_nin()` samples in per call; a valid call writes the modem frame's 240 equalised latents (n_floats_out = 240,
+    radae_rxe.py:121-123, :315), an end-of-over call the EOO soft bits; the UW errors are never summed (:300-312); returns valid | endofover << 1."""
+    _flags, _row = engine.BYPASS_DEC, engine.ZMF

@@ -1559,3 +1559,35 @@ def test_config4_sharding_two_ranks_on_one_device():
     for k in ("offered_frames", "decoded_frames", "rx_calls", "sync_calls", "search_calls"):
         assert job["job_last_step"][k] == shards[0]["job_last_step"][k] + shards[1]["job_last_step"][k], k
     assert job["job_last_step"]["decoded_frames"] > 0
+
+
+def test_python_cli_filters_like_the_reference_tools(golden, tmp_path):
+    """`python -m radae_amd.cli txe | rxe` in place of `python3 radae_txe.py | radae_rxe.py` (radae_txe.py:146-180, radae_rxe.py:332-371), three of the reference's pipelines:
+    (i) ctest radae_eoo_data_py (CMakeLists.txt:578-583): features -> txe --eoo_data_test -> rxe --eoo_data_test prints the BER line and PASS, eoo_tx.f32 is written;
+    (ii) the transmit samples equal the golden ones (enc_tx.npz), the EOO frame follows; (iii) ctest radae_rx_slip_plus_drops (:397-407): the 61 s int16 file through
+    `int16tof32 --zeropad | rxe`, last stderr line `state: sync`; (iv) txe | rxe --bypass_dec writes 240 floats per valid frame."""
+    import subprocess, sys
+    from radae_amd import wire
+    env = dict(os.environ); env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    def run(args, data):
+        r = subprocess.run([sys.executable, "-m", "radae_amd.cli"] + args, input=data, capture_output=True, cwd=str(tmp_path), env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        return r.stdout, r.stderr.decode()
+    e = golden("enc_tx")
+    feats = e["features"][0].astype(np.float32)                           # (120, 36): ten modem frames
+    iq, _ = run(["txe", "--eoo_data_test"], feats.tobytes())
+    iq = np.frombuffer(iq, np.complex64)
+    assert iq.size == 10 * 960 + 1152 and np.abs(iq[:9600].reshape(10, 960) - e["tx"][0]).max() < 2e-5
+    bits = np.fromfile(str(tmp_path / "eoo_tx.f32"), np.float32)
+    rng = np.random.default_rng(65647)
+    assert np.array_equal(bits, np.sign(rng.random(180) - 0.5).astype(np.float32))
+    rx_in = np.concatenate([np.zeros(960, np.complex64), iq, np.zeros(2400, np.complex64)])
+    fo, err = run(["rxe", "--eoo_data_test"], rx_in.tobytes())
+    assert "EOO data n_bits: 180 n_errors: 0 BER:  0.00" in err and "PASS" in err
+    n_valid = len(fo) // (432 * 4)
+    assert n_valid >= 6 and len(fo) % (432 * 4) == 0
+    zo, _ = run(["rxe", "--bypass_dec", "-v", "0"], rx_in.tobytes())
+    assert len(zo) == n_valid * 240 * 4
+    g = golden("rxtrace_slipdrops")
+    _, err = run(["rxe", "-v", "1", "--no_stdout"], wire.int16_to_f32(g["rx_i16"].tobytes(), zeropad=True))
+    assert err.strip().splitlines()[-1] == "state: sync"
