@@ -31,3 +31,50 @@ def find_loss(features: np.ndarray, features_hat: np.ndarray):
         if l < best:
             best, start = l, s
     return best, start
+
+
+def main(argv=None) -> int:
+    """The command line of the reference's loss.py (:36-112, without --plot): time-aligned loss between two `.f32` feature files, PASS / FAIL against thresholds;
+    what its ctests run after every receive pipeline (`python3 loss.py features_in.f32 features_out.f32 --loss_test 0.15 --acq_time_test 0.5 --clip_end 100`)."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="radae_amd.loss")
+    ap.add_argument("features", type=str, help="path to input feature file in .f32 format")
+    ap.add_argument("features_hat", type=str, help="path to output feature file in .f32 format")
+    ap.add_argument("--features_hat2", type=str, help="path to optional 2nd features file to compare two runs")
+    ap.add_argument("--loss_test", type=float, default=0.0, help="compare loss to arg, print PASS/FAIL")
+    ap.add_argument("--acq_time_test", type=float, default=0, help="compare acquisition time to threshold arg, print PASS/FAIL")
+    ap.add_argument("--clip_start", type=int, default=0)
+    ap.add_argument("--clip_end", type=int, default=0)
+    ap.add_argument("--compare", action="store_true", help="compare features_hat and features_hat2")
+    args = ap.parse_args(argv)
+
+    def load(fn):
+        f = np.fromfile(fn, np.float32)
+        return f.reshape(-1, 36)
+
+    def one(fn_hat):
+        f, h = load(args.features), load(fn_hat)
+        h = h[args.clip_start:len(h) - args.clip_end]
+        loss, start = find_loss(f, h)
+        print(f"Loss between {args.features:s} and {fn_hat:s}")
+        print(f"  loss: {loss:5.3f} start: {start:d} acq_time: {start * 0.01:5.2f} s")
+        return loss, start
+
+    loss, start = one(args.features_hat)
+    if args.loss_test > 0.0 and loss > args.loss_test:
+        print("FAIL"); return 0                            # (the reference prints and quits with status 0; its ctests grep for PASS)
+    if args.acq_time_test > 0 and start * 0.01 > args.acq_time_test:
+        print("FAIL"); return 0
+    if args.loss_test > 0.0 or args.acq_time_test:
+        print("PASS")
+    if args.features_hat2:
+        loss2, _ = one(args.features_hat2)
+        if args.compare:
+            print(f"loss1: {loss:5.3f} loss2: {loss2:5.3f} delta: {abs(loss - loss2):5.3f}")
+            if abs(loss - loss2) < 0.01:
+                print("PASS")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

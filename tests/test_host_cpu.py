@@ -587,3 +587,22 @@ def test_sleeping_wait_estimate_recovers_from_an_outlier(lib):
             calls_to_recover = k + 1
     assert total < 40000.0 and calls_to_recover is not None and calls_to_recover < 10, (total, calls_to_recover)
     assert 1400.0 < est.value < 3500.0
+
+
+def test_loss_command_line(golden, tmp_path, capsys):
+    """`python -m radae_amd.loss` = the reference's loss.py command line (:36-112): aligned loss, acquisition time, PASS / FAIL, --compare; on the awgn trace's features
+    (the reference's own receiver output) the printed loss is find_loss's and the thresholds behave like the ctests use them (CMakeLists.txt:300-420)."""
+    from radae_amd import loss
+    g = golden("rxtrace_awgn")
+    fi, fo = g["features_in"].astype(np.float32), g["features_out"].reshape(-1, 36).astype(np.float32)
+    a, b = str(tmp_path / "features_in.f32"), str(tmp_path / "features_out.f32")
+    fi.tofile(a); fo.tofile(b)
+    want, start = loss.find_loss(fi, fo)
+    assert loss.main([a, b, "--loss_test", "10.0", "--acq_time_test", "10.0"]) == 0
+    out = capsys.readouterr().out
+    assert f"  loss: {want:5.3f} start: {start:d} acq_time: {start * 0.01:5.2f} s" in out and out.strip().endswith("PASS")
+    loss.main([a, b, "--loss_test", "1e-6"]); assert capsys.readouterr().out.strip().endswith("FAIL")
+    if start > 0:
+        loss.main([a, b, "--acq_time_test", str(start * 0.01 / 2)]); assert capsys.readouterr().out.strip().endswith("FAIL")
+    loss.main([a, b, "--features_hat2", b, "--compare", "--clip_end", "12"]); out = capsys.readouterr().out
+    assert "delta: 0.0" in out and out.strip().endswith("PASS")
