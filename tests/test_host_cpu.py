@@ -606,3 +606,17 @@ def test_loss_command_line(golden, tmp_path, capsys):
         loss.main([a, b, "--acq_time_test", str(start * 0.01 / 2)]); assert capsys.readouterr().out.strip().endswith("FAIL")
     loss.main([a, b, "--features_hat2", b, "--compare", "--clip_end", "12"]); out = capsys.readouterr().out
     assert "delta: 0.0" in out and out.strip().endswith("PASS")
+
+
+def test_eoo_ber_tool(golden, tmp_path, capsys):
+    """`python -m radae_amd.wire eoo_ber eoo_tx.f32 eoo_rx.f32` = the reference's eoo_ber.py on the five end-of-over frames the reference receiver decoded through MPP
+    (rxtrace_eoo_mpp.npz; ctest radae_eoo_data_mpp: one frame below 5 % is a PASS)."""
+    from radae_amd import wire
+    g = golden("rxtrace_eoo_mpp")
+    a, b = str(tmp_path / "eoo_tx.f32"), str(tmp_path / "eoo_rx.f32")
+    g["tx_bits"].astype(np.float32).tofile(a); g["eoo_out"].astype(np.float32).tofile(b)
+    bers, n_ok = wire.eoo_ber(g["tx_bits"], g["eoo_out"].ravel())
+    assert np.allclose(bers, g["eoo_ber"]) and n_ok == int((g["eoo_ber"] < 0.05).sum()) >= 1
+    assert wire.main(["eoo_ber", a, b]) == 0
+    cap = capsys.readouterr()
+    assert cap.out.count("frame received!") == 5 and "EOO frames  received: 5 n_ok_frames: 1" in cap.err and cap.err.strip().endswith("PASS")
