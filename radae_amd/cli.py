@@ -4,6 +4,9 @@
     python -m radae_amd.cli rxe [--bypass_dec] [--disable_unsync S] [--foff_err HZ] [--eoo_data_test] [--no_stdout] [-v N] [--model_name BLOB]
                                                                                                      IQ.f32 -> features.f32 (or z_hat.f32)  /root/reference/radae_rxe.py:332-371
 
+    python -m radae_amd.cli inference MODEL features.f32 features_hat.f32 --EbNodB .. [--g_file g.f32] --write_rx rx.f32 [...]    the channel-simulation run of inference.py (rate Fs)
+    python -m radae_amd.cli multipath_samples mpp 8000 50 30 10 h.f32 g.f32                                                      multipath_samples.m
+
 so that the reference's shell pipelines (`cat features_in.f32 | python3 radae_txe.py > rx.f32`, `cat rx.f32 | python3 radae_rxe.py > features_out.f32`: CMakeLists.txt:300-420) run with
 `python3 -m radae_amd.cli txe|rxe` in their place.  Everything computes in libradehip.so on the GPU (radae_amd/api.py over include/rade_api.h; the bypass modes over a one-stream
 batched engine); `--model_name` takes a DNNw blob (the reference's `.pth` checkpoints are not in its tree), default weights/model19_check3.bin.  `--noauxdata` is not offered: model19_check3 has the aux symbol.
@@ -93,12 +96,110 @@ def _rxe(argv):
     return 0
 
 
+def _inference(argv):
+    """inference.py's rate-Fs channel-simulation run as the streaming ctests use it (`inference.sh model wav /dev/null --EbNodB .. --freq_offset .. [--df_dt ..] [--g_file g.f32]
+    --rate_Fs --pilots --pilot_eq --eq_ls --cp 0.004 --bottleneck 3 --time_offset -16 --auxdata --write_rx rx.f32 [--prepend_noise s] [--append_noise s] [--end_of_over]
+    [--sine_amp a --sine_freq f] [--rx_gain g] [--write_tx tx.f32]`, CMakeLists.txt:300-420; inference.py:43-79, :253-300): encoder + OFDM modulator, the two-path Doppler
+    channel from a `g_file` (multipath_samples' format: gain sample, then ..G1G2..), AWGN at the Eb/No, frequency offset / drift, the write_rx tail.  The model-shape switches
+    (--rate_Fs --pilots --pilot_eq --eq_ls --cp --bottleneck --time_offset --auxdata --correct_freq_offset --coarse_mag --latent-dim) are accepted and must describe model19_check3's
+    waveform, the only one this path implements.  `features_hat` receives what the STREAMING receiver (radae_rxe's) decodes from the written samples -- the reference runs its
+    stateless receiver with ideal timing there; the ctests of this path pass /dev/null.  Noise: the device's Philox generator (--seed), not torch's."""
+    import torch
+    from . import engine, wire
+    from .loss import find_loss
+    ap = argparse.ArgumentParser(prog="radae_amd.cli inference")
+    ap.add_argument("model_name"); ap.add_argument("features"); ap.add_argument("features_hat")
+    ap.add_argument("--EbNodB", type=float, default=100.0); ap.add_argument("--g_file", type=str, default=""); ap.add_argument("--write_rx", type=str, default="")
+    ap.add_argument("--rx_gain", type=float, default=1.0); ap.add_argument("--write_tx", type=str, default=""); ap.add_argument("--freq_offset", type=float, default=0.0)
+    ap.add_argument("--df_dt", type=float, default=0.0); ap.add_argument("--prepend_noise", type=float, default=0.0); ap.add_argument("--append_noise", type=float, default=0.0)
+    ap.add_argument("--end_of_over", action="store_true"); ap.add_argument("--sine_amp", type=float, default=0.0); ap.add_argument("--sine_freq", type=float, default=1000.0)
+    ap.add_argument("--loss_test", type=float, default=0.0); ap.add_argument("--seed", type=int, default=1)
+    for flag in ("--rate_Fs", "--pilots", "--pilot_eq", "--eq_ls", "--auxdata", "--correct_freq_offset", "--coarse_mag"):
+        ap.add_argument(flag, action="store_true")
+    ap.add_argument("--cp", type=float, default=0.004); ap.add_argument("--bottleneck", type=int, default=3); ap.add_argument("--time_offset", type=int, default=-16)
+    ap.add_argument("--latent-dim", type=int, default=80)
+    args = ap.parse_args(argv)
+    if args.bottleneck != 3 or abs(args.cp - 0.004) > 1e-9 or args.time_offset != -16 or args.latent_dim != 80:
+        raise SystemExit("radae_amd.cli inference: only model19_check3's waveform (--rate_Fs --pilots --pilot_eq --eq_ls --cp 0.004 --bottleneck 3 --time_offset -16 --auxdata) is implemented")
+    blob = args.model_name if args.model_name.endswith(".bin") else None
+    feats = wire.read_features(args.features)
+    n_mf = len(feats) // 12                                   # whole modem frames (radae.py:303-310)
+    feats = np.ascontiguousarray(feats[:12 * n_mf])
+    dev = torch.device("cuda", 0)
+    eng = engine.BatchEngine(1, max_tx_mf=n_mf, blob=blob)
+    iq = eng.tx(torch.tensor(feats[None], device=dev))
+    n_sig = n_mf * engine.NMF
+    G = None
+    if args.g_file:
+        g = np.fromfile(args.g_file, np.complex64).reshape(-1, 2)
+        mp_gain = np.real(g[0, 0]); g = (mp_gain * g[1:]).astype(np.complex64)          # inference.py:160-171
+        if len(g) < n_sig:
+            raise SystemExit("Multipath Doppler spread file too short")
+        G = torch.tensor(np.ascontiguousarray(g[:n_sig])[None], device=dev)
+    sigma = engine.sigma_from_EbNodB(args.EbNodB)
+    n_pre, n_post = int(8000 * args.prepend_noise), int(8000 * args.append_noise)
+    rx = eng.channel(iq, sigma, args.freq_offset, n_pre=n_pre, n_post=n_post, with_eoo=args.end_of_over, G=G, seed=args.seed, df_dt=args.df_dt,
+                     sine_amp=args.sine_amp, sine_freq=args.sine_freq, rx_gain=args.rx_gain)
+    tx = iq.cpu().numpy()[0]
+    S = float(np.mean(np.abs(tx) ** 2)); N = sigma ** 2
+    EbNo = 10 ** (args.EbNodB / 10); Rb, Bw = 2000.0, 3000.0
+    print("          Eb/No   C/No     SNR3k  Rb'    Eq     PAPR")
+    print(f"Target..: {args.EbNodB:6.2f}  {10 * np.log10(EbNo * Rb):6.2f}  {10 * np.log10(EbNo * Rb / Bw):6.2f}  {2400:d}")
+    cno = 10 * np.log10(S * 8000.0 / N)
+    print(f"Measured: {cno + 10 * np.log10(160 / (8000.0 * 30 * 2)):6.2f}  {cno:6.2f}  {cno - 10 * np.log10(Bw):6.2f}                {20 * np.log10(np.max(np.abs(tx)) / np.sqrt(S)):5.2f}")
+    if args.write_rx:
+        rx.cpu().numpy()[0].astype(np.complex64).tofile(args.write_rx)
+    if args.write_tx:
+        tx.astype(np.complex64).tofile(args.write_tx)
+    fo, st, _ = eng.rx(rx if args.rx_gain == 1.0 else rx.clone())
+    nv = st[0].n_valid
+    fh = fo.cpu().numpy()[0, :nv].reshape(-1, 36)
+    if args.features_hat != "/dev/null":
+        fh.astype(np.float32).tofile(args.features_hat)
+    if nv:
+        loss, start = find_loss(feats, fh)
+        print(f"loss: {loss:5.3f} (streaming receiver: {12 * nv} frames decoded, aligned at frame {start})")
+        if args.loss_test > 0.0:
+            print("PASS" if loss < args.loss_test else "FAIL")
+    else:
+        print("loss: n/a (the streaming receiver decoded nothing)")
+    eng.close()
+    return 0
+
+
+def _multipath_samples(argv):
+    """multipath_samples.m's command line: `multipath_samples(ch, Fs, Rs, Nc, Nseconds, H_fn, G_fn="", H_complex=0)` -> the rate-Rs `H` file (magnitudes, or complex with
+    --complex) and the rate-Fs `G` file (gain sample, then ..G1G2.. complex64) that inference.py's --h_file / --g_file read.  numpy's generator instead of Octave's randn('seed', 1)."""
+    from .channel_tools import PRESETS
+    ap = argparse.ArgumentParser(prog="radae_amd.cli multipath_samples")
+    ap.add_argument("ch", choices=sorted(PRESETS)); ap.add_argument("Fs", type=int); ap.add_argument("Rs", type=int); ap.add_argument("Nc", type=int)
+    ap.add_argument("Nseconds", type=float); ap.add_argument("H_fn"); ap.add_argument("G_fn", nargs="?", default="")
+    ap.add_argument("--complex", action="store_true", dest="h_complex"); ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args(argv)
+    import math
+    from .channel_tools import doppler_spread
+    nsam = int(args.Fs * args.Nseconds)
+    rng = np.random.default_rng(args.seed)
+    g1 = doppler_spread(PRESETS[args.ch][0], args.Fs, nsam, rng); g2 = doppler_spread(PRESETS[args.ch][0], args.Fs, nsam, rng)      # the draws of channel_tools.multipath_g
+    hf_gain = 1.0 / math.sqrt(np.var(g1) + np.var(g2))                                 # multipath_samples.m:31
+    m = args.Fs // args.Rs
+    d = PRESETS[args.ch][1]
+    H = hf_gain * (g1[::m, None] + g2[::m, None] * np.exp(-2j * np.pi * np.arange(args.Nc)[None, :] * d * args.Rs))      # :33-40
+    (H.astype(np.complex64) if args.h_complex else np.abs(H).astype(np.float32)).tofile(args.H_fn)
+    if args.G_fn:                                                                      # :92-103: four floats of hf_gain, then ..G1G2.. UN-scaled (inference.py:160-171 multiplies)
+        out = np.concatenate([np.full((1, 2), hf_gain * (1 + 1j), np.complex64), np.stack([g1, g2], axis=1).astype(np.complex64)])
+        out.tofile(args.G_fn)
+    print(f"{args.ch}: Doppler spread {PRESETS[args.ch][0]:g} Hz, path delay {d * 1e3:g} ms, {len(H)} x {args.Nc} H samples" + (f", {nsam} G samples" if args.G_fn else ""))
+    return 0
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
-    if not argv or argv[0] not in ("txe", "rxe"):
+    cmds = {"txe": _txe, "rxe": _rxe, "inference": _inference, "multipath_samples": _multipath_samples}
+    if not argv or argv[0] not in cmds:
         print(__doc__, file=sys.stderr)
         return 2
-    return _txe(argv[1:]) if argv[0] == "txe" else _rxe(argv[1:])
+    return cmds[argv[0]](argv[1:])
 
 
 if __name__ == "__main__":

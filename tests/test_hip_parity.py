@@ -1591,3 +1591,34 @@ def test_python_cli_filters_like_the_reference_tools(golden, tmp_path):
     g = golden("rxtrace_slipdrops")
     _, err = run(["rxe", "-v", "1", "--no_stdout"], wire.int16_to_f32(g["rx_i16"].tobytes(), zeropad=True))
     assert err.strip().splitlines()[-1] == "state: sync"
+
+
+def test_ctest_pipeline_radae_rx_mpp_through_the_command_lines(tmp_path):
+    """The reference's ctest radae_rx_mpp (CMakeLists.txt:326-334) as a shell pipeline of this repo's command lines -- multipath_samples -> inference (--g_file, Eb/No 3 dB,
+    -11 Hz, prepend 1 s, append 3 s, end of over) -> rxe (--disable_unsync 5) -> loss (--loss_test, --acq_time_test) -- on synthetic features (no speech file exists here: out of distribution for the trained model, loss 0.7 in
+    loopback and ~2.2 at 3 dB MPP, so the threshold is a sanity bound, not the ctest's 0.3); and the same samples through the oracle receiver decode the same frames."""
+    import subprocess, sys
+    from radae_amd.channel_tools import synth_features
+    env = dict(os.environ); env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    def run(mod, args, stdin=None):
+        r = subprocess.run([sys.executable, "-m", mod] + args, input=stdin, capture_output=True, cwd=str(tmp_path), env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        return r.stdout, r.stderr.decode()
+    synth_features(4242, 600).tofile(str(tmp_path / "features_in.f32"))
+    out, _ = run("radae_amd.cli", ["multipath_samples", "mpp", "8000", "50", "30", "10", "h_mpp.f32", "g_mpp.f32"])
+    out, _ = run("radae_amd.cli", ["inference", "model19_check3", "features_in.f32", "/dev/null", "--EbNodB", "3", "--freq_offset", "-11", "--g_file", "g_mpp.f32", "--rate_Fs", "--pilots",
+                                   "--pilot_eq", "--eq_ls", "--cp", "0.004", "--bottleneck", "3", "--time_offset", "-16", "--write_rx", "rx.f32", "--prepend_noise", "1", "--append_noise", "3",
+                                   "--end_of_over", "--auxdata", "--correct_freq_offset"])
+    assert b"Target..:   3.00" in out and b"Measured:" in out
+    rx = np.fromfile(str(tmp_path / "rx.f32"), np.complex64)
+    assert rx.size == 8000 + 50 * 960 + 1152 + 24000
+    fo, err = run("radae_amd.cli", ["rxe", "--disable_unsync", "5", "-v", "1"], rx.tobytes())
+    (tmp_path / "features_rx_out.f32").write_bytes(fo)
+    n = len(fo) // (36 * 4)
+    assert n >= 12 * 30                                        # most of the 50 modem frames decoded at 3 dB MPP
+    out, _ = run("radae_amd.loss", ["features_in.f32", "features_rx_out.f32", "--loss_test", "4.0", "--acq_time_test", "1.5", "--clip_end", "100"])
+    assert out.decode().strip().endswith("PASS"), out.decode()
+    from oracle import oracle_py as O
+    O.build()
+    d = O.run_rx_stream(O.Model(), rx, 1, 0.0, 5.0)
+    assert len(d["features_out"]) * 12 == n and rms(np.frombuffer(fo, np.float32).reshape(-1, 432), d["features_out"]) < 1e-5
