@@ -6,6 +6,7 @@
 
     python -m radae_amd.cli inference MODEL features.f32 features_hat.f32 --EbNodB .. [--g_file g.f32] --write_rx rx.f32 [...]    the channel-simulation run of inference.py (rate Fs)
     python -m radae_amd.cli multipath_samples mpp 8000 50 30 10 h.f32 g.f32                                                      multipath_samples.m
+    python -m radae_amd.cli bbfm_inference MODEL features.f32 features_hat.f32 [--CNRdB ..] [--h_file h_lmr60.f32] [--write_latent z.f32]    bbfm_inference.py
 
 so that the reference's shell pipelines (`cat features_in.f32 | python3 radae_txe.py > rx.f32`, `cat rx.f32 | python3 radae_rxe.py > features_out.f32`: CMakeLists.txt:300-420) run with
 `python3 -m radae_amd.cli txe|rxe` in their place.  Everything computes in libradehip.so on the GPU (radae_amd/api.py over include/rade_api.h; the bypass modes over a one-stream
@@ -193,9 +194,65 @@ def _multipath_samples(argv):
     return 0
 
 
+def _bbfm_inference(argv):
+    """bbfm_inference.py (:43-170): features -> core encoder (bottleneck 1) -> the analog-FM channel model (bbfm.py:157-197: per-symbol CNR = 20 log10 |H| + CNRdB, FM demodulator SNR
+    with its threshold at 12 dB, noise, clamp) -> core decoder -> features_hat; `--h_file` = rate-Rs fading magnitudes (multipath_samples("lmr60", 8000, 2000, 1, ...)), `--write_latent`,
+    `--write_CNRdB`, `--loss_test`, `--passthru`.  `model_name`: a DNNw blob of the BBFM architecture (default weights/bbfm_random_seed20240501.bin: no trained BBFM weights exist in the
+    reference tree).  Noise: the device's Philox generator (--seed)."""
+    import math
+    import os
+    import torch
+    from . import engine, wire
+    from .loss import distortion_loss
+    ap = argparse.ArgumentParser(prog="radae_amd.cli bbfm_inference")
+    ap.add_argument("model_name"); ap.add_argument("features"); ap.add_argument("features_hat")
+    ap.add_argument("--latent-dim", type=int, default=80); ap.add_argument("--write_latent", type=str, default=""); ap.add_argument("--CNRdB", type=float, default=100.0)
+    ap.add_argument("--passthru", action="store_true"); ap.add_argument("--h_file", type=str, default=""); ap.add_argument("--write_CNRdB", type=str, default="")
+    ap.add_argument("--loss_test", type=float, default=0.0); ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args(argv)
+    feats = wire.read_features(args.features)
+    T = len(feats) // 4                                      # encoder steps of four frames (bbfm.py / radae_base.py:158)
+    feats = np.ascontiguousarray(feats[:4 * T])
+    if args.passthru:
+        feats.astype(np.float32).tofile(args.features_hat); return 0
+    blob = args.model_name if args.model_name.endswith(".bin") else os.path.join(os.path.dirname(engine.DEFAULT_BLOB), "bbfm_random_seed20240501.bin")
+    dev = torch.device("cuda", 0)
+    Tc = 3 * ((T + 2) // 3)
+    eng = engine.BatchEngine(1, max_tx_mf=Tc // 3, blob=blob, flags=engine.BOTTLENECK1)
+    x = np.zeros((1, Tc, 80), np.float32); x[0, :T] = feats[:, :20].reshape(T, 80)
+    z = eng.encode(torch.tensor(x, device=dev))
+    nsym = Tc * 80
+    H = None; Hn = np.ones(nsym, np.float32)
+    if args.h_file:
+        h = np.fromfile(args.h_file, np.float32)
+        if h.size < T * 80:
+            raise SystemExit("Multipath H file too short")
+        Hn[:T * 80] = h[:T * 80]; H = torch.tensor(Hn[None], device=dev)
+    Gfm = 10 * math.log10(3 * (5000 / 3000) ** 2 * (5000 / 3000 + 1))       # bbfm.py:78-80, fd 5000 Hz, fm 3000 Hz
+    zh = eng.channel_symbol(z, "bbfm", args.CNRdB, Gfm, H=H, seed=args.seed)
+    fh = eng.decode(zh, 80).cpu().numpy()[0, :T].reshape(4 * T, 20)
+    cnr = 20 * np.log10(Hn[:T * 80]) + args.CNRdB
+    snr = np.maximum(cnr - 12, 0) + 12 + Gfm - np.maximum(-(cnr - 12), 0) * (1 + Gfm / 3)      # bbfm.py:178-179
+    zhn = zh.cpu().numpy()[0, :T].ravel()
+    print(f"SNRdB Measured: {10 * np.log10(np.mean(zhn ** 2) / np.mean(10 ** (-snr / 10))):6.2f}")
+    out = np.zeros((4 * T, 36), np.float32); out[:, :20] = fh
+    if args.features_hat != "/dev/null":
+        out.tofile(args.features_hat)
+    loss = distortion_loss(feats[:, :20], fh)
+    print(f"loss: {loss:5.3f}")
+    if args.loss_test > 0.0:
+        print("PASS" if loss < args.loss_test else "FAIL")
+    if args.write_latent:
+        zhn.astype(np.float32).tofile(args.write_latent)
+    if args.write_CNRdB:
+        cnr.astype(np.float32).tofile(args.write_CNRdB)
+    eng.close()
+    return 0
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
-    cmds = {"txe": _txe, "rxe": _rxe, "inference": _inference, "multipath_samples": _multipath_samples}
+    cmds = {"txe": _txe, "rxe": _rxe, "inference": _inference, "multipath_samples": _multipath_samples, "bbfm_inference": _bbfm_inference}
     if not argv or argv[0] not in cmds:
         print(__doc__, file=sys.stderr)
         return 2

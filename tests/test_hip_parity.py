@@ -1622,3 +1622,28 @@ def test_ctest_pipeline_radae_rx_mpp_through_the_command_lines(tmp_path):
     O.build()
     d = O.run_rx_stream(O.Model(), rx, 1, 0.0, 5.0)
     assert len(d["features_out"]) * 12 == n and rms(np.frombuffer(fo, np.float32).reshape(-1, 432), d["features_out"]) < 1e-5
+
+
+def test_bbfm_inference_command_line(golden, tmp_path):
+    """`python -m radae_amd.cli bbfm_inference` = bbfm_inference.py (:43-170) on the BBFM golden's features: at CNR 100 dB (no channel noise to speak of) the written features_hat
+    equal the reference model's noise-free forward through the same de-quantised weights to 1e-4, the latents written by --write_latent equal its z; with the lmr60 |H| file made by
+    `multipath_samples lmr60 8000 2000 1 ..` (BBFM.md:37) and CNR 14 dB the loss rises and the per-symbol CNR file is 20 log10 |H| + 14."""
+    import subprocess, sys
+    env = dict(os.environ); env["PYTHONPATH"] = REPO + os.pathsep + env.get("PYTHONPATH", "")
+    def run(args):
+        r = subprocess.run([sys.executable, "-m", "radae_amd.cli"] + args, capture_output=True, cwd=str(tmp_path), env=env, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-1500:]
+        return r.stdout.decode()
+    g = golden("bbfm")
+    f36 = np.zeros((len(g["features"]), 36), np.float32); f36[:, :20] = g["features"]
+    f36.tofile(str(tmp_path / "features_in.f32"))
+    out = run(["bbfm_inference", "default", "features_in.f32", "features_hat.f32", "--CNRdB", "100", "--write_latent", "z.f32", "--loss_test", "5.0"])
+    assert "SNRdB Measured:" in out and out.strip().endswith("PASS")
+    z = np.fromfile(str(tmp_path / "z.f32"), np.float32).reshape(-1, 80)
+    assert np.abs(z - np.clip(g["z"], -1, 1)).max() < 1e-4                  # sigma at 113 dB SNR is 2e-6: z_hat = clamp(z)
+    run(["multipath_samples", "lmr60", "8000", "2000", "1", "6", "h_lmr60.f32"])
+    out2 = run(["bbfm_inference", "default", "features_in.f32", "/dev/null", "--CNRdB", "14", "--h_file", "h_lmr60.f32", "--write_CNRdB", "cnr.f32"])
+    h = np.fromfile(str(tmp_path / "h_lmr60.f32"), np.float32); cnr = np.fromfile(str(tmp_path / "cnr.f32"), np.float32)
+    assert np.abs(cnr - (20 * np.log10(h[:cnr.size]) + 14.0)).max() < 1e-3
+    loss = lambda o: float([l for l in o.splitlines() if l.startswith("loss:")][0].split()[1])
+    assert loss(out2) > loss(out)
