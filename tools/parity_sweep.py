@@ -12,7 +12,7 @@ INT_KEYS = ["state_before", "state_after", "nin_before", "nin_after", "ret", "tm
 N = int(os.environ.get("SWEEP_N", "48")); n_mf = 24
 O.build(); m = O.Model()
 rng = np.random.default_rng(int(os.environ.get("SWEEP_SEED", "2026")))
-bad = 0; ties = 0; dties = 0; tties = 0; tot_calls = 0; tot_valid = 0
+bad = 0; ties = 0; dties = 0; tties = 0; sties = 0; tot_calls = 0; tot_valid = 0
 for case in range(N):
     seed = int(rng.integers(1, 1 << 30)); eb = float(rng.uniform(-1.0, 12.0)); fo = float(rng.uniform(-40.0, 40.0))
     chan = ["awgn", "mpp", "mpd", "mpg"][int(rng.integers(0, 4))]
@@ -73,14 +73,23 @@ for case in range(N):
             differ = [i for i in range(len(t["tmax"])) if any(t[k][i] != d[k][i] for k in INT_KEYS)]
             ttie = margin < 3e-7 and int(d["state_before"][i_first]) == 2 and max(differ) < len(t["tmax"]) - 1 and max(differ) - i_first <= 8
             print(f"  (oracle arg-max margin at call {i_first}: {margin:.3e}; calls that differ: {differ})")
+        # rade_snrdB_3k_est is the float32 estimate TRUNCATED to an integer (radae_rxe.py get_snrdB_3k_est -> int(), rade_api.c): the device's estimate is within a few 1e-6 dB of the
+        # oracle's (float32 sums in another order); when the estimate itself is within 1e-5 dB of an integer the truncation can fall on either side.  Accepted as a tie if snr_int is the
+        # ONLY differing output, on calls whose two float estimates agree to 1e-5 dB and lie within 1e-5 dB of that integer boundary (round 6: seen once in 16 seeds, 7.9999986 / 8.0000010)
+        stie = False
+        if first and set(first) == {"snr_int"} and len(t["snr_int"]) == len(d["snr_int"]):
+            calls = [i for i in range(len(t["snr_int"])) if t["snr_int"][i] != d["snr_int"][i]]
+            stie = all(abs(float(t["snrdB_3k_est"][i]) - float(d["snrdB_3k_est"][i])) < 1e-5 and abs(float(d["snrdB_3k_est"][i]) - round(float(d["snrdB_3k_est"][i]))) < 1e-5 for i in calls)
+            print(f"  (snr_int differs on calls {calls}: estimates {[(float(t['snrdB_3k_est'][i]), float(d['snrdB_3k_est'][i])) for i in calls]})")
+        sties += stie
         tties += ttie
-        dties += dtie; ties += tie; bad += not (tie or dtie or ttie)
-        print(f"{'refine near-tie' if tie else ('detect near-tie' if dtie else ('refine tie between timings' if ttie else 'MISMATCH'))} case {case}: seed {seed} {chan} Eb/No {eb!r} dB fo {fo!r} Hz valid {nv}/{len(d['features_out'])} max |fmax diff| {dfm:.4f} first differing call per key {first}")
+        dties += dtie; ties += tie; bad += not (tie or dtie or ttie or stie)
+        print(f"{'refine near-tie' if tie else ('detect near-tie' if dtie else ('refine tie between timings' if ttie else ('snr_int truncation tie' if stie else 'MISMATCH')))} case {case}: seed {seed} {chan} Eb/No {eb!r} dB fo {fo!r} Hz valid {nv}/{len(d['features_out'])} max |fmax diff| {dfm:.4f} first differing call per key {first}")
     eng.close()
-print(f"{N} cases, {tot_calls} receiver calls, {tot_valid} decoded frames: {bad} mismatching case(s), {ties} with a refine() near-tie resolved the other way, {dties} with a detect_pilots arg-max tie (1 ulp) on an unsynchronised call, {tties} with a refine() tie between two timings (oracle margin < 3e-7, traces equal again within 8 calls)")
+print(f"{N} cases, {tot_calls} receiver calls, {tot_valid} decoded frames: {bad} mismatching case(s), {ties} with a refine() near-tie resolved the other way, {dties} with a detect_pilots arg-max tie (1 ulp) on an unsynchronised call, {tties} with a refine() tie between two timings (oracle margin < 3e-7, traces equal again within 8 calls), {sties} with an snr_int truncation tie (estimate within 1e-5 dB of an integer)")
 if os.environ.get("SWEEP_JSON"):
     import json
     json.dump({"tool": "tools/parity_sweep.py", "seed": int(os.environ.get("SWEEP_SEED", "2026")), "cases": N, "receiver_calls": int(tot_calls), "decoded_modem_frames": int(tot_valid),
-               "mismatching_cases": int(bad), "refine_near_tie_cases": int(ties), "detect_argmax_tie_cases": int(dties), "refine_tie_between_timings_cases": int(tties),
+               "mismatching_cases": int(bad), "refine_near_tie_cases": int(ties), "detect_argmax_tie_cases": int(dties), "refine_tie_between_timings_cases": int(tties), "snr_int_truncation_tie_cases": int(sties),
                "rule": "per-call discrete outputs equal and features within 1e-4 RMS; a case whose discrete outputs are all equal but whose fmax differs by < 0.05 Hz is a refine() tie if, in addition, the oracle's own arg-max margin (runner-up cell relative to the winner) at the first differing call is below 3e-7 (two 0.1 Hz bins whose float32 magnitudes are within an ulp: summation order decides); a case whose only differing outputs are (tmax, f_ind_max) of unsynchronised calls whose maxima agree to 1e-6 is a detect_pilots arg-max tie (two of the 38,400 float32 cells within one ulp; FFT convolution and direct sums round differently), every later output being equal again; a case whose first differing call is a synchronised one at which the oracle's own refine() arg-max margin is below 3e-7 (two cells of different timing with equal float32 magnitudes), with the same number of decoded frames and traces that are equal again within 8 calls and to the end, is a refine() tie between timings"},
               open(os.environ["SWEEP_JSON"], "w"), indent=1)
